@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+# coding=utf-8
+"""bench.py -- throughput of Duet's step E/F hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (ef_classify -> ef_seed_sort -> ef_finalize, plus the single
+all-gather of the per-candidate records when N > 1) over one batch of synthetic input that is already
+resident in HBM.  Workload: BASELINE.json configs[1] -- one contig, ~1.0M SV support-read marks,
+200k reads, 100k candidates (duet_amd.synth.bench_contig, seed 1).  With N > 1 every rank owns one
+such contig (contig sharding, weak scaling) and the results are reassembled with one
+all_gather_into_tensor over RCCL.  Rank 0 prints ONE JSON line.
+
+`roofline` prices the dominant kernel (ef_classify): algorithmic bytes per launch
+(12 B/mark + 18 B/candidate in + 5 B/candidate out + 8 B/read) / mean duration from HIP
+events recorded on the launch stream during the timed region / 8 TB/s.
+`cpu_baseline` times oracle/ef_oracle.c (scalar C port, 1 core) on the same arrays, rank 0, N=1.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def classify_bytes(soa):
+    """Algorithmic HBM bytes of one ef_classify launch: mark_read 4 B + gathered tag 8 B per mark;
+    cand_off 4 + svlen 4 + svread 4 + refread 4 + gt_ok 1 in and pred 1 + ps 4 out per candidate;
+    the read-tag table counted once (8 B/read)."""
+    return 12 * soa.n_marks + 22 * soa.n_cands + 8 * soa.n_reads
+
+
+def cpu_baseline(soa, budget_s=10.0):
+    from oracle import c_oracle
+    c_oracle.load()
+    t0 = time.perf_counter()
+    c_oracle.ef(soa, 50, 2)
+    one = time.perf_counter() - t0
+    reps = max(1, min(200, int(budget_s / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c_oracle.ef(soa, 50, 2)
+    dt = (time.perf_counter() - t0) / reps
+    return {'value': soa.n_marks / dt, 'unit': 'marks/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d passes of oracle/ef_oracle.c (scalar C restatement, gcc -O2) over the same %d-mark / '
+                      '%d-candidate arrays; filter+class+seeds+vote+decision only, no text I/O' % (
+                          reps, soa.n_marks, soa.n_cands),
+            'ms_per_pass': dt * 1e3}
+
+
+def python_baseline(contigs, n_cands=4000):
+    """The Python oracle (closest in kind to upstream's own code) on a bounded slice, rows/s only as a
+    side note: it needs the text inputs, so a small work dir is written to a temp dir."""
+    import shutil
+    import tempfile
+    from duet_amd import synth
+    from oracle import ef_oracle
+    small = synth.bench_contig('1', 2 * n_cands, n_cands, 1)
+    home = tempfile.mkdtemp(prefix='duet_bench_')
+    try:
+        synth.write_workdir(home, [small], write_bam=False)
+        t0 = time.perf_counter()
+        ef_oracle.sv_phasing_text(home, 50, 2)
+        dt = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(home, ignore_errors=True)
+    marks = int(small.cand_off[-1])
+    return {'value': marks / dt, 'unit': 'marks/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle/ef_oracle.py (pure Python, text VCF+SAM -> phased_sv.vcf text) on %d marks' % marks}
+
+
+def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, gather):
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one():
+        dp.run(ctx, stream)
+        if gather is not None:
+            gather()
+
+    for _ in range(warmup):
+        one()
+    ctx.check(stream)
+    ctx.set_profiling(True)
+    ctx.profile_collect()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_collect()
+    ctx.set_profiling(False)
+    ctx.check(stream)
+    return dt, prof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the larger single-GPU roofline points')
+    ap.add_argument('--large', action='store_true', help='also run the 2e8-mark single-GPU point')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                     '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d' % (args.gpus, args.gpus))
+        sys.exit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+
+    import torch
+    from duet_amd import _lib, dist, engine, synth
+    from duet_amd.devmem import DeviceProblem
+
+    torch.cuda.set_device(local_rank)
+    dist_mod = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist_mod.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    ctx = _lib.Context(local_rank)
+
+    # ---- workload: one config-2 contig per rank ------------------------------------------------------
+    label = synth.DEFAULT_CONTIGS[rank % len(synth.DEFAULT_CONTIGS)]
+    contig = synth.bench_contig('1', 200000, 100000, 1 + rank, spelled='chr' + label)
+    soa = engine.soa_from_synth([contig])
+    n_max = soa.n_cands                      # every rank has exactly 100000 candidates
+    dp = DeviceProblem(soa, 50, 2, device='cuda:%d' % local_rank, n_cands_max=n_max)
+
+    gather = None
+    if world > 1:
+        def gather():
+            return dist.allgather_records(dp.out_block, world)
+
+    dt, prof = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod, gather)
+
+    # correctness of what was timed (rank-local, against the C oracle) -- outside the timed region
+    pred, ps = dp.results()
+    from oracle import c_oracle
+    rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
+    parity = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
+
+    marks_local = soa.n_marks
+    if world > 1:
+        t = torch.tensor([dt, float(marks_local), float(parity)], dtype=torch.float64, device='cuda')
+        tmax = t.clone()
+        dist_mod.all_reduce(tmax, op=dist_mod.ReduceOp.MAX)
+        tsum = t.clone()
+        dist_mod.all_reduce(tsum, op=dist_mod.ReduceOp.SUM)
+        dt = float(tmax[0])
+        marks_total = float(tsum[1])
+        parity = bool(tsum[2] == world)
+    else:
+        marks_total = float(marks_local)
+
+    if rank == 0:
+        kname = _lib.KERNEL_NAMES[0]
+        k_ms = float(prof.kernel_ms[0])
+        abytes = classify_bytes(soa)
+        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            'metric': 'SV support-read marks clustered+phased /sec; bit-exact phased_sv.vcf vs ref',
+            'value': marks_total * args.steps / dt, 'unit': 'marks/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32/u64 integer + f64 threshold compares',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: synthetic 1 contig per GPU, %d SV marks / %d candidates / '
+                                   '%d tagged reads per contig, resident in HBM; step = classify+seed_sort+finalize%s'
+                                   % (soa.n_marks, soa.n_cands, soa.n_reads,
+                                      ' + one all_gather_into_tensor of 5 B/candidate records' if world > 1 else ''),
+                       'marks_per_gpu': soa.n_marks, 'candidates_per_gpu': soa.n_cands, 'reads_per_gpu': soa.n_reads,
+                       'parallelism': 'contig-sharded x%d' % world, 'svlen_thres': 50, 'suppread_thres': 2},
+            'parity_vs_oracle': parity,
+            'kernels_ms': {n: float(prof.kernel_ms[i]) for i, n in enumerate(_lib.KERNEL_NAMES)},
+            'kernels_total_ms': float(prof.total_ms),
+            'roofline': {'kernel': kname, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': abytes, 'launch_ms': k_ms,
+                         'note': 'config 2 is 14.6 MB per launch (~1.8 us at peak): launch-latency bound; '
+                                 'see extra.* for the bandwidth-bound sizes'},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(soa)
+            out['cpu_baseline_python'] = python_baseline([contig])
+        if world == 1 and not args.no_extra:
+            out['extra'] = extra_points(ctx, torch, engine, synth, DeviceProblem, args.large)
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+    if world > 1:
+        dist_mod.barrier()
+        dist_mod.destroy_process_group()
+    ctx.close()
+
+
+def extra_points(ctx, torch, engine, synth, DeviceProblem, large):
+    """Single-GPU roofline at sizes where the path is bandwidth-bound rather than launch-bound
+    (SURVEY.md section 8d): config 3's 2e7 marks on one GPU, optionally 2e8."""
+    pts = {}
+    sizes = [('config3_1gpu_2e7_marks', 20000000, 24)]
+    if large:
+        sizes.append(('1gpu_2e8_marks', 200000000, 24))
+    for name, marks, _k in sizes:
+        contigs = synth.bench_genome(marks, 3)
+        soa = engine.soa_from_synth(contigs)
+        del contigs
+        dp = DeviceProblem(soa, 50, 2)
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            dp.run(ctx, stream)
+        ctx.check(stream)
+        ctx.set_profiling(True)
+        ctx.profile_collect()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            dp.run(ctx, stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        prof = ctx.profile_collect()
+        ctx.set_profiling(False)
+        ab = classify_bytes(soa)
+        kms = float(prof.kernel_ms[0])
+        pts[name] = {'marks': soa.n_marks, 'candidates': soa.n_cands, 'reads': soa.n_reads,
+                     'contigs': soa.n_contigs, 'ms_per_step': dt * 1e3, 'marks_per_s': soa.n_marks / dt,
+                     'kernels_ms': {k: float(prof.kernel_ms[i]) for i, k in enumerate(('ef_classify', 'ef_seed_sort', 'ef_finalize'))},
+                     'classify_GBs': ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                     'classify_frac_of_8TBs': ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else 0.0,
+                     'pipeline_GBs_B_EF': soa.algorithmic_bytes() / (float(prof.total_ms) * 1e-3) / 1e9
+                     if prof.total_ms > 0 else 0.0}
+        del dp
+        torch.cuda.empty_cache()
+    return pts
+
+
+if __name__ == '__main__':
+    main()

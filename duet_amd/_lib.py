@@ -1,0 +1,186 @@
+# coding=utf-8
+"""ctypes binding of include/duet_ef.h (libduet_ef.so, hand-written HIP for gfx950).
+
+There is deliberately NO CPU fallback: if the shared library is missing or no MI355X is visible,
+every entry point raises.  Build the library with `python -c "import __graft_entry__ as g; g.build()"`
+(or `make -C duet_amd/csrc`).
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libduet_ef.so')
+
+DUET_OK = 0
+DUET_ERR_DIV_ZERO = -5
+MARK_ABSENT = 0xFFFFFFFF
+N_KERNELS = 3
+KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
+
+# every symbol include/duet_ef.h declares (checked by tests/test_abi.py)
+EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
+           'duet_ctx_set_profiling', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
+           'duet_ef_profile_collect', 'duet_ef_get_seed_ps')
+
+
+class EfProblem(ctypes.Structure):
+    _fields_ = [('n_contigs', ctypes.c_uint32), ('n_cands', ctypes.c_uint32), ('n_marks', ctypes.c_uint32),
+                ('n_reads', ctypes.c_uint32),
+                ('cand_ctg_off', ctypes.c_void_p), ('read_tag', ctypes.c_void_p), ('cand_pos', ctypes.c_void_p),
+                ('cand_svlen', ctypes.c_void_p), ('cand_svread', ctypes.c_void_p), ('cand_refread', ctypes.c_void_p),
+                ('cand_gt_ok', ctypes.c_void_p), ('cand_off', ctypes.c_void_p), ('mark_read', ctypes.c_void_p),
+                ('svlen_thres', ctypes.c_uint32), ('suppread_thres', ctypes.c_uint32)]
+
+
+class EfStats(ctypes.Structure):
+    _fields_ = [('algorithmic_bytes', ctypes.c_uint64), ('n_seed_ps', ctypes.c_uint32),
+                ('n_profiled_runs', ctypes.c_uint32), ('kernel_ms', ctypes.c_float * N_KERNELS),
+                ('total_ms', ctypes.c_float)]
+
+
+class DuetLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libduet_ef.so (once). Raises DuetLibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DuetLibraryError('%s is missing: the HIP extension has not been built '
+                               '(run __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.duet_abi_version.restype = ctypes.c_int
+    lib.duet_ctx_create.restype = ctypes.c_void_p
+    lib.duet_ctx_create.argtypes = [ctypes.c_int]
+    lib.duet_ctx_destroy.restype = None
+    lib.duet_ctx_destroy.argtypes = [ctypes.c_void_p]
+    lib.duet_last_error.restype = ctypes.c_char_p
+    lib.duet_last_error.argtypes = [ctypes.c_void_p]
+    lib.duet_ctx_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.duet_ef_run_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfProblem), ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p]
+    lib.duet_ef_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.duet_ef_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfProblem), ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.POINTER(EfStats)]
+    lib.duet_ef_profile_collect.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfStats)]
+    lib.duet_ef_get_seed_ps.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None and a.size else ctypes.c_void_p(0)
+
+
+class Context(object):
+    """One duet_ctx on one HIP device."""
+
+    def __init__(self, device_id=0):
+        self.lib = load()
+        self.handle = self.lib.duet_ctx_create(int(device_id))
+        if not self.handle:
+            raise DuetLibraryError('duet_ctx_create(%d) failed: %s' % (
+                device_id, self.lib.duet_last_error(None).decode('utf-8', 'replace')))
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.duet_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _raise(self, rc):
+        msg = self.lib.duet_last_error(self.handle).decode('utf-8', 'replace')
+        if rc == DUET_ERR_DIV_ZERO:
+            raise ZeroDivisionError('division by zero')        # what upstream raises (sv_phasing_fn.py:123)
+        raise DuetLibraryError('duet_ef call failed (%d): %s' % (rc, msg))
+
+    def set_profiling(self, on):
+        rc = self.lib.duet_ctx_set_profiling(self.handle, 1 if on else 0)
+        if rc:
+            self._raise(rc)
+
+    # -- host arrays ---------------------------------------------------------------------------
+    def run_host(self, soa, svlen_thres, suppread_thres, want_stats=False):
+        """soa: engine.EfSoA with numpy arrays. Returns (pred u8[C], ps u32[C][, stats])."""
+        prob, keep = problem_from_arrays(soa, svlen_thres, suppread_thres)
+        C = soa.n_cands
+        pred = np.zeros(C, dtype=np.uint8)
+        ps = np.zeros(C, dtype=np.uint32)
+        stats = EfStats()
+        rc = self.lib.duet_ef_run_host(self.handle, ctypes.byref(prob), _ptr(pred), _ptr(ps), ctypes.byref(stats))
+        del keep
+        if rc:
+            self._raise(rc)
+        return (pred, ps, stats) if want_stats else (pred, ps)
+
+    # -- device pointers (torch tensors' data_ptr()) -----------------------------------------------
+    def run_device(self, prob, out_pred_ptr, out_ps_ptr, stream=0):
+        rc = self.lib.duet_ef_run_device(self.handle, ctypes.byref(prob), ctypes.c_void_p(out_pred_ptr),
+                                         ctypes.c_void_p(out_ps_ptr), ctypes.c_void_p(stream))
+        if rc:
+            self._raise(rc)
+
+    def check(self, stream=0):
+        rc = self.lib.duet_ef_check(self.handle, ctypes.c_void_p(stream))
+        if rc:
+            self._raise(rc)
+
+    def profile_collect(self):
+        st = EfStats()
+        rc = self.lib.duet_ef_profile_collect(self.handle, ctypes.byref(st))
+        if rc:
+            self._raise(rc)
+        return st
+
+    def seed_ps(self, contig, cap=1 << 20):
+        out = np.zeros(cap, dtype=np.uint32)
+        n = self.lib.duet_ef_get_seed_ps(self.handle, int(contig), _ptr(out), cap)
+        if n < 0:
+            self._raise(n)
+        return out[:min(n, cap)].copy()
+
+
+def clamp_u32(v):
+    v = int(v)
+    return 0 if v < 0 else (0xFFFFFFFF if v > 0xFFFFFFFF else v)
+
+
+def problem_from_arrays(soa, svlen_thres, suppread_thres):
+    """EfProblem over host numpy arrays; returns (problem, keepalive)."""
+    p = EfProblem()
+    p.n_contigs, p.n_cands, p.n_marks, p.n_reads = soa.n_contigs, soa.n_cands, soa.n_marks, soa.n_reads
+    keep = [soa.cand_ctg_off, soa.read_tag, soa.cand_pos, soa.cand_svlen, soa.cand_svread, soa.cand_refread,
+            soa.cand_gt_ok, soa.cand_off, soa.mark_read]
+    (p.cand_ctg_off, p.read_tag, p.cand_pos, p.cand_svlen, p.cand_svread, p.cand_refread, p.cand_gt_ok,
+     p.cand_off, p.mark_read) = [a.ctypes.data if a.size else None for a in keep]
+    p.svlen_thres = clamp_u32(svlen_thres)
+    p.suppread_thres = clamp_u32(suppread_thres)
+    return p, keep
+
+
+def problem_from_device(soa_host, dev_ptrs, svlen_thres, suppread_thres):
+    """EfProblem whose arrays are device pointers (dict name -> int) and cand_ctg_off the host array."""
+    p = EfProblem()
+    p.n_contigs, p.n_cands, p.n_marks, p.n_reads = (soa_host.n_contigs, soa_host.n_cands, soa_host.n_marks,
+                                                    soa_host.n_reads)
+    p.cand_ctg_off = soa_host.cand_ctg_off.ctypes.data
+    for name in ('read_tag', 'cand_pos', 'cand_svlen', 'cand_svread', 'cand_refread', 'cand_gt_ok', 'cand_off',
+                 'mark_read'):
+        setattr(p, name, dev_ptrs[name] or None)
+    p.svlen_thres = clamp_u32(svlen_thres)
+    p.suppread_thres = clamp_u32(suppread_thres)
+    return p

@@ -108,6 +108,7 @@ class SynthContig:
         self.cand_svread = None         # int64[C]
         self.cand_refread = None        # int64[C]
         self.cand_gt = None             # list[str]
+        self.cand_ref_dot = None        # bool[C] or None: print the reference-read field as '.' (parses as 0)
         self.cand_off = None            # int64[C+1]
         self.mark_name_id = None        # int64[M]  name id (>= n_names means a name with no SAM line)
 
@@ -152,20 +153,18 @@ class SynthContig:
             mark_read = np.full(len(self.mark_name_id), -1, dtype=np.int64)
         svlen = self.cand_svlen.copy()
         svlen[svlen == -(1 << 62)] = 0
+        refread = self.cand_refread
+        if self.cand_ref_dot is not None:
+            refread = np.where(self.cand_ref_dot, 0, refread)
         return dict(read_tag=read_tag, cand_pos=self.cand_pos, cand_svlen_abs=np.abs(svlen),
-                    cand_svread=self.cand_svread, cand_refread=self.cand_refread,
+                    cand_svread=self.cand_svread, cand_refread=refread,
                     cand_gt_ok=np.array([g != './.' for g in self.cand_gt], dtype=np.uint8),
                     cand_off=self.cand_off, mark_read=mark_read)
 
 
 def pack_tags(hap, pc, ps):
-    """hap(2 bits) | pc(30 bits) | ps(32 bits) -> uint64 (the device tag word, include/duet_ef.h)."""
-    hap = np.asarray(hap, dtype=np.int64)
-    pc = np.asarray(pc, dtype=np.int64)
-    ps = np.asarray(ps, dtype=np.int64)
-    hcode = np.where((hap == 1) | (hap == 2), hap, 3).astype(np.uint64)
-    pcc = np.minimum(pc, (1 << 30) - 2).astype(np.uint64)
-    return (hcode << np.uint64(62)) | (pcc << np.uint64(32)) | ps.astype(np.uint64)
+    from duet_amd.engine import pack_tags as _pack
+    return _pack(hap, pc, ps)
 
 
 # ------------------------------------------------------------------------------------------
@@ -309,6 +308,7 @@ def fuzz_case(seed, labels=None, n_contigs=3):
         # keep svread + refread > 0 (the reference divides by it, sv_phasing_fn.py:123)
         gsel = rng.below(C, len(_GTS) + 6)
         c.cand_gt = [_GTS[g] if g < len(_GTS) else '0/1' for g in gsel]
+        c.cand_ref_dot = rng.chance(C, 1, 25)
         c.cand_off = off
         c.mark_name_id = mark
         out.append(c)
@@ -322,7 +322,7 @@ def fuzz_case(seed, labels=None, n_contigs=3):
 DIALECTS = ('cutesv', 'sniffles', 'svim')
 
 
-def _info_and_sample(dialect, svtype, svlen, pos, svread, refread, gt, names, rng_bits):
+def _info_and_sample(dialect, svtype, svlen, pos, svread, refread, gt, names, rng_bits, ref_dot=False):
     svlen_s = '.' if svlen == -(1 << 62) else str(int(svlen))
     end = pos + (abs(int(svlen)) if svlen != -(1 << 62) and svtype != 'INS' else 0)
     rn = ','.join(names)
@@ -330,7 +330,7 @@ def _info_and_sample(dialect, svtype, svlen, pos, svread, refread, gt, names, rn
         info = 'PRECISE;SVTYPE=%s;SVLEN=%s;END=%d;CIPOS=-%d,%d;CILEN=-1,1;RE=%d;RNAMES=%s;STRAND=+-' % (
             svtype, svlen_s, end, rng_bits % 7, rng_bits % 5, svread, rn)
         fmt = 'GT:DR:DV:PL:GQ'
-        dr = '.' if (rng_bits % 53 == 0) else str(int(refread))
+        dr = '.' if ref_dot else str(int(refread))
         sample = '%s:%s:%d:%d,%d,%d:%d' % (gt, dr, svread, rng_bits % 97, rng_bits % 13, rng_bits % 89,
                                           rng_bits % 61)
     elif dialect == 'sniffles':
@@ -341,7 +341,7 @@ def _info_and_sample(dialect, svtype, svlen, pos, svread, refread, gt, names, rn
         fmt = 'GT:GQ:DR:DV'
         # NB the reference takes subfield 1 (= GQ) as the "ref read" count for this layout
         # (read_file.py:63-69), so the generator's refread goes there.
-        sample = '%s:%d:%d:%d' % (gt, refread, rng_bits % 40, svread)
+        sample = '%s:%s:%d:%d' % (gt, '.' if ref_dot else str(int(refread)), rng_bits % 40, svread)
     elif dialect == 'svim':
         info = 'SVTYPE=%s;END=%d;SVLEN=%s;SUPPORT=%d;STD_SPAN=%d.5;STD_POS=%d.25;READS=%s' % (
             svtype, end, svlen_s, svread, rng_bits % 17, rng_bits % 19, rn)
@@ -349,7 +349,7 @@ def _info_and_sample(dialect, svtype, svlen, pos, svread, refread, gt, names, rn
         if gt == './.':
             sample = './.:.:.,.'
         else:
-            sample = '%s:%d:%d,%d' % (gt, refread + svread, refread, svread)
+            sample = '%s:%d:%s,%d' % (gt, refread + svread, '.' if ref_dot else str(int(refread)), svread)
     else:
         raise ValueError('unknown dialect ' + dialect)
     return info, fmt, sample
@@ -382,7 +382,8 @@ def write_vcf(path, contigs, dialect='cutesv', header_contigs=None, extra_contig
             svtype = c.cand_svtype[j]
             info, fmt, sample = _info_and_sample(dialect, svtype, int(c.cand_svlen[j]), int(c.cand_pos[j]),
                                                  int(c.cand_svread[j]), int(c.cand_refread[j]),
-                                                 c.cand_gt[j], names, int(bits[j]))
+                                                 c.cand_gt[j], names, int(bits[j]),
+                                                 bool(c.cand_ref_dot[j]) if c.cand_ref_dot is not None else False)
             alt = '<%s>' % svtype
             ref = 'N'
             if dialect == 'cutesv' and svtype in ('INS', 'DEL') and (int(bits[j]) & 3) == 0:

@@ -1,0 +1,136 @@
+/*
+ * duet_ef.h -- C ABI of the MI355X (gfx950) implementation of Duet's step E/F:
+ * integration of read-haplotype tags with SV support-read marks, per-candidate haplotype vote and
+ * the T1-T5 threshold decision.
+ *
+ * The reference (yekaizhou/duet v0.6) is pure Python and has no FFI; the seam this library sits
+ * behind is the body of
+ *     generate_phased_callset(vcf_path, sam_home, svlen_thres, suppread_thres, thread, include_all_ctgs)
+ *                                                                   src/duet/sv_phasing_fn.py:185-230
+ * between "callset built" (generate_callinfo, :36-68) and "rows sorted" (:229):
+ *     filter            sv_phasing_fn.py:189-190
+ *     PS-class          sv_phasing_fn.py:191-194
+ *     seed sets         sv_phasing_fn.py:195-203
+ *     vote + features   sv_phasing_fn.py:70-140   (get_phase_info)
+ *     decision          sv_phasing_fn.py:142-183  (predict_hp)
+ *     contig drop       sv_phasing_fn.py:209-210
+ * and the join of mark names against the per-contig tag dict (:46-48), which the host performs
+ * while flattening names to indices.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; no exception crosses the ABI; every
+ * call returns DUET_OK (0) or a negative duet_status and duet_last_error() describes the failure.
+ * A context is driven by one host thread at a time.
+ */
+#ifndef DUET_EF_H
+#define DUET_EF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUET_ABI_VERSION 1
+
+typedef enum duet_status {
+    DUET_OK = 0,
+    DUET_ERR_INVALID = -1,    /* bad argument (NULL pointer, inconsistent sizes) */
+    DUET_ERR_NO_DEVICE = -2,  /* no usable gfx950 device / HIP runtime failure at context creation */
+    DUET_ERR_HIP = -3,        /* a HIP call failed; duet_last_error has hipGetErrorString */
+    DUET_ERR_OOM = -4,        /* device allocation failed */
+    DUET_ERR_DIV_ZERO = -5    /* a candidate that reaches the decision has svread + refread == 0: the
+                                 reference raises ZeroDivisionError there (sv_phasing_fn.py:123) */
+} duet_status;
+
+/*
+ * Read tag word (one per read that is in its contig's tag dict, sv_phasing_fn.py:28-29):
+ *     bits 63..62  hap   1 or 2 (HP:i); 3 = any other value (never counted as a haplotype vote)
+ *     bits 61..32  pc    PC:i, saturated at 2^30-2 (only `pc <= 8100` and sums of such pc are used)
+ *     bits 31..0   ps    PS:i
+ */
+#define DUET_TAG(hap, pc, ps) (((uint64_t)(hap) << 62) | ((uint64_t)(pc) << 32) | (uint64_t)(uint32_t)(ps))
+#define DUET_MARK_ABSENT 0xFFFFFFFFu   /* mark whose read name is not in its contig's tag dict */
+#define DUET_PC_MAX 8100u              /* sv_phasing_fn.py:76,88,201 */
+
+/*
+ * One E/F problem in structure-of-arrays form.  Candidates are in callset order
+ * (generate_callinfo, sv_phasing_fn.py:50-67): contig-major in chrom-list order, file order inside a
+ * contig; cand_ctg_off[k]..cand_ctg_off[k+1] are the candidates of contig k.
+ * Marks of candidate c are mark_read[cand_off[c] .. cand_off[c+1]) in RNAMES/READS list order
+ * (duplicates kept), each an index into read_tag (already resolved against the candidate's OWN
+ * contig table, sv_phasing_fn.py:47-48) or DUET_MARK_ABSENT.  Every candidate has >= 1 mark.
+ *
+ * cand_ctg_off is ALWAYS a host pointer (K+1 small integers; the library stages it).  The other
+ * arrays are device pointers for duet_ef_run_device and host pointers for duet_ef_run_host.
+ */
+typedef struct duet_ef_problem {
+    uint32_t n_contigs;             /* K */
+    uint32_t n_cands;               /* C */
+    uint32_t n_marks;               /* M = cand_off[C] */
+    uint32_t n_reads;               /* R = length of read_tag */
+    const uint32_t *cand_ctg_off;   /* [K+1] HOST */
+    const uint64_t *read_tag;       /* [R]   */
+    const uint32_t *cand_pos;       /* [C]   VCF POS */
+    const uint32_t *cand_svlen;     /* [C]   abs(SVLEN) (sv_phasing_fn.py:62) */
+    const uint32_t *cand_svread;    /* [C]   INFO support count (read_file.py:40-47) */
+    const uint32_t *cand_refread;   /* [C]   reference-read count as the reference derives it (read_file.py:56-76) */
+    const uint8_t *cand_gt_ok;      /* [C]   1 unless the genotype string is exactly "./." (sv_phasing_fn.py:190) */
+    const uint32_t *cand_off;       /* [C+1] CSR offsets into mark_read */
+    const uint32_t *mark_read;      /* [M]   */
+    uint32_t svlen_thres;           /* -s / --sv_min_size */
+    uint32_t suppread_thres;        /* -r / --min_support_read */
+} duet_ef_problem;
+
+/* Kernels of one run, in launch order. */
+enum { DUET_K_CLASSIFY = 0, DUET_K_SEEDS = 1, DUET_K_FINALIZE = 2, DUET_N_KERNELS = 3 };
+
+typedef struct duet_ef_stats {
+    uint64_t algorithmic_bytes;     /* 12*M + 27*C + 8*R */
+    uint32_t n_seed_ps;             /* distinct seed phase sets over all contigs (valid after a host run) */
+    uint32_t n_profiled_runs;       /* runs averaged into kernel_ms (profiling mode only) */
+    float kernel_ms[DUET_N_KERNELS];/* mean duration per kernel from HIP events on the run's stream */
+    float total_ms;                 /* mean first-kernel-start to last-kernel-end */
+} duet_ef_stats;
+
+typedef struct duet_ctx duet_ctx;
+
+int duet_abi_version(void);
+
+/* Context on HIP device `device_id`. NULL on failure; duet_last_error(NULL) then holds the reason. */
+duet_ctx *duet_ctx_create(int device_id);
+void duet_ctx_destroy(duet_ctx *ctx);
+const char *duet_last_error(const duet_ctx *ctx);
+
+/* 1: bracket every kernel with HIP events on the run's stream (resolved by duet_ef_profile_collect). */
+int duet_ctx_set_profiling(duet_ctx *ctx, int enabled);
+
+/*
+ * Run E/F on device-resident inputs, asynchronously on `stream` (a hipStream_t passed as void*, NULL =
+ * the null stream).  out_pred[C] (0 = filtered, 1 = "1|0", 2 = "0|1", 3 = "1|1") and out_ps[C] are
+ * device pointers.  out_ps[c] is the PS predict_hp returns when the reference calls it for c, else 0.
+ * The call does not synchronise; DUET_ERR_DIV_ZERO is reported by duet_ef_check (or by the host run).
+ */
+int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pred, uint32_t *out_ps,
+                       void *stream);
+
+/* Synchronise `stream` and return the deferred status of the runs issued on this context since the
+ * last check (DUET_OK or DUET_ERR_DIV_ZERO / DUET_ERR_HIP). */
+int duet_ef_check(duet_ctx *ctx, void *stream);
+
+/* Host convenience: copies the arrays to the device, runs, copies the results back, synchronises.
+ * stats may be NULL. */
+int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pred, uint32_t *out_ps,
+                     duet_ef_stats *stats);
+
+/* Profiling mode: synchronise, average the per-kernel event timings of the runs since the last
+ * collect into *stats, and reset. */
+int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
+
+/* Debug/inspection: copy contig k's sorted seed-PS array of the LAST run to `out` (capacity `cap`),
+ * return its length (or a negative status). */
+int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUET_EF_H */

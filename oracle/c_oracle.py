@@ -1,0 +1,46 @@
+# coding=utf-8
+"""TEST INFRASTRUCTURE ONLY -- ctypes loader of oracle/_build/libef_oracle.so (the scalar C
+restatement in ef_oracle.c). Same rules as ef_oracle.py: never imported by the product path."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, '_build', 'libef_oracle.so')
+_lib = None
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', HERE])
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            build()
+        _lib = ctypes.CDLL(SO)
+        _lib.duet_oracle_ef.restype = ctypes.c_int
+        _lib.duet_oracle_ef.argtypes = [ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_void_p] * 9 + \
+            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data if a.size else 0)
+
+
+def ef(soa, svlen_thres, suppread_thres):
+    """soa: any object with the EfSoA attributes. -> (rc, pred u8[C], ps u32[C])"""
+    lib = load()
+    C = soa.n_cands
+    pred = np.zeros(max(C, 1), dtype=np.uint8)
+    ps = np.zeros(max(C, 1), dtype=np.uint32)
+    clamp = lambda v: 0 if v < 0 else min(int(v), 0xFFFFFFFF)
+    rc = lib.duet_oracle_ef(soa.n_contigs, C, _p(soa.read_tag), _p(soa.cand_ctg_off), _p(soa.cand_pos),
+                            _p(soa.cand_svlen), _p(soa.cand_svread), _p(soa.cand_refread), _p(soa.cand_gt_ok),
+                            _p(soa.cand_off), _p(soa.mark_read), clamp(svlen_thres), clamp(suppread_thres),
+                            _p(pred), _p(ps))
+    return rc, pred[:C], ps[:C]

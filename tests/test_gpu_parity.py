@@ -1,0 +1,173 @@
+# coding=utf-8
+"""-m gpu: the HIP path through the C ABI against the oracles and the reference goldens.
+Bit-exact: pred (u8) and ps (u32) per candidate, and the bytes of phased_sv.vcf."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from duet_amd import _lib, engine, synth
+from duet_amd.sv_phasing import sv_phasing
+from oracle import c_oracle
+from tests import helpers as H
+from tests import soa_fuzz
+from tests.test_c_oracle import materialise_bams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def check_against_c_oracle(ctx, soa, svlen_thres=50, suppread_thres=2):
+    rc, want_pred, want_ps = c_oracle.ef(soa, svlen_thres, suppread_thres)
+    assert rc == 0
+    pred, ps = ctx.run_host(soa, svlen_thres, suppread_thres)
+    bad = np.nonzero((pred != want_pred) | (ps != want_ps))[0]
+    assert bad.size == 0, 'first mismatches at %s: got %s/%s want %s/%s' % (
+        bad[:5], pred[bad[:5]], ps[bad[:5]], want_pred[bad[:5]], want_ps[bad[:5]])
+    return pred, ps
+
+
+def run_product(home, svlen_thres, suppread_thres):
+    sv_phasing(home, svlen_thres, suppread_thres, 4, False)
+    with open(os.path.join(home, 'phased_sv.vcf')) as f:
+        return f.read()
+
+
+@pytest.mark.parametrize('name,src,params', H.full_cases(), ids=[c[0] for c in H.full_cases()])
+def test_golden_cases_bytes(name, src, params, tmp_path):
+    home = str(tmp_path / name)
+    shutil.copytree(src, home)
+    os.remove(os.path.join(home, 'phased_sv.vcf'))
+    materialise_bams(home)
+    with open(os.path.join(src, 'phased_sv.vcf')) as f:
+        want = f.read()
+    assert run_product(home, params['svlen_thres'], params['suppread_thres']) == want
+
+
+def test_seeded_cases_sha(tmp_path):
+    for p in H.seeded_plan():
+        if p['kind'] == 'config2':
+            continue
+        home = str(tmp_path / ('%s_%d_%s' % (p['kind'], p['seed'], p['dialect'])))
+        H.build_case(home, p['kind'], p['seed'], p['dialect'], write_sam=False)
+        got = run_product(home, p['svlen_thres'], p['suppread_thres'])
+        assert H.sha256_bytes(got.encode()) == p['output_sha256'], p
+        shutil.rmtree(home)
+
+
+def test_config2_text_sha(tmp_path):
+    """BASELINE config 2 (1 contig, ~1M marks / 200k reads / 100k candidates) through the whole
+    product path, byte-identical to the reference's phased_sv.vcf (sha256 captured in make_golden)."""
+    plan = [p for p in H.seeded_plan() if p['kind'] == 'config2']
+    assert plan, 'config2 golden missing'
+    p = plan[0]
+    home = str(tmp_path / 'config2')
+    H.build_case(home, 'config2', p['seed'], p['dialect'], write_sam=False)
+    got = run_product(home, p['svlen_thres'], p['suppread_thres'])
+    assert sum(1 for l in got.splitlines() if not l.startswith('#')) == p['rows']
+    assert H.sha256_bytes(got.encode()) == p['output_sha256']
+
+
+def test_config2_soa_vs_oracle(ctx):
+    soa = engine.soa_from_synth(H.case_contigs('config2', 1))
+    assert 990000 < soa.n_marks < 1010000 and soa.n_cands == 100000
+    pred, _ = check_against_c_oracle(ctx, soa)
+    assert 40000 < int((pred != 0).sum()) < 60000
+
+
+def test_config3_shape_soa_vs_oracle(ctx):
+    """24 contigs, 2e6 marks (a tenth of config 3; the full size runs in bench.py)."""
+    soa = engine.soa_from_synth(synth.bench_genome(2000000, 3))
+    assert soa.n_contigs == 24
+    check_against_c_oracle(ctx, soa)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_fuzz_soa(ctx, seed):
+    soa = soa_fuzz.random_soa(seed, n_contigs=1 + seed % 5, sorted_pos=bool(seed % 3))
+    check_against_c_oracle(ctx, soa, 50, 2)
+    check_against_c_oracle(ctx, soa, 0, 0)
+    check_against_c_oracle(ctx, soa, 52, 4)
+
+
+def test_long_candidates_cross_lds_chunks(ctx):
+    """Candidates with more marks than one LDS pass holds (4096) and than a whole workgroup's pass."""
+    soa = soa_fuzz.random_soa(101, n_contigs=2, cands_per_contig=(300, 600), reads_per_contig=(500, 900),
+                              big_deg=9000, empty_contig_rate=0, no_seed_contig_rate=0)
+    assert int(np.diff(soa.cand_off.astype(np.int64)).max()) == 9000
+    check_against_c_oracle(ctx, soa)
+
+
+def test_many_seed_sets_global_sort(ctx):
+    """> 16384 distinct seed PS in one contig: the seed sort leaves LDS for the in-HBM network."""
+    soa = soa_fuzz.random_soa(202, n_contigs=1, cands_per_contig=(150000, 150000), reads_per_contig=(100000, 100000),
+                              n_ps=(60000, 60000), ps_spread=4000000, deg=(1, 2), empty_contig_rate=0,
+                              no_seed_contig_rate=0, sorted_pos=False)
+    check_against_c_oracle(ctx, soa)
+    assert ctx.seed_ps(0).size > 16384
+    s = ctx.seed_ps(0)
+    assert np.all(s[1:] > s[:-1])
+
+
+def test_many_contigs(ctx):
+    """-a style contig universe: thousands of small contigs, many empty or seedless."""
+    soa = soa_fuzz.random_soa(303, n_contigs=3000, cands_per_contig=(0, 12), reads_per_contig=(4, 30), n_ps=(1, 3),
+                              empty_contig_rate=3, no_seed_contig_rate=4)
+    check_against_c_oracle(ctx, soa)
+
+
+def test_plan_reuse_and_relayout(ctx):
+    """Back-to-back runs on one context: same layout (self-cleaning hash set), then a different one."""
+    a = soa_fuzz.random_soa(7, n_contigs=4)
+    b = soa_fuzz.random_soa(8, n_contigs=2)
+    for soa in (a, a, b, a, b, b):
+        check_against_c_oracle(ctx, soa)
+
+
+def test_division_by_zero_is_reported(ctx):
+    soa = soa_fuzz.random_soa(9, n_contigs=2, allow_divzero=True, empty_contig_rate=0, no_seed_contig_rate=0)
+    rc, _, _ = c_oracle.ef(soa, 50, 0)
+    assert rc == -5
+    with pytest.raises(ZeroDivisionError):
+        ctx.run_host(soa, 50, 0)
+    # with -r 2 such candidates never reach the decision (svread = 0 < 2), as upstream
+    check_against_c_oracle(ctx, soa, 50, 2)
+
+
+def test_device_pointer_entry_unaligned_marks(ctx):
+    """duet_ef_run_device on torch-owned buffers; mark_read deliberately 4-byte (not 16-byte) aligned
+    so the scalar staging variant of ef_classify runs too."""
+    import torch
+    from duet_amd.devmem import DeviceProblem
+    soa = soa_fuzz.random_soa(11, n_contigs=3, cands_per_contig=(300, 500))
+    rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
+    for mis in (4, 0):
+        dp = DeviceProblem(soa, 50, 2, misalign_marks=mis)
+        assert (dp.problem.mark_read % 16 != 0) == bool(mis)
+        torch.cuda.synchronize()
+        stream = dp.run(ctx)
+        ctx.check(stream)
+        pred, ps = dp.results()
+        assert np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps)
+
+
+def test_idempotent_and_linear_in_contigs(ctx):
+    """Size-independent properties at the full config-2 size: running twice gives the same bytes;
+    a problem made of two copies of a contig gives each copy the single-contig answer."""
+    one = H.case_contigs('config2', 1)
+    soa1 = engine.soa_from_synth(one)
+    p1, s1 = ctx.run_host(soa1, 50, 2)
+    p1b, s1b = ctx.run_host(soa1, 50, 2)
+    assert np.array_equal(p1, p1b) and np.array_equal(s1, s1b)
+    soa2 = engine.soa_from_synth(one + one)
+    p2, s2 = ctx.run_host(soa2, 50, 2)
+    C = soa1.n_cands
+    assert np.array_equal(p2[:C], p1) and np.array_equal(p2[C:], p1)
+    assert np.array_equal(s2[:C], s1) and np.array_equal(s2[C:], s1)
