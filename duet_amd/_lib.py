@@ -56,6 +56,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DuetLibraryError('%s is missing: the HIP extension has not been built '
                                '(run __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64 and loads
+    # them by unversioned name, so if this library pulled in /opt/rocm's copy first, torch would load a
+    # second runtime and find no GPU.  Importing torch first makes the loader bind our DT_NEEDED
+    # libamdhip64.so.7 to the copy torch already mapped (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.duet_abi_version.restype = ctypes.c_int
     lib.duet_ctx_create.restype = ctypes.c_void_p
