@@ -40,13 +40,18 @@ constexpr uint32_t kPcMax = DUET_PC_MAX;
 
 // provisional code written by ef_classify into out_pred; values < 4 are already final
 constexpr uint8_t kNeedNearest = 4;               // ps must become nearest(oneps, pos)
-constexpr uint8_t kClass2 = 8;                    // multi-PS candidate: evaluated in ef_finalize
+constexpr uint8_t kClass2 = 8;                    // multi-PS candidate with a group summary (out_ps = slot)
+constexpr uint8_t kClass2Slow = 16;               // multi-PS candidate without one: ef_finalize re-gathers
 constexpr uint8_t kDivZero = 32;                  // kept candidate with svread + refread == 0
 
 constexpr int kCandPerBlock = 256;
 constexpr int kChunk = 4096;                      // marks staged in LDS per pass (32 KiB of tags)
 constexpr int kSortThreads = 1024;
-constexpr uint32_t kSortLds = 16384;              // seeds sorted in LDS (64 KiB)
+constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB)
+constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
+constexpr uint32_t kC2Quota = 32;                 // group-summary slots per classify block
+constexpr int kC2Groups = 4;                      // voter groups kept per summary
+constexpr int kC2Words = 2 + 6 * kC2Groups;       // allhap, ng, then {ps, n, n1, n2, t1, t2} per group
 
 struct Vote {
     uint32_t hap1, hap2, hap0, allhap;
@@ -111,21 +116,25 @@ struct Params {
     const uint8_t *cand_gt_ok;
     const uint32_t *cand_off, *mark_read;
     uint32_t svlen_thres, suppread_thres;
-    // workspace
+    // workspace (plan-time constants)
     const uint32_t *ctg_off;          // [K+1] device copy of cand_ctg_off
-    const uint32_t *tab_off;          // [K]   first slot of contig k's hash set
-    const uint32_t *tab_mask;         // [K]   slots-1 (power of two)
-    uint32_t *tab;                    // hash slots, kEmpty when free
-    uint32_t *seed_cnt;               // [K]   distinct seeds inserted so far
-    uint32_t *seedbuf;                // [C]   per contig (at ctg_off[k]): slot list, then sorted seeds
-    uint32_t *n_one;                  // [K]   length of contig k's sorted seed array
+    const uint8_t *ctg_start;         // [C]   1 where a candidate is the first of its contig
+    const uint32_t *blk_ctg;          // [B]   contig of candidate 256*b
+    // workspace (per run)
+    uint32_t *blk_cnt;                // [B]   seed entries emitted by classify block b
+    uint64_t *seed_ent;               // [B*256] (candidate << 32 | seed PS), compacted per block
+    uint32_t *onebuf;                 // [C]   per contig (at ctg_off[k]): ascending distinct seed PS
+    uint32_t *tmpbuf;                 // [C]   scratch of the out-of-LDS seed sort
+    uint32_t *n_one;                  // [K]   length of contig k's seed array
+    uint32_t *c2rec;                  // [B*kC2Quota*kC2Words] group summaries of multi-PS candidates
     uint32_t *status;                 // [0] = div-zero flag
     uint8_t *out_pred;
     uint32_t *out_ps;
+    uint32_t dbg;                     // diagnostic ablation bits (0 in production)
 };
 
 // ---------------------------------------------------------------------------------------------
-// kernel 1
+// kernel 1: join + filter + PS-class + seeds + one-PS vote/decision + multi-PS group summaries
 // ---------------------------------------------------------------------------------------------
 
 template <bool VEC>
@@ -134,32 +143,42 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
     __shared__ uint64_t s_tag[kChunk];
     __shared__ uint32_t s_off[kCandPerBlock + 1];
     __shared__ uint32_t s_seed[kCandPerBlock];
+    __shared__ uint32_t s_wcnt[kCandPerBlock / 64], s_wlast[kCandPerBlock / 64], s_wclean[kCandPerBlock / 64];
+    __shared__ uint32_t s_c2n;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t c0 = blockIdx.x * kCandPerBlock;
     const uint32_t nc = min((uint32_t)kCandPerBlock, p.C - c0);
     for (uint32_t i = tid; i <= nc; i += kCandPerBlock) s_off[i] = p.cand_off[c0 + i];
+    if (tid == 0) s_c2n = 0;
 
     // candidate scalars, coalesced
     const bool live = tid < nc;
     const uint32_t c = c0 + tid;
-    uint32_t svlen = 0, svread = 0, refread = 0, gt_ok = 0;
+    uint32_t svlen = 0, svread = 0, refread = 0, gt_ok = 0, is_start = 0;
     if (live) {
         svlen = p.cand_svlen[c];
         svread = p.cand_svread[c];
         refread = p.cand_refread[c];
         gt_ok = p.cand_gt_ok[c];
+        is_start = p.ctg_start[c];
     }
+    const bool kept = live && svlen >= p.svlen_thres && svread >= p.suppread_thres && gt_ok != 0;   // :189-190
+    const bool divzero = kept && ((uint64_t)svread + (uint64_t)refread == 0);
+    const bool active = kept && !divzero;
     __syncthreads();
     const uint32_t m_begin = s_off[0], m_end = s_off[nc];
     const uint32_t my_b = live ? s_off[tid] : 0, my_e = live ? s_off[tid + 1] : 0;
 
     // per-candidate running state over marks in list order
     uint32_t n_ps = 0, first_ps = 0;          // distinct PS among tagged marks: 0, 1, 2(=many)
-    uint32_t seed = kEmpty;                   // PS of first voter
+    uint32_t seed = kEmpty;                   // PS of first voter (:199-203)
     uint32_t last_ps = 0;                     // PS of last voter (:77)
-    uint32_t h1 = 0, h2 = 0;
-    uint64_t t1 = 0, t2 = 0;
+    uint32_t h1 = 0, h2 = 0, t1 = 0, t2 = 0;  // per-chunk partial sums (<= 4096 * 8100)
+    uint64_t T1 = 0, T2 = 0;
+    uint8_t code = 0;
+    uint32_t ps_out = 0;
+    bool c2_done = false;
 
     const uint32_t base = VEC ? (m_begin & ~3u) : m_begin;
     for (uint32_t cs = base; cs < m_end; cs += kChunk) {
@@ -205,79 +224,153 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
             }
         }
         __syncthreads();
-        // ---- consume: each thread walks its candidate's part of this chunk --------------------
-        const uint32_t lo = max(my_b, cs);
+        // ---- consume: each thread walks its candidate's part of this chunk (branch-light) ------
+        uint32_t lo = max(my_b, cs);
         const uint32_t hi = min(my_e, cs + (uint32_t)kChunk);
+        if (!active || (p.dbg & 4)) lo = hi;
         for (uint32_t m = lo; m < hi; ++m) {
             const uint64_t tag = s_tag[m - cs];
-            if (tag == kUntagged) continue;
-            const uint32_t ps = tag_ps(tag);
-            if (n_ps == 0) { n_ps = 1; first_ps = ps; }
-            else if (ps != first_ps) n_ps = 2;
-            const uint32_t pc = tag_pc(tag);
-            if (pc <= kPcMax) {
-                if (seed == kEmpty) seed = ps;
-                last_ps = ps;
-                const uint32_t hap = tag_hap(tag);
-                if (hap == 1) { ++h1; t1 += pc; }
-                else if (hap == 2) { ++h2; t2 += pc; }
+            const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
+            const bool tagged = w != 0xFFFFFFFFu;           // an absent mark is all ones
+            const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
+            const bool voter = pc <= kPcMax;                // absent marks have pc = 2^30-1: never voters
+            const bool fresh = tagged && n_ps == 0;
+            first_ps = fresh ? ps : first_ps;
+            n_ps = tagged ? (ps != first_ps ? 2u : max(n_ps, 1u)) : n_ps;
+            seed = (voter && seed == kEmpty) ? ps : seed;
+            last_ps = voter ? ps : last_ps;
+            const bool v1 = voter && hap == 1, v2 = voter && hap == 2;
+            h1 += v1; t1 += v1 ? pc : 0u;
+            h2 += v2; t2 += v2 ? pc : 0u;
+        }
+        T1 += t1; T2 += t2; t1 = 0; t2 = 0;
+        // ---- multi-PS candidate that lies entirely in this chunk: summarise its voter groups -------
+        // (first-seen order, sv_phasing_fn.py:85-98) so that ef_finalize needs no second gather
+        if (active && n_ps == 2 && !c2_done && my_b >= cs && my_e <= cs + (uint32_t)kChunk) {
+            c2_done = true;
+            uint32_t g_ps[kC2Groups], g_n[kC2Groups], g_n1[kC2Groups], g_n2[kC2Groups], g_t1[kC2Groups], g_t2[kC2Groups];
+#pragma unroll
+            for (int k = 0; k < kC2Groups; ++k) { g_ps[k] = 0; g_n[k] = 0; g_n1[k] = 0; g_n2[k] = 0; g_t1[k] = 0; g_t2[k] = 0; }
+            uint32_t ng = 0, allhap = 0;
+            bool overflow = false;
+            for (uint32_t m = my_b; m < my_e; ++m) {
+                const uint64_t tag = s_tag[m - cs];
+                const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
+                const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
+                if (pc > kPcMax) continue;
+                ++allhap;
+                int idx = -1;
+#pragma unroll
+                for (int k = 0; k < kC2Groups; ++k) if ((uint32_t)k < ng && g_ps[k] == ps) idx = k;
+                if (idx < 0) {
+                    if (ng == kC2Groups) { overflow = true; continue; }
+                    idx = (int)ng++;
+                }
+#pragma unroll
+                for (int k = 0; k < kC2Groups; ++k) {
+                    const bool hit = k == idx;
+                    g_ps[k] = hit ? ps : g_ps[k];
+                    g_n[k] += hit;
+                    g_n1[k] += hit && hap == 1;
+                    g_n2[k] += hit && hap == 2;
+                    g_t1[k] += (hit && hap == 1) ? pc : 0u;
+                    g_t2[k] += (hit && hap == 2) ? pc : 0u;
+                }
+            }
+            const uint32_t rank = overflow ? kC2Quota : atomicAdd(&s_c2n, 1u);
+            if (rank < kC2Quota) {
+                const uint32_t slot = blockIdx.x * kC2Quota + rank;
+                uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
+                rec[0] = allhap;
+                rec[1] = ng;
+#pragma unroll
+                for (int k = 0; k < kC2Groups; ++k) {
+                    if ((uint32_t)k < ng) {
+                        rec[2 + 6 * k + 0] = g_ps[k]; rec[2 + 6 * k + 1] = g_n[k];
+                        rec[2 + 6 * k + 2] = g_n1[k]; rec[2 + 6 * k + 3] = g_n2[k];
+                        rec[2 + 6 * k + 4] = g_t1[k]; rec[2 + 6 * k + 5] = g_t2[k];
+                    }
+                }
+                code = kClass2;
+                ps_out = slot;
             }
         }
         __syncthreads();
     }
 
     // ---- per-candidate result ------------------------------------------------------------------
-    uint8_t code = 0;
-    uint32_t ps_out = 0;
     bool want_seed = false;
     if (live) {
-        const bool kept = svlen >= p.svlen_thres && svread >= p.suppread_thres && gt_ok != 0;      // :189-190
-        if (kept) {
+        if (divzero) {
+            code = kDivZero;
+        } else if (active) {
             want_seed = (n_ps == 1) && seed != kEmpty;                                             // :198-203
-            if ((uint64_t)svread + (uint64_t)refread == 0) {
-                code = kDivZero;
-            } else if (n_ps == 2) {
-                code = kClass2;
+            if (n_ps == 2) {
+                if (code != kClass2) code = kClass2Slow;        // no summary: ef_finalize re-gathers
             } else {
                 Vote v;
-                v.hap1 = n_ps ? h1 : 0; v.hap2 = n_ps ? h2 : 0; v.hap0 = 0;
-                v.allhap = v.hap1 + v.hap2;
-                v.t1 = n_ps ? t1 : 0; v.t2 = n_ps ? t2 : 0;
-                code = (uint8_t)decide((int)n_ps, v, my_e - my_b, svread, refread);
+                v.hap1 = h1; v.hap2 = h2; v.hap0 = 0;
+                v.allhap = h1 + h2;
+                v.t1 = T1; v.t2 = T2;
+                code = (p.dbg & 2) ? 0 : (uint8_t)decide((int)n_ps, v, my_e - my_b, svread, refread);
                 ps_out = last_ps;
-                if (n_ps == 0 || (v.hap1 == 0 && v.hap2 == 0)) code |= kNeedNearest;               // :106
+                if (n_ps == 0 || (h1 == 0 && h2 == 0)) code |= kNeedNearest;                       // :106
             }
         }
         p.out_pred[c] = code;
         p.out_ps[c] = ps_out;
     }
 
-    // ---- seed set insertion (neighbour-deduplicated) -------------------------------------------
+    // ---- seeds of this block, compacted.  A seed equal to the seed of the previous seed-bearing
+    // candidate is dropped, unless a contig starts in between (seed sets are per contig).  Only the
+    // set matters downstream, so dropping duplicates early just shortens ef_seed_sort's input.
+    if (p.dbg & 1) want_seed = false;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long wmask = __ballot(want_seed);
+    const unsigned long long smask = __ballot(is_start != 0);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);    // lanes 0..lane
     s_seed[tid] = want_seed ? seed : kEmpty;
     __syncthreads();
-    if (want_seed) {
-        const uint32_t k = find_contig(p.ctg_off, p.K, c);
-        const bool same_as_prev = tid > 0 && s_seed[tid - 1] == seed && (c - 1) >= p.ctg_off[k];
-        if (!same_as_prev) {
-            const uint32_t mask = p.tab_mask[k];
-            uint32_t *tab = p.tab + p.tab_off[k];
-            uint32_t slot = (seed * 2654435761u) & mask;
-            for (;;) {
-                const uint32_t old = atomicCAS(&tab[slot], kEmpty, seed);
-                if (old == kEmpty) {
-                    const uint32_t idx = atomicAdd(&p.seed_cnt[k], 1u);
-                    p.seedbuf[p.ctg_off[k] + idx] = p.tab_off[k] + slot;
-                    break;
-                }
-                if (old == seed) break;
-                slot = (slot + 1) & mask;
-            }
+    if (lane == 0) {
+        if (wmask) {
+            const uint32_t li = 63u - (uint32_t)__clzll(wmask);
+            s_wlast[wave] = s_seed[wave * 64 + li];
+            s_wclean[wave] = (li == 63 || (smask >> (li + 1)) == 0) ? 1u : 0u;   // no contig start after it
+        } else {
+            s_wlast[wave] = kEmpty;
+            s_wclean[wave] = 0;
         }
     }
+    __syncthreads();
+    bool keep = want_seed;
+    if (want_seed) {
+        const unsigned long long lower = wmask & (upto >> 1);                   // seed lanes below this one
+        if (lower) {
+            const uint32_t pl = 63u - (uint32_t)__clzll(lower);
+            const unsigned long long between = smask & upto & ~((1ull << (pl + 1)) - 1ull);   // starts in (pl, lane]
+            keep = !(between == 0 && s_seed[wave * 64 + pl] == seed);
+        } else if (wave > 0) {
+            keep = !((smask & upto) == 0 && s_wclean[wave - 1] && s_wlast[wave - 1] == seed);
+        }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kCandPerBlock / 64; ++w) {
+        before += w < wave ? s_wcnt[w] : 0u;
+        total += s_wcnt[w];
+    }
+    if (keep) {
+        const uint32_t at = before + (uint32_t)__popcll(mask & (upto >> 1));
+        p.seed_ent[(size_t)blockIdx.x * kCandPerBlock + at] = ((uint64_t)c << 32) | seed;
+    }
+    if (tid == 0) p.blk_cnt[blockIdx.x] = total;
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel 2
+// kernel 2: per contig, distinct seeds -> ascending array (np.sort(list(oneps_set)), :107)
 // ---------------------------------------------------------------------------------------------
 
 // All-ascending bitonic network ("flip" form): every compare-exchange puts the smaller key at the
@@ -310,40 +403,109 @@ __device__ void bitonic_sort(uint32_t *a, uint32_t n, uint32_t tid, uint32_t nth
     }
 }
 
+// exclusive prefix sum of one value per thread over the block; *total gets the block sum
+__device__ uint32_t block_exscan(uint32_t v, uint32_t tid, uint32_t *s_part /* [nthreads/64 + 1] */, uint32_t nthreads,
+                                 uint32_t *total)
+{
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) s_part[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    for (uint32_t w = 0; w < nthreads / 64; ++w) {
+        const uint32_t pw = s_part[w];
+        before += w < wave ? pw : 0u;
+        tot += pw;
+    }
+    __syncthreads();
+    *total = tot;
+    return before + x - v;
+}
+
+// sorted keys src[0..n) -> distinct keys dst[...]; returns the number of distinct keys.
+// Each thread owns a contiguous slice so the output order is the input order.
+__device__ uint32_t unique_copy(const uint32_t *src, uint32_t n, uint32_t *dst, uint32_t tid, uint32_t nthreads,
+                                uint32_t *s_part)
+{
+    const uint32_t per = (n + nthreads - 1) / nthreads;
+    const uint32_t b = min(n, tid * per), e = min(n, b + per);
+    uint32_t cnt = 0;
+    for (uint32_t i = b; i < e; ++i) cnt += (i == 0 || src[i] != src[i - 1]);
+    uint32_t total;
+    uint32_t at = block_exscan(cnt, tid, s_part, nthreads, &total);
+    for (uint32_t i = b; i < e; ++i)
+        if (i == 0 || src[i] != src[i - 1]) dst[at++] = src[i];
+    return total;
+}
+
 __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
 {
     __shared__ uint32_t s_key[kSortLds];
+    __shared__ uint32_t s_part[kSortThreads / 64 + 1];
+    __shared__ uint32_t s_n;
     const uint32_t k = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = p.seed_cnt[k];
-    uint32_t *buf = p.seedbuf + p.ctg_off[k];
-    __syncthreads();
-    if (tid == 0) { p.n_one[k] = n; p.seed_cnt[k] = 0; }
-    if (n == 0) return;
-    if (n <= kSortLds) {
-        for (uint32_t i = tid; i < n; i += kSortThreads) {
-            const uint32_t slot = buf[i];
-            s_key[i] = p.tab[slot];
-            p.tab[slot] = kEmpty;
-        }
-        __syncthreads();
-        bitonic_sort(s_key, n, tid, kSortThreads);
-        for (uint32_t i = tid; i < n; i += kSortThreads) buf[i] = s_key[i];
-    } else {
-        for (uint32_t i = tid; i < n; i += kSortThreads) {
-            const uint32_t slot = buf[i];
-            buf[i] = p.tab[slot];
-            p.tab[slot] = kEmpty;
-        }
-        __syncthreads();
-        bitonic_sort(buf, n, tid, kSortThreads);
+    const uint32_t c_lo = p.ctg_off[k], c_hi = p.ctg_off[k + 1];
+    if (c_lo == c_hi) {
+        if (tid == 0) p.n_one[k] = 0;
+        return;
     }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // seed entries of the classify blocks that overlap this contig; keep those whose candidate is ours
+    const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
+    uint32_t *glist = p.onebuf + c_lo;                       // capacity c_hi - c_lo >= number of entries
+    for (uint32_t b = b_lo + tid; b <= b_hi; b += kSortThreads) {
+        const uint32_t cnt = p.blk_cnt[b];
+        const uint64_t *ent = p.seed_ent + (size_t)b * kCandPerBlock;
+        // the last entry of the previous block, if it belongs to this contig, absorbs an equal first entry
+        uint32_t prev_ps = kEmpty;
+        if (b > b_lo && cnt) {
+            const uint32_t pc = p.blk_cnt[b - 1];
+            if (pc) {
+                const uint64_t pe = p.seed_ent[(size_t)(b - 1) * kCandPerBlock + pc - 1];
+                if ((uint32_t)(pe >> 32) >= c_lo) prev_ps = (uint32_t)pe;
+            }
+        }
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint64_t e = ent[j];
+            const uint32_t c = (uint32_t)(e >> 32);
+            if (c < c_lo || c >= c_hi) continue;
+            if (j == 0 && (uint32_t)e == prev_ps) continue;     // both candidates lie in [c_lo, c_hi)
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < kSortLds) s_key[at] = (uint32_t)e;
+            glist[at] = (uint32_t)e;                          // also kept in HBM for the large path
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    uint32_t n_one;
+    if (n == 0) {
+        n_one = 0;
+    } else if (n <= kSortLds) {
+        bitonic_sort(s_key, n, tid, kSortThreads);
+        n_one = unique_copy(s_key, n, glist, tid, kSortThreads, s_part);
+    } else {
+        // more seeds than LDS holds (unsorted input with very many phase sets): sort in HBM
+        __threadfence_block();
+        bitonic_sort(glist, n, tid, kSortThreads);
+        uint32_t *tmp = p.tmpbuf + c_lo;
+        n_one = unique_copy(glist, n, tmp, tid, kSortThreads, s_part);
+        __syncthreads();
+        for (uint32_t i = tid; i < n_one; i += kSortThreads) glist[i] = tmp[i];
+    }
+    if (tid == 0) p.n_one[k] = n_one;
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel 3
+// kernel 3: contig drop, nearest PS, multi-PS vote + decision
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__ a, uint32_t n, uint32_t key)
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t key)
 {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
@@ -353,8 +515,14 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__
     return lo;
 }
 
+__device__ __forceinline__ bool is_member(const uint32_t *a, uint32_t n, uint32_t key)
+{
+    const uint32_t at = lower_bound_u32(a, n, key);
+    return at < n && a[at] == key;
+}
+
 // sv_phasing_fn.py:107-111 -- ties go to the larger seed
-__device__ __forceinline__ uint32_t nearest_ps(const uint32_t *__restrict__ a, uint32_t n, uint32_t pos)
+__device__ __forceinline__ uint32_t nearest_ps(const uint32_t *a, uint32_t n, uint32_t pos)
 {
     const uint32_t i = lower_bound_u32(a, n, pos);
     const uint32_t lo = i > 0 ? i - 1 : 0;
@@ -370,30 +538,91 @@ __device__ __forceinline__ uint64_t fetch_tag(const Params &p, uint32_t m)
     return r == kEmpty ? kUntagged : p.read_tag[r];
 }
 
+// multi-PS vote straight from the marks (:85-105): only for candidates without a group summary
+__device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *one, uint32_t n_one, Vote &v, uint32_t &ps)
+{
+    const uint32_t b = p.cand_off[c], e = p.cand_off[c + 1];
+    uint32_t best = 0;
+    for (uint32_t m = b; m < e; ++m) {
+        const uint64_t t = fetch_tag(p, m);
+        if (t == kUntagged || tag_pc(t) > kPcMax) continue;
+        ++v.allhap;
+    }
+    uint32_t done_ps = kEmpty;                                 // last group evaluated (cheap duplicate skip)
+    for (uint32_t m = b; m < e; ++m) {
+        const uint64_t t = fetch_tag(p, m);
+        if (t == kUntagged || tag_pc(t) > kPcMax) continue;
+        const uint32_t g = tag_ps(t);
+        if (g == done_ps || (g == ps && best)) continue;
+        if (!is_member(one, n_one, g)) continue;               // :91
+        // size and sums of g's group over the whole list; a later occurrence of an already
+        // evaluated group reproduces the same n and cannot beat it (strict '>', :101)
+        uint32_t n = 0, n1 = 0, n2 = 0;
+        uint64_t s1 = 0, s2 = 0;
+        for (uint32_t j = b; j < e; ++j) {
+            const uint64_t u = fetch_tag(p, j);
+            if (u == kUntagged || tag_pc(u) > kPcMax || tag_ps(u) != g) continue;
+            ++n;
+            const uint32_t hap = tag_hap(u);
+            if (hap == 1) { ++n1; s1 += tag_pc(u); }
+            else if (hap == 2) { ++n2; s2 += tag_pc(u); }
+        }
+        done_ps = g;
+        if (n > best) {
+            best = n; ps = g;
+            v.hap1 = n1; v.hap2 = n2; v.t1 = s1; v.t2 = s2;
+            v.hap0 = v.allhap - n1 - n2;                       // only with a winner (:105)
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void ef_finalize(const Params p)
 {
-    __shared__ uint32_t s_k0, s_any_empty;
+    __shared__ uint32_t s_one[kOneLds];
+    __shared__ uint32_t s_meta[4];                             // k0, n_one[k0] or ~0 (not LDS mode), any_empty, ctg_off[k0]
     const uint32_t tid = threadIdx.x;
     const uint32_t c0 = blockIdx.x * 256u;
     const uint32_t c = c0 + tid;
+    const bool live = c < p.C;
+    const uint8_t code = live ? p.out_pred[c] : 0;
+    const uint32_t ps_in = live ? p.out_ps[c] : 0;
     if (tid == 0) {
         const uint32_t last = min(c0 + 255u, p.C - 1);
-        const uint32_t k0 = find_contig(p.ctg_off, p.K, c0), k1 = find_contig(p.ctg_off, p.K, last);
+        const uint32_t k0 = p.blk_ctg[blockIdx.x];
+        uint32_t k1 = k0;
+        while (last >= p.ctg_off[k1 + 1]) ++k1;
         uint32_t any = 0;
         for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0);
-        s_k0 = k0;
-        s_any_empty = any;
+        const uint32_t n0 = p.n_one[k0];
+        s_meta[0] = k0;
+        s_meta[1] = (k0 == k1 && n0 > 0 && n0 <= kOneLds) ? n0 : kEmpty;
+        s_meta[2] = any;
+        s_meta[3] = p.ctg_off[k0];
     }
     __syncthreads();
-    if (c >= p.C) return;
-    const uint8_t code = p.out_pred[c];
-    if (code < 4 && !s_any_empty) return;                      // already final
-    uint32_t k = s_k0;
-    while (c >= p.ctg_off[k + 1]) ++k;
-    const uint32_t n_one = p.n_one[k];
+    const uint32_t k0 = s_meta[0], n_lds = s_meta[1], any_empty = s_meta[2];
+    const bool lds_mode = n_lds != kEmpty;
+    if (lds_mode) {
+        const uint32_t *src = p.onebuf + s_meta[3];
+        for (uint32_t i = tid; i < n_lds; i += 256u) s_one[i] = src[i];
+        __syncthreads();
+    }
+    if (!live) return;
+    if (code < 4 && !any_empty) return;                        // already final
+    const uint32_t *one;
+    uint32_t n_one;
+    if (lds_mode) {
+        one = s_one;
+        n_one = n_lds;
+    } else {
+        uint32_t k = k0;
+        while (c >= p.ctg_off[k + 1]) ++k;
+        n_one = p.n_one[k];
+        one = p.onebuf + p.ctg_off[k];
+    }
     if (n_one == 0) {                                          // :209-210
         if (code != 0) p.out_pred[c] = 0;
-        p.out_ps[c] = 0;
+        if (ps_in != 0) p.out_ps[c] = 0;
         return;
     }
     if (code < 4) return;
@@ -403,51 +632,46 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         p.out_ps[c] = 0;
         return;
     }
-    const uint32_t *one = p.seedbuf + p.ctg_off[k];
-    if (code & kClass2) {                                      // :85-105, :148-155
-        const uint32_t b = p.cand_off[c], e = p.cand_off[c + 1];
+    if (code & (kClass2 | kClass2Slow)) {                      // :85-105, :148-155
         Vote v = {0, 0, 0, 0, 0, 0};
-        uint32_t ps = 0, best = 0;
-        for (uint32_t m = b; m < e; ++m) {
-            const uint64_t t = fetch_tag(p, m);
-            if (t == kUntagged || tag_pc(t) > kPcMax) continue;
-            ++v.allhap;
-        }
-        uint32_t done_ps = kEmpty;                             // last group evaluated (cheap duplicate skip)
-        for (uint32_t m = b; m < e; ++m) {
-            const uint64_t t = fetch_tag(p, m);
-            if (t == kUntagged || tag_pc(t) > kPcMax) continue;
-            const uint32_t g = tag_ps(t);
-            if (g == done_ps || g == ps && best) continue;
-            const uint32_t at = lower_bound_u32(one, n_one, g);
-            if (at >= n_one || one[at] != g) continue;         // :91
-            // size and sums of g's group over the whole list; a later occurrence of an already
-            // evaluated group reproduces the same n and cannot beat it (strict '>', :101)
-            uint32_t n = 0, n1 = 0, n2 = 0;
-            uint64_t s1 = 0, s2 = 0;
-            for (uint32_t j = b; j < e; ++j) {
-                const uint64_t u = fetch_tag(p, j);
-                if (u == kUntagged || tag_pc(u) > kPcMax || tag_ps(u) != g) continue;
-                ++n;
-                const uint32_t hap = tag_hap(u);
-                if (hap == 1) { ++n1; s1 += tag_pc(u); }
-                else if (hap == 2) { ++n2; s2 += tag_pc(u); }
+        uint32_t ps = 0;
+        if (code & kClass2) {
+            const uint32_t *rec = p.c2rec + (size_t)ps_in * kC2Words;
+            uint32_t w[kC2Words];
+#pragma unroll
+            for (int i = 0; i < kC2Words; ++i) w[i] = rec[i];  // slots beyond ng hold stale words, never used
+            v.allhap = w[0];
+            const uint32_t ng = w[1];
+            uint32_t best = 0;
+#pragma unroll
+            for (int k = 0; k < kC2Groups; ++k) {
+                if ((uint32_t)k < ng && w[2 + 6 * k + 1] > best && is_member(one, n_one, w[2 + 6 * k])) {
+                    best = w[2 + 6 * k + 1];
+                    ps = w[2 + 6 * k];
+                    v.hap1 = w[2 + 6 * k + 2]; v.hap2 = w[2 + 6 * k + 3];
+                    v.t1 = w[2 + 6 * k + 4]; v.t2 = w[2 + 6 * k + 5];
+                    v.hap0 = v.allhap - v.hap1 - v.hap2;       // only with a winner (:105)
+                }
             }
-            done_ps = g;
-            if (n > best) {
-                best = n; ps = g;
-                v.hap1 = n1; v.hap2 = n2; v.t1 = s1; v.t2 = s2;
-                v.hap0 = v.allhap - n1 - n2;                   // only with a winner (:105)
-            }
+        } else {
+            class2_from_marks(p, c, one, n_one, v, ps);
         }
         if (v.hap1 == 0 && v.hap2 == 0) ps = nearest_ps(one, n_one, p.cand_pos[c]);       // :106
-        p.out_pred[c] = (uint8_t)decide(2, v, e - b, p.cand_svread[c], p.cand_refread[c]);
+        const uint32_t deg = p.cand_off[c + 1] - p.cand_off[c];
+        p.out_pred[c] = (uint8_t)decide(2, v, deg, p.cand_svread[c], p.cand_refread[c]);
         p.out_ps[c] = ps;
         return;
     }
     // kNeedNearest
     p.out_pred[c] = code & 3;
     p.out_ps[c] = nearest_ps(one, n_one, p.cand_pos[c]);
+}
+
+// plan time: ctg_start[c] = 1 for the first candidate of every non-empty contig
+__global__ void plan_mark_starts(const uint32_t *ctg_off, uint32_t K, uint8_t *ctg_start)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K && ctg_off[k] < ctg_off[k + 1]) ctg_start[ctg_off[k]] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,14 +691,15 @@ struct duet_ctx {
     int device = 0;
     std::string err;
     bool profiling = false;
+    uint32_t dbg = 0;
     hipStream_t own_stream = nullptr;
     // plan (workspace keyed by the contig layout)
     std::vector<uint32_t> plan_off;        // cached cand_ctg_off
     uint32_t plan_C = 0;
-    DevBuf ws_small;                        // ctg_off | tab_off | tab_mask | seed_cnt | n_one | status
-    DevBuf ws_tab, ws_seed;
-    uint32_t *d_ctg_off = nullptr, *d_tab_off = nullptr, *d_tab_mask = nullptr, *d_seed_cnt = nullptr,
-             *d_n_one = nullptr, *d_status = nullptr;
+    DevBuf ws_small;                        // ctg_off | n_one | status | blk_ctg | blk_cnt
+    DevBuf ws_start, ws_ent, ws_one, ws_tmp, ws_c2;
+    uint32_t *d_ctg_off = nullptr, *d_n_one = nullptr, *d_status = nullptr, *d_blk_ctg = nullptr,
+             *d_blk_cnt = nullptr;
     // host-run staging
     DevBuf h_in[9], h_out[2];
     // profiling events: 4 per run
@@ -512,13 +737,6 @@ int reserve(duet_ctx *ctx, DevBuf &b, size_t bytes)
     return DUET_OK;
 }
 
-uint32_t pow2_ceil(uint64_t x)
-{
-    uint64_t p = 1;
-    while (p < x) p <<= 1;
-    return (uint32_t)p;
-}
-
 // (re)build the workspace for this contig layout; a no-op when it matches the cached plan
 int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
 {
@@ -526,35 +744,41 @@ int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
     if (ctx->plan_C == C && ctx->plan_off.size() == (size_t)K + 1 &&
         memcmp(ctx->plan_off.data(), pr->cand_ctg_off, sizeof(uint32_t) * (K + 1)) == 0)
         return DUET_OK;
-    std::vector<uint32_t> tab_off(K + 1), tab_mask(K + 1);
-    uint64_t total = 0;
-    for (uint32_t k = 0; k < K; ++k) {
-        const uint64_t cnt = pr->cand_ctg_off[k + 1] - pr->cand_ctg_off[k];
-        const uint32_t slots = pow2_ceil(cnt * 2 < 16 ? 16 : cnt * 2);
-        tab_off[k] = (uint32_t)total;
-        tab_mask[k] = slots - 1;
-        total += slots;
+    const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
+    // contig of the first candidate of every 256-candidate block
+    std::vector<uint32_t> blk_ctg(B);
+    {
+        uint32_t k = 0;
+        for (uint32_t b = 0; b < B; ++b) {
+            const uint32_t c = b * kCandPerBlock;
+            while (c >= pr->cand_ctg_off[k + 1]) ++k;
+            blk_ctg[b] = k;
+        }
     }
-    if (total >= 0xFFFFFFF0ull) return fail(ctx, DUET_ERR_INVALID, "too many candidates for the seed hash set");
-    const size_t small_words = (size_t)(K + 1) * 3 + (size_t)K * 2 + 8;
+    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B * 2;
     int rc;
     // the previous plan's buffers may still be in use by work queued on a stream
     HIP_TRY(ctx, hipDeviceSynchronize());
     if ((rc = reserve(ctx, ctx->ws_small, small_words * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_tab, (size_t)total * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_seed, (size_t)(C ? C : 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->ws_start, C))) return rc;
+    if ((rc = reserve(ctx, ctx->ws_ent, (size_t)B * kCandPerBlock * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->ws_one, (size_t)C * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->ws_tmp, (size_t)C * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->ws_c2, (size_t)B * kC2Quota * kC2Words * 4))) return rc;
     uint32_t *w = (uint32_t *)ctx->ws_small.ptr;
     ctx->d_ctg_off = w;            w += K + 1;
-    ctx->d_tab_off = w;            w += K + 1;
-    ctx->d_tab_mask = w;           w += K + 1;
-    ctx->d_seed_cnt = w;           w += K;
     ctx->d_n_one = w;              w += K;
-    ctx->d_status = w;
+    ctx->d_status = w;             w += 8;
+    ctx->d_blk_ctg = w;            w += B;
+    ctx->d_blk_cnt = w;
     HIP_TRY(ctx, hipMemcpy(ctx->d_ctg_off, pr->cand_ctg_off, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_tab_off, tab_off.data(), sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_tab_mask, tab_mask.data(), sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(ctx->d_seed_cnt, 0, sizeof(uint32_t) * ((size_t)K * 2 + 8)));
-    HIP_TRY(ctx, hipMemset(ctx->ws_tab.ptr, 0xFF, (size_t)total * 4));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_blk_ctg, blk_ctg.data(), sizeof(uint32_t) * B, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ctx->d_n_one, 0, sizeof(uint32_t) * ((size_t)K + 8)));
+    HIP_TRY(ctx, hipMemset(ctx->ws_start.ptr, 0, C));
+    hipLaunchKernelGGL(plan_mark_starts, dim3((K + 255) / 256), dim3(256), 0, 0, ctx->d_ctg_off, K,
+                       (uint8_t *)ctx->ws_start.ptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
     ctx->plan_off.assign(pr->cand_ctg_off, pr->cand_ctg_off + K + 1);
     ctx->plan_C = C;
     (void)stream;
@@ -630,7 +854,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
-    DevBuf *all[] = {&ctx->ws_small, &ctx->ws_tab, &ctx->ws_seed};
+    DevBuf *all[] = {&ctx->ws_small, &ctx->ws_start, &ctx->ws_ent, &ctx->ws_one, &ctx->ws_tmp, &ctx->ws_c2};
     for (DevBuf *b : all) if (b->ptr) (void)hipFree(b->ptr);
     for (DevBuf &b : ctx->h_in) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->h_out) if (b.ptr) (void)hipFree(b.ptr);
@@ -642,6 +866,13 @@ int duet_ctx_set_profiling(duet_ctx *ctx, int enabled)
 {
     if (!ctx) return fail(nullptr, DUET_ERR_INVALID, "null context");
     ctx->profiling = enabled != 0;
+    return DUET_OK;
+}
+
+int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags)
+{
+    if (!ctx) return fail(nullptr, DUET_ERR_INVALID, "null context");
+    ctx->dbg = flags;
     return DUET_OK;
 }
 
@@ -661,10 +892,12 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     p.cand_refread = pr->cand_refread; p.cand_gt_ok = pr->cand_gt_ok;
     p.cand_off = pr->cand_off; p.mark_read = pr->mark_read;
     p.svlen_thres = pr->svlen_thres; p.suppread_thres = pr->suppread_thres;
-    p.ctg_off = ctx->d_ctg_off; p.tab_off = ctx->d_tab_off; p.tab_mask = ctx->d_tab_mask;
-    p.tab = (uint32_t *)ctx->ws_tab.ptr; p.seed_cnt = ctx->d_seed_cnt;
-    p.seedbuf = (uint32_t *)ctx->ws_seed.ptr; p.n_one = ctx->d_n_one; p.status = ctx->d_status;
+    p.ctg_off = ctx->d_ctg_off; p.ctg_start = (const uint8_t *)ctx->ws_start.ptr; p.blk_ctg = ctx->d_blk_ctg;
+    p.blk_cnt = ctx->d_blk_cnt; p.seed_ent = (uint64_t *)ctx->ws_ent.ptr;
+    p.onebuf = (uint32_t *)ctx->ws_one.ptr; p.tmpbuf = (uint32_t *)ctx->ws_tmp.ptr;
+    p.n_one = ctx->d_n_one; p.c2rec = (uint32_t *)ctx->ws_c2.ptr; p.status = ctx->d_status;
     p.out_pred = out_pred; p.out_ps = out_ps;
+    p.dbg = ctx->dbg;
 
     hipEvent_t *ev = nullptr;
     if (ctx->profiling) {
@@ -746,7 +979,7 @@ int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t 
     HIP_TRY(ctx, hipMemcpy(&n, ctx->d_n_one + contig, 4, hipMemcpyDeviceToHost));
     const uint32_t take = n < cap ? n : cap;
     if (take && out)
-        HIP_TRY(ctx, hipMemcpy(out, (uint32_t *)ctx->ws_seed.ptr + ctx->plan_off[contig], (size_t)take * 4,
+        HIP_TRY(ctx, hipMemcpy(out, (uint32_t *)ctx->ws_one.ptr + ctx->plan_off[contig], (size_t)take * 4,
                                hipMemcpyDeviceToHost));
     return (int)n;
 }

@@ -97,6 +97,17 @@ def test_fuzz_soa(ctx, seed):
     check_against_c_oracle(ctx, soa, 52, 4)
 
 
+def test_multi_ps_heavy(ctx):
+    """Most candidates see several phase sets (more than the 4 groups a summary holds, and more
+    multi-PS candidates per workgroup than summary slots): exercises both ef_finalize paths."""
+    soa = soa_fuzz.random_soa(77, n_contigs=2, cands_per_contig=(2000, 3000), reads_per_contig=(60, 90),
+                              n_ps=(9, 14), deg=(4, 30), empty_contig_rate=0, no_seed_contig_rate=0)
+    check_against_c_oracle(ctx, soa)
+    soa = soa_fuzz.random_soa(78, n_contigs=3, cands_per_contig=(1000, 2000), reads_per_contig=(40, 200),
+                              n_ps=(2, 5), deg=(2, 12), empty_contig_rate=0, no_seed_contig_rate=0)
+    check_against_c_oracle(ctx, soa)
+
+
 def test_long_candidates_cross_lds_chunks(ctx):
     """Candidates with more marks than one LDS pass holds (4096) and than a whole workgroup's pass."""
     soa = soa_fuzz.random_soa(101, n_contigs=2, cands_per_contig=(300, 600), reads_per_contig=(500, 900),
