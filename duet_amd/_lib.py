@@ -116,8 +116,9 @@ class Context(object):
             raise ZeroDivisionError('division by zero')        # what upstream raises (sv_phasing_fn.py:123)
         raise DuetLibraryError('duet_ef call failed (%d): %s' % (rc, msg))
 
-    def set_profiling(self, on):
-        rc = self.lib.duet_ctx_set_profiling(self.handle, 1 if on else 0)
+    def set_profiling(self, mode):
+        """0 off, 1 (or True) events around ef_classify only, 2 around every kernel."""
+        rc = self.lib.duet_ctx_set_profiling(self.handle, int(mode))
         if rc:
             self._raise(rc)
 

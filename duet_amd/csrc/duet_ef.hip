@@ -34,6 +34,12 @@
 
 namespace {
 
+#ifdef DUET_STAMPS
+#define STAMP(k, i) do { if (threadIdx.x == 0 && p.stamps) p.stamps[((size_t)(k) * 65536 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(k, i) do { } while (0)
+#endif
+
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;          // empty hash slot / "no seed"
 constexpr uint64_t kUntagged = ~0ull;             // LDS tag word of an absent mark
 constexpr uint32_t kPcMax = DUET_PC_MAX;
@@ -50,7 +56,7 @@ constexpr int kSortThreads = 1024;
 constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB)
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
 constexpr uint32_t kC2Quota = 32;                 // group-summary slots per classify block
-constexpr int kC2Groups = 4;                      // voter groups kept per summary
+constexpr int kC2Groups = 2;                      // voter groups kept per summary (first two seen)
 constexpr int kC2Words = 2 + 6 * kC2Groups;       // allhap, ng, then {ps, n, n1, n2, t1, t2} per group
 
 struct Vote {
@@ -131,6 +137,7 @@ struct Params {
     uint8_t *out_pred;
     uint32_t *out_ps;
     uint32_t dbg;                     // diagnostic ablation bits (0 in production)
+    unsigned long long *stamps;       // diagnostic build only: [kernel][block][8] wall-clock stamps
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
     __shared__ uint32_t s_c2n;
 
     const uint32_t tid = threadIdx.x;
+    STAMP(0, 0);
     const uint32_t c0 = blockIdx.x * kCandPerBlock;
     const uint32_t nc = min((uint32_t)kCandPerBlock, p.C - c0);
     for (uint32_t i = tid; i <= nc; i += kCandPerBlock) s_off[i] = p.cand_off[c0 + i];
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
     const bool divzero = kept && ((uint64_t)svread + (uint64_t)refread == 0);
     const bool active = kept && !divzero;
     __syncthreads();
+    STAMP(0, 1);
     const uint32_t m_begin = s_off[0], m_end = s_off[nc];
     const uint32_t my_b = live ? s_off[tid] : 0, my_e = live ? s_off[tid + 1] : 0;
 
@@ -174,11 +183,15 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
     uint32_t n_ps = 0, first_ps = 0;          // distinct PS among tagged marks: 0, 1, 2(=many)
     uint32_t seed = kEmpty;                   // PS of first voter (:199-203)
     uint32_t last_ps = 0;                     // PS of last voter (:77)
-    uint32_t h1 = 0, h2 = 0, t1 = 0, t2 = 0;  // per-chunk partial sums (<= 4096 * 8100)
-    uint64_t T1 = 0, T2 = 0;
+    // voters grouped by PS, first two groups in first-seen order (A, B); a third group sets `more`.
+    // With one PS (class 1) group A is the whole vote (:74-84); with several it feeds :85-105.
+    uint32_t ps_a = 0, ps_b = 0, n_a = 0, n_b = 0, nv = 0;
+    uint32_t a1 = 0, a2 = 0, b1 = 0, b2 = 0;          // hap-1 / hap-2 counts per group
+    uint32_t ta1 = 0, ta2 = 0, tb1 = 0, tb2 = 0;      // PC sums; A's are per-chunk partials folded into TA1/TA2
+    uint64_t TA1 = 0, TA2 = 0;
+    bool more = false;
     uint8_t code = 0;
     uint32_t ps_out = 0;
-    bool c2_done = false;
 
     const uint32_t base = VEC ? (m_begin & ~3u) : m_begin;
     for (uint32_t cs = base; cs < m_end; cs += kChunk) {
@@ -224,6 +237,7 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
             }
         }
         __syncthreads();
+        STAMP(0, 2);
         // ---- consume: each thread walks its candidate's part of this chunk (branch-light) ------
         uint32_t lo = max(my_b, cs);
         const uint32_t hi = min(my_e, cs + (uint32_t)kChunk);
@@ -239,88 +253,65 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
             n_ps = tagged ? (ps != first_ps ? 2u : max(n_ps, 1u)) : n_ps;
             seed = (voter && seed == kEmpty) ? ps : seed;
             last_ps = voter ? ps : last_ps;
-            const bool v1 = voter && hap == 1, v2 = voter && hap == 2;
-            h1 += v1; t1 += v1 ? pc : 0u;
-            h2 += v2; t2 += v2 ? pc : 0u;
+            nv += voter;
+            ps_a = (voter && n_a == 0) ? ps : ps_a;
+            const bool in_a = voter && ps == ps_a;
+            ps_b = (voter && !in_a && n_b == 0) ? ps : ps_b;
+            const bool in_b = voter && !in_a && ps == ps_b;
+            more = more || (voter && !in_a && !in_b);
+            const bool is1 = hap == 1, is2 = hap == 2;
+            n_a += in_a; n_b += in_b;
+            a1 += in_a && is1; a2 += in_a && is2;
+            b1 += in_b && is1; b2 += in_b && is2;
+            ta1 += (in_a && is1) ? pc : 0u; ta2 += (in_a && is2) ? pc : 0u;
+            tb1 += (in_b && is1) ? pc : 0u; tb2 += (in_b && is2) ? pc : 0u;
         }
-        T1 += t1; T2 += t2; t1 = 0; t2 = 0;
-        // ---- multi-PS candidate that lies entirely in this chunk: summarise its voter groups -------
-        // (first-seen order, sv_phasing_fn.py:85-98) so that ef_finalize needs no second gather
-        if (active && n_ps == 2 && !c2_done && my_b >= cs && my_e <= cs + (uint32_t)kChunk) {
-            c2_done = true;
-            uint32_t g_ps[kC2Groups], g_n[kC2Groups], g_n1[kC2Groups], g_n2[kC2Groups], g_t1[kC2Groups], g_t2[kC2Groups];
-#pragma unroll
-            for (int k = 0; k < kC2Groups; ++k) { g_ps[k] = 0; g_n[k] = 0; g_n1[k] = 0; g_n2[k] = 0; g_t1[k] = 0; g_t2[k] = 0; }
-            uint32_t ng = 0, allhap = 0;
-            bool overflow = false;
-            for (uint32_t m = my_b; m < my_e; ++m) {
-                const uint64_t tag = s_tag[m - cs];
-                const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
-                const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
-                if (pc > kPcMax) continue;
-                ++allhap;
-                int idx = -1;
-#pragma unroll
-                for (int k = 0; k < kC2Groups; ++k) if ((uint32_t)k < ng && g_ps[k] == ps) idx = k;
-                if (idx < 0) {
-                    if (ng == kC2Groups) { overflow = true; continue; }
-                    idx = (int)ng++;
-                }
-#pragma unroll
-                for (int k = 0; k < kC2Groups; ++k) {
-                    const bool hit = k == idx;
-                    g_ps[k] = hit ? ps : g_ps[k];
-                    g_n[k] += hit;
-                    g_n1[k] += hit && hap == 1;
-                    g_n2[k] += hit && hap == 2;
-                    g_t1[k] += (hit && hap == 1) ? pc : 0u;
-                    g_t2[k] += (hit && hap == 2) ? pc : 0u;
-                }
-            }
-            const uint32_t rank = overflow ? kC2Quota : atomicAdd(&s_c2n, 1u);
-            if (rank < kC2Quota) {
-                const uint32_t slot = blockIdx.x * kC2Quota + rank;
-                uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
-                rec[0] = allhap;
-                rec[1] = ng;
-#pragma unroll
-                for (int k = 0; k < kC2Groups; ++k) {
-                    if ((uint32_t)k < ng) {
-                        rec[2 + 6 * k + 0] = g_ps[k]; rec[2 + 6 * k + 1] = g_n[k];
-                        rec[2 + 6 * k + 2] = g_n1[k]; rec[2 + 6 * k + 3] = g_n2[k];
-                        rec[2 + 6 * k + 4] = g_t1[k]; rec[2 + 6 * k + 5] = g_t2[k];
-                    }
-                }
-                code = kClass2;
-                ps_out = slot;
-            }
-        }
+        TA1 += ta1; TA2 += ta2; ta1 = 0; ta2 = 0;
+        STAMP(0, 3);
         __syncthreads();
     }
 
+    STAMP(0, 4);
     // ---- per-candidate result ------------------------------------------------------------------
     bool want_seed = false;
+    // multi-PS candidates get a summary slot (first two voter groups) unless a third group exists or
+    // the PC sums could leave 32 bits; those few are re-gathered by ef_finalize
+    const bool c2 = active && n_ps == 2;
+    const bool c2_fast = c2 && !more && (my_e - my_b) < 500000u;
+    const uint32_t rank = c2_fast ? atomicAdd(&s_c2n, 1u) : kC2Quota;
     if (live) {
         if (divzero) {
             code = kDivZero;
         } else if (active) {
             want_seed = (n_ps == 1) && seed != kEmpty;                                             // :198-203
-            if (n_ps == 2) {
-                if (code != kClass2) code = kClass2Slow;        // no summary: ef_finalize re-gathers
+            if (c2) {
+                if (rank < kC2Quota) {
+                    const uint32_t slot = blockIdx.x * kC2Quota + rank;
+                    uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
+                    const uint32_t ng = (n_a != 0) + (n_b != 0);
+                    rec[0] = nv; rec[1] = ng;
+                    rec[2] = ps_a; rec[3] = n_a; rec[4] = a1; rec[5] = a2; rec[6] = (uint32_t)TA1; rec[7] = (uint32_t)TA2;
+                    rec[8] = ps_b; rec[9] = n_b; rec[10] = b1; rec[11] = b2; rec[12] = tb1; rec[13] = tb2;
+                    code = kClass2;
+                    ps_out = slot;
+                } else {
+                    code = kClass2Slow;
+                }
             } else {
                 Vote v;
-                v.hap1 = h1; v.hap2 = h2; v.hap0 = 0;
-                v.allhap = h1 + h2;
-                v.t1 = T1; v.t2 = T2;
+                v.hap1 = a1; v.hap2 = a2; v.hap0 = 0;
+                v.allhap = a1 + a2;
+                v.t1 = TA1; v.t2 = TA2;
                 code = (p.dbg & 2) ? 0 : (uint8_t)decide((int)n_ps, v, my_e - my_b, svread, refread);
                 ps_out = last_ps;
-                if (n_ps == 0 || (h1 == 0 && h2 == 0)) code |= kNeedNearest;                       // :106
+                if (n_ps == 0 || (a1 == 0 && a2 == 0)) code |= kNeedNearest;                       // :106
             }
         }
         p.out_pred[c] = code;
         p.out_ps[c] = ps_out;
     }
 
+    STAMP(0, 5);
     // ---- seeds of this block, compacted.  A seed equal to the seed of the previous seed-bearing
     // candidate is dropped, unless a contig starts in between (seed sets are per contig).  Only the
     // set matters downstream, so dropping duplicates early just shortens ef_seed_sort's input.
@@ -367,6 +358,7 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         p.seed_ent[(size_t)blockIdx.x * kCandPerBlock + at] = ((uint64_t)c << 32) | seed;
     }
     if (tid == 0) p.blk_cnt[blockIdx.x] = total;
+    STAMP(0, 6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,22 +369,24 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
 // lower index, so indices >= n behave as +inf padding without being stored.
 __device__ void bitonic_sort(uint32_t *a, uint32_t n, uint32_t tid, uint32_t nthreads)
 {
-    uint32_t N = 1;
-    while (N < n) N <<= 1;
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-        const uint32_t half = k >> 1;
-        for (uint32_t i = tid; i < (N >> 1); i += nthreads) {
-            const uint32_t blk = i / half, off = i % half;
-            const uint32_t x = blk * k + off, y = blk * k + (k - 1 - off);
+    uint32_t lN = 0;
+    while ((1u << lN) < n) ++lN;
+    const uint32_t pairs = (1u << lN) >> 1;
+    for (uint32_t lk = 1; lk <= lN; ++lk) {
+        const uint32_t k = 1u << lk, half = k >> 1;
+        for (uint32_t i = tid; i < pairs; i += nthreads) {
+            const uint32_t base = (i >> (lk - 1)) << lk, off = i & (half - 1);
+            const uint32_t x = base + off, y = base + (k - 1 - off);
             if (y < n) {
                 const uint32_t ax = a[x], ay = a[y];
                 if (ax > ay) { a[x] = ay; a[y] = ax; }
             }
         }
         __syncthreads();
-        for (uint32_t j = half >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < (N >> 1); i += nthreads) {
-                const uint32_t x = (i / j) * (j << 1) + (i % j), y = x + j;
+        for (int lj = (int)lk - 2; lj >= 0; --lj) {
+            const uint32_t j = 1u << lj;
+            for (uint32_t i = tid; i < pairs; i += nthreads) {
+                const uint32_t x = ((i >> lj) << (lj + 1)) + (i & (j - 1)), y = x + j;
                 if (y < n) {
                     const uint32_t ax = a[x], ay = a[y];
                     if (ax > ay) { a[x] = ay; a[y] = ax; }
@@ -401,6 +395,26 @@ __device__ void bitonic_sort(uint32_t *a, uint32_t n, uint32_t tid, uint32_t nth
             __syncthreads();
         }
     }
+}
+
+// A few rounds of odd-even transposition: finishes lists that are sorted up to local disorder (seed
+// lists of position-sorted VCFs).  Returns true when the list is sorted afterwards.
+__device__ bool oddeven_rounds(uint32_t *a, uint32_t n, uint32_t tid, uint32_t nthreads, uint32_t *s_flag, int max_rounds)
+{
+    for (int r = 0; r < max_rounds; ++r) {
+        if (tid == 0) *s_flag = 0;
+        __syncthreads();
+        for (int par = 0; par < 2; ++par) {
+            for (uint32_t i = 2 * tid + par; i + 1 < n; i += 2 * nthreads) {
+                const uint32_t x = a[i], y = a[i + 1];
+                if (x > y) { a[i] = y; a[i + 1] = x; *s_flag = 1; }
+            }
+            __syncthreads();
+        }
+        if (*s_flag == 0) return true;
+        __syncthreads();
+    }
+    return false;
 }
 
 // exclusive prefix sum of one value per thread over the block; *total gets the block sum
@@ -447,58 +461,122 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
 {
     __shared__ uint32_t s_key[kSortLds];
     __shared__ uint32_t s_part[kSortThreads / 64 + 1];
-    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_unsorted;
     const uint32_t k = blockIdx.x, tid = threadIdx.x;
+    STAMP(1, 0);
     const uint32_t c_lo = p.ctg_off[k], c_hi = p.ctg_off[k + 1];
     if (c_lo == c_hi) {
         if (tid == 0) p.n_one[k] = 0;
         return;
     }
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    // seed entries of the classify blocks that overlap this contig; keep those whose candidate is ours
+    if (tid == 0) s_unsorted = 0;
+    // Seed entries of the classify blocks that overlap this contig, in candidate order: thread t owns
+    // a contiguous run of blocks, counts the entries it will keep, and an exclusive scan gives its
+    // output position -- so a position-sorted VCF yields an (almost always) already ascending list.
     const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
+    const uint32_t nb = b_hi - b_lo + 1;
+    const uint32_t per = (nb + kSortThreads - 1) / kSortThreads;
+    const uint32_t my_lo = min(b_lo + tid * per, b_hi + 1), my_hi = min(my_lo + per, b_hi + 1);
     uint32_t *glist = p.onebuf + c_lo;                       // capacity c_hi - c_lo >= number of entries
-    for (uint32_t b = b_lo + tid; b <= b_hi; b += kSortThreads) {
-        const uint32_t cnt = p.blk_cnt[b];
-        const uint64_t *ent = p.seed_ent + (size_t)b * kCandPerBlock;
+    uint32_t mine = 0;
+    // common case: one classify block per thread with at most 4 entries -> read once, keep in registers
+    const bool small = per == 1;
+    uint32_t cnt0 = 0, prev0 = kEmpty;
+    uint64_t e0[4] = {0, 0, 0, 0};
+    if (small && my_lo < my_hi) {
+        cnt0 = p.blk_cnt[my_lo];
+        const uint32_t pcnt = my_lo > b_lo ? p.blk_cnt[my_lo - 1] : 0u;
+        const uint64_t *ent = p.seed_ent + (size_t)my_lo * kCandPerBlock;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if ((uint32_t)j < cnt0) e0[j] = ent[j];
+        if (pcnt) {
+            const uint64_t pe = p.seed_ent[(size_t)(my_lo - 1) * kCandPerBlock + pcnt - 1];
+            if ((uint32_t)(pe >> 32) >= c_lo) prev0 = (uint32_t)pe;
+        }
+    }
+    const bool cached = small && cnt0 <= 4;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t at = 0;
+        if (pass == 1) {
+            uint32_t total;
+            at = block_exscan(mine, tid, s_part, kSortThreads, &total);
+            if (tid == 0) s_part[kSortThreads / 64] = total;
+        }
         // the last entry of the previous block, if it belongs to this contig, absorbs an equal first entry
         uint32_t prev_ps = kEmpty;
-        if (b > b_lo && cnt) {
-            const uint32_t pc = p.blk_cnt[b - 1];
-            if (pc) {
-                const uint64_t pe = p.seed_ent[(size_t)(b - 1) * kCandPerBlock + pc - 1];
+        if (cached) {
+            prev_ps = prev0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if ((uint32_t)j >= cnt0) continue;
+                const uint32_t c = (uint32_t)(e0[j] >> 32), ps = (uint32_t)e0[j];
+                if (c < c_lo || c >= c_hi || ps == prev_ps) continue;
+                if (pass == 0) {
+                    ++mine;
+                } else {
+                    if (at < kSortLds) s_key[at] = ps;
+                    glist[at] = ps;
+                    ++at;
+                }
+                prev_ps = ps;
+            }
+            continue;
+        }
+        if (my_lo < my_hi && my_lo > b_lo) {
+            const uint32_t pcnt = p.blk_cnt[my_lo - 1];
+            if (pcnt) {
+                const uint64_t pe = p.seed_ent[(size_t)(my_lo - 1) * kCandPerBlock + pcnt - 1];
                 if ((uint32_t)(pe >> 32) >= c_lo) prev_ps = (uint32_t)pe;
             }
         }
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const uint64_t e = ent[j];
-            const uint32_t c = (uint32_t)(e >> 32);
-            if (c < c_lo || c >= c_hi) continue;
-            if (j == 0 && (uint32_t)e == prev_ps) continue;     // both candidates lie in [c_lo, c_hi)
-            const uint32_t at = atomicAdd(&s_n, 1u);
-            if (at < kSortLds) s_key[at] = (uint32_t)e;
-            glist[at] = (uint32_t)e;                          // also kept in HBM for the large path
+        for (uint32_t b = my_lo; b < my_hi; ++b) {
+            const uint32_t cnt = p.blk_cnt[b];
+            const uint64_t *ent = p.seed_ent + (size_t)b * kCandPerBlock;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint64_t e = ent[j];
+                const uint32_t c = (uint32_t)(e >> 32), ps = (uint32_t)e;
+                if (c < c_lo || c >= c_hi) continue;
+                if (ps == prev_ps) continue;                  // same contig (both candidates in [c_lo, c_hi))
+                if (pass == 0) {
+                    ++mine;
+                } else {
+                    if (at < kSortLds) s_key[at] = ps;
+                    glist[at] = ps;                           // also kept in HBM for the large path
+                    ++at;
+                }
+                prev_ps = ps;
+            }
         }
     }
     __syncthreads();
-    const uint32_t n = s_n;
+    STAMP(1, 1);
+    const uint32_t n = s_part[kSortThreads / 64];
+    {
+        const uint32_t *lst = n <= kSortLds ? s_key : glist;
+        for (uint32_t i = tid + 1; i < n; i += kSortThreads)
+            if (lst[i] < lst[i - 1]) s_unsorted = 1;
+    }
+    __syncthreads();
+    const bool unsorted = s_unsorted != 0;
     uint32_t n_one;
     if (n == 0) {
         n_one = 0;
     } else if (n <= kSortLds) {
-        bitonic_sort(s_key, n, tid, kSortThreads);
+        if (unsorted && !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 6))
+            bitonic_sort(s_key, n, tid, kSortThreads);
+        STAMP(1, 2);
         n_one = unique_copy(s_key, n, glist, tid, kSortThreads, s_part);
     } else {
-        // more seeds than LDS holds (unsorted input with very many phase sets): sort in HBM
+        // more seeds than LDS holds (unsorted input with very many phase sets): work in HBM
         __threadfence_block();
-        bitonic_sort(glist, n, tid, kSortThreads);
+        if (unsorted) bitonic_sort(glist, n, tid, kSortThreads);
         uint32_t *tmp = p.tmpbuf + c_lo;
         n_one = unique_copy(glist, n, tmp, tid, kSortThreads, s_part);
         __syncthreads();
         for (uint32_t i = tid; i < n_one; i += kSortThreads) glist[i] = tmp[i];
     }
     if (tid == 0) p.n_one[k] = n_one;
+    STAMP(1, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -581,6 +659,7 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
     __shared__ uint32_t s_one[kOneLds];
     __shared__ uint32_t s_meta[4];                             // k0, n_one[k0] or ~0 (not LDS mode), any_empty, ctg_off[k0]
     const uint32_t tid = threadIdx.x;
+    STAMP(2, 0);
     const uint32_t c0 = blockIdx.x * 256u;
     const uint32_t c = c0 + tid;
     const bool live = c < p.C;
@@ -600,6 +679,7 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         s_meta[3] = p.ctg_off[k0];
     }
     __syncthreads();
+    STAMP(2, 1);
     const uint32_t k0 = s_meta[0], n_lds = s_meta[1], any_empty = s_meta[2];
     const bool lds_mode = n_lds != kEmpty;
     if (lds_mode) {
@@ -607,6 +687,7 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         for (uint32_t i = tid; i < n_lds; i += 256u) s_one[i] = src[i];
         __syncthreads();
     }
+    STAMP(2, 2);
     if (!live) return;
     if (code < 4 && !any_empty) return;                        // already final
     const uint32_t *one;
@@ -690,8 +771,10 @@ struct DevBuf {
 struct duet_ctx {
     int device = 0;
     std::string err;
-    bool profiling = false;
+    int profiling = 0;                     // 0 off, 1 events around ef_classify only, 2 around every kernel
+    int ev_mode = 0;                       // mode the pooled events were recorded with
     uint32_t dbg = 0;
+    unsigned long long *d_stamps = nullptr;
     hipStream_t own_stream = nullptr;
     // plan (workspace keyed by the contig layout)
     std::vector<uint32_t> plan_off;        // cached cand_ctg_off
@@ -865,9 +948,21 @@ void duet_ctx_destroy(duet_ctx *ctx)
 int duet_ctx_set_profiling(duet_ctx *ctx, int enabled)
 {
     if (!ctx) return fail(nullptr, DUET_ERR_INVALID, "null context");
-    ctx->profiling = enabled != 0;
+    if (ctx->ev_used && ctx->ev_mode != enabled) return fail(ctx, DUET_ERR_INVALID, "collect the pending profile before changing the mode");
+    ctx->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return DUET_OK;
 }
+
+#ifdef DUET_STAMPS
+int duet_dbg_stamps(duet_ctx *ctx, int enable, unsigned long long *host_out)
+{
+    const size_t bytes = (size_t)3 * 65536 * 8 * 8;
+    if (enable && !ctx->d_stamps) { if (hipMalloc((void **)&ctx->d_stamps, bytes) != hipSuccess) return -1; }
+    if (enable) { (void)hipMemset(ctx->d_stamps, 0, bytes); return 0; }
+    if (ctx->d_stamps && host_out) { (void)hipDeviceSynchronize(); (void)hipMemcpy(host_out, ctx->d_stamps, bytes, hipMemcpyDeviceToHost); }
+    return 0;
+}
+#endif
 
 int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags)
 {
@@ -898,9 +993,12 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     p.n_one = ctx->d_n_one; p.c2rec = (uint32_t *)ctx->ws_c2.ptr; p.status = ctx->d_status;
     p.out_pred = out_pred; p.out_ps = out_ps;
     p.dbg = ctx->dbg;
+    p.stamps = ctx->d_stamps;
 
     hipEvent_t *ev = nullptr;
-    if (ctx->profiling) {
+    const int prof = ctx->profiling;
+    if (prof) {
+        ctx->ev_mode = prof;
         while (ctx->ev_pool.size() < ctx->ev_used + 4) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreate(&e));
@@ -917,9 +1015,9 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
         hipLaunchKernelGGL(ef_classify<false>, dim3(blocks), dim3(kCandPerBlock), 0, stream, p);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], stream));
     hipLaunchKernelGGL(ef_seed_sort, dim3(pr->n_contigs), dim3(kSortThreads), 0, stream, p);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], stream));
+    if (ev && prof == 2) HIP_TRY(ctx, hipEventRecord(ev[2], stream));
     hipLaunchKernelGGL(ef_finalize, dim3((pr->n_cands + 255) / 256), dim3(256), 0, stream, p);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[3], stream));
+    if (ev && prof == 2) HIP_TRY(ctx, hipEventRecord(ev[3], stream));
     HIP_TRY(ctx, hipGetLastError());
     ctx->pending_check = true;
     return DUET_OK;
@@ -950,14 +1048,15 @@ int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats)
     double acc[DUET_N_KERNELS] = {0, 0, 0}, tot = 0;
     for (size_t r = 0; r < runs; ++r) {
         hipEvent_t *ev = &ctx->ev_pool[4 * r];
-        HIP_TRY(ctx, hipEventSynchronize(ev[3]));
-        for (int i = 0; i < DUET_N_KERNELS; ++i) {
+        const int last = ctx->ev_mode == 2 ? 3 : 1;
+        HIP_TRY(ctx, hipEventSynchronize(ev[last]));
+        for (int i = 0; i < last; ++i) {
             float ms = 0;
             HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             acc[i] += ms;
         }
         float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[0], ev[3]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[0], ev[last]));
         tot += ms;
     }
     if (runs) {

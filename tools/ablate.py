@@ -20,12 +20,16 @@ for name, soa in sizes.items():
         for _ in range(5):
             dp.run(ctx, stream)
         torch.cuda.synchronize()
-        ctx.set_profiling(True); ctx.profile_collect()
-        t0 = time.perf_counter()
-        for _ in range(30):
-            dp.run(ctx, stream)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 30
-        st = ctx.profile_collect(); ctx.set_profiling(False)
-        print(name, 'dbg=%d' % fl, 'step_us=%.1f' % (dt * 1e6), 'k_us=[%.1f %.1f %.1f]' % tuple(1e3 * x for x in st.kernel_ms))
+        res = []
+        for mode in (0, 1, 2):
+            ctx.set_profiling(mode); ctx.profile_collect()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                dp.run(ctx, stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 50
+            st = ctx.profile_collect(); ctx.set_profiling(0)
+            res.append((dt, st))
+        print(name, 'dbg=%d' % fl, 'step_us(no events / classify events / all events)=%.1f %.1f %.1f' % tuple(r[0] * 1e6 for r in res),
+              'k1_us(mode1)=%.1f' % (res[1][1].kernel_ms[0] * 1e3), 'k_us(mode2)=[%.1f %.1f %.1f]' % tuple(1e3 * x for x in res[2][1].kernel_ms))
     lib.duet_ctx_set_debug(ctx.handle, 0)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""GPU-side diagnostic: per-block phase timeline of the three kernels (libduet_ef_stamps.so, -DDUET_STAMPS).
+Not part of the product; run its numbers as SHARES, the stamped build is slower."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from duet_amd import _lib, engine, synth
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libduet_ef_stamps.so')
+from duet_amd.devmem import DeviceProblem
+
+ctx = _lib.Context(0)
+lib = _lib.load()
+lib.duet_dbg_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+which = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+soa = engine.soa_from_synth([synth.bench_contig('1', 200000, 100000, 1)]) if which == 'cfg2' else \
+    engine.soa_from_synth(synth.bench_genome(20000000, 3))
+dp = DeviceProblem(soa, 50, 2)
+stream = torch.cuda.current_stream().cuda_stream
+for _ in range(5):
+    dp.run(ctx, stream)
+torch.cuda.synchronize()
+lib.duet_dbg_stamps(ctx.handle, 1, None)
+dp.run(ctx, stream)
+torch.cuda.synchronize()
+buf = np.zeros(3 * 65536 * 8, dtype=np.uint64)
+lib.duet_dbg_stamps(ctx.handle, 0, buf.ctypes.data)
+st = buf.reshape(3, 65536, 8).astype(np.int64)
+t0 = st[0][st[0][:, 0] > 0][:, 0].min()
+names = [['start', 'offsets', 'staged', 'consumed', 'loop_end', 'decided', 'end'], ['start', 'gathered', 'sorted', 'end'],
+         ['start', 'meta', 'staged']]
+for k in range(3):
+    blk = st[k][st[k][:, 0] > 0]
+    nb = len(blk)
+    print('kernel', k, 'blocks stamped', nb)
+    rel = (blk - t0) * 10.0 / 1000.0   # 100 MHz ticks -> us
+    for i, nm in enumerate(names[k]):
+        col = rel[:, i]
+        col = col[blk[:, i] > 0]
+        if len(col):
+            print('  %-9s first %.2f  median %.2f  p90 %.2f  last %.2f us' % (nm, col.min(), np.median(col), np.percentile(col, 90), col.max()))
+    d = np.diff(rel[:, :len(names[k])], axis=1)
+    print('  phase durations (median us):', ' '.join('%s=%.2f' % (names[k][i + 1], np.median(d[:, i])) for i in range(d.shape[1])))
