@@ -39,6 +39,21 @@ def classify_bytes(soa):
     return 12 * soa.n_marks + 22 * soa.n_cands + 8 * soa.n_reads
 
 
+def pmc_traffic(soa):
+    """HBM bytes per ef_classify launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE exact), or None
+    when no committed counter run matches the workload."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if '%d marks' % soa.n_marks in d.get('workload', ''):
+            return d['traffic_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(soa, budget_s=10.0):
     from oracle import c_oracle
     c_oracle.load()
@@ -102,9 +117,16 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, gather):
         dist_mod.barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_collect()
+    # after the timed region: every kernel bracketed by its own dispatch events (serialises the stream, so it
+    # is kept out of `value`); these are the durations rocprofv3 --kernel-trace reports
+    ctx.set_profiling(2)
+    for _ in range(min(steps, 50)):
+        dp.run(ctx, stream)
+    torch.cuda.synchronize()
+    iso = ctx.profile_collect()
     ctx.set_profiling(0)
     ctx.check(stream)
-    return dt, prof
+    return dt, prof, iso
 
 
 def main():
@@ -151,7 +173,7 @@ def main():
         def gather():
             return dist.allgather_records(dp.out_block, world)
 
-    dt, prof = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod, gather)
+    dt, prof, iso = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod, gather)
 
     # correctness of what was timed (rank-local, against the C oracle) -- outside the timed region
     pred, ps = dp.results()
@@ -190,8 +212,9 @@ def main():
                        'marks_per_gpu': soa.n_marks, 'candidates_per_gpu': soa.n_cands, 'reads_per_gpu': soa.n_reads,
                        'parallelism': 'contig-sharded x%d' % world, 'svlen_thres': 50, 'suppread_thres': 2},
             'parity_vs_oracle': parity,
+            'kernels_us_isolated': {n: round(float(iso.kernel_ms[i]) * 1e3, 2) for i, n in enumerate(_lib.KERNEL_NAMES)},
             'roofline': {'kernel': kname, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(soa),
                          'algorithmic_bytes_per_launch': abytes, 'launch_ms': k_ms,
                          'note': 'config 2 is 14.6 MB per launch (~1.8 us at peak): launch-latency bound; '
                                  'see extra.* for the bandwidth-bound sizes'},

@@ -22,6 +22,7 @@
 // Floating point: IEEE binary64, operations exactly as upstream, built with -ffp-contract=off.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -995,29 +996,28 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     p.dbg = ctx->dbg;
     p.stamps = ctx->d_stamps;
 
-    hipEvent_t *ev = nullptr;
+    // Profiling: the start/stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL),
+    // so hipEventElapsedTime is the kernel's execution time as rocprofv3 --kernel-trace reports it.
+    // 6 events per run: {start, stop} x {classify, seed_sort, finalize}; mode 1 uses the first pair only.
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const int prof = ctx->profiling;
     if (prof) {
         ctx->ev_mode = prof;
-        while (ctx->ev_pool.size() < ctx->ev_used + 4) {
+        while (ctx->ev_pool.size() < ctx->ev_used + 6) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreate(&e));
             ctx->ev_pool.push_back(e);
         }
-        ev = &ctx->ev_pool[ctx->ev_used];
-        ctx->ev_used += 4;
-        HIP_TRY(ctx, hipEventRecord(ev[0], stream));
+        for (int i = 0; i < (prof == 2 ? 6 : 2); ++i) ev[i] = ctx->ev_pool[ctx->ev_used + i];
+        ctx->ev_used += 6;
     }
     const uint32_t blocks = (pr->n_cands + kCandPerBlock - 1) / kCandPerBlock;
     if (((uintptr_t)pr->mark_read & 15) == 0)
-        hipLaunchKernelGGL(ef_classify<true>, dim3(blocks), dim3(kCandPerBlock), 0, stream, p);
+        hipExtLaunchKernelGGL(ef_classify<true>, dim3(blocks), dim3(kCandPerBlock), 0, stream, ev[0], ev[1], 0, p);
     else
-        hipLaunchKernelGGL(ef_classify<false>, dim3(blocks), dim3(kCandPerBlock), 0, stream, p);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], stream));
-    hipLaunchKernelGGL(ef_seed_sort, dim3(pr->n_contigs), dim3(kSortThreads), 0, stream, p);
-    if (ev && prof == 2) HIP_TRY(ctx, hipEventRecord(ev[2], stream));
-    hipLaunchKernelGGL(ef_finalize, dim3((pr->n_cands + 255) / 256), dim3(256), 0, stream, p);
-    if (ev && prof == 2) HIP_TRY(ctx, hipEventRecord(ev[3], stream));
+        hipExtLaunchKernelGGL(ef_classify<false>, dim3(blocks), dim3(kCandPerBlock), 0, stream, ev[0], ev[1], 0, p);
+    hipExtLaunchKernelGGL(ef_seed_sort, dim3(pr->n_contigs), dim3(kSortThreads), 0, stream, ev[2], ev[3], 0, p);
+    hipExtLaunchKernelGGL(ef_finalize, dim3((pr->n_cands + 255) / 256), dim3(256), 0, stream, ev[4], ev[5], 0, p);
     HIP_TRY(ctx, hipGetLastError());
     ctx->pending_check = true;
     return DUET_OK;
@@ -1044,19 +1044,19 @@ int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats)
     if (!ctx || !stats) return fail(ctx, DUET_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     memset(stats, 0, sizeof(*stats));
-    const size_t runs = ctx->ev_used / 4;
+    const size_t runs = ctx->ev_used / 6;
     double acc[DUET_N_KERNELS] = {0, 0, 0}, tot = 0;
+    const int nk = ctx->ev_mode == 2 ? DUET_N_KERNELS : 1;
     for (size_t r = 0; r < runs; ++r) {
-        hipEvent_t *ev = &ctx->ev_pool[4 * r];
-        const int last = ctx->ev_mode == 2 ? 3 : 1;
-        HIP_TRY(ctx, hipEventSynchronize(ev[last]));
-        for (int i = 0; i < last; ++i) {
+        hipEvent_t *ev = &ctx->ev_pool[6 * r];
+        HIP_TRY(ctx, hipEventSynchronize(ev[2 * nk - 1]));
+        for (int i = 0; i < nk; ++i) {
             float ms = 0;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
             acc[i] += ms;
         }
         float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[0], ev[last]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[0], ev[2 * nk - 1]));
         tot += ms;
     }
     if (runs) {

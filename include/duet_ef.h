@@ -101,9 +101,10 @@ duet_ctx *duet_ctx_create(int device_id);
 void duet_ctx_destroy(duet_ctx *ctx);
 const char *duet_last_error(const duet_ctx *ctx);
 
-/* HIP events on the run's stream, resolved by duet_ef_profile_collect: 0 = none, 1 = around the dominant
- * kernel (ef_classify) only -- two events per run, what bench.py uses inside its timed region --,
- * 2 = around every kernel (kernel_ms[] complete, total_ms = first start to last end). */
+/* HIP events attached to the kernels' own dispatches (hipExtLaunchKernelGGL start/stop events on the run's
+ * stream), resolved by duet_ef_profile_collect: 0 = none, 1 = the dominant kernel (ef_classify) only -- two
+ * events per run, what bench.py uses inside its timed region --, 2 = every kernel (kernel_ms[] complete,
+ * total_ms = first start to last end; serialises the stream a little more). */
 int duet_ctx_set_profiling(duet_ctx *ctx, int mode);
 
 /*
