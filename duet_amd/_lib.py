@@ -23,7 +23,7 @@ KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
 # every symbol include/duet_ef.h declares (checked by tests/test_abi.py)
 EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
            'duet_ctx_set_profiling', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
-           'duet_ef_profile_collect', 'duet_ef_get_seed_ps')
+           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host')
 
 
 class EfProblem(ctypes.Structure):
@@ -39,6 +39,21 @@ class EfStats(ctypes.Structure):
     _fields_ = [('algorithmic_bytes', ctypes.c_uint64), ('n_seed_ps', ctypes.c_uint32),
                 ('n_profiled_runs', ctypes.c_uint32), ('kernel_ms', ctypes.c_float * N_KERNELS),
                 ('total_ms', ctypes.c_float)]
+
+
+class ClusterProblem(ctypes.Structure):
+    _fields_ = [('n_marks', ctypes.c_uint32), ('part_gap', ctypes.c_uint32), ('part_max', ctypes.c_uint32),
+                ('n_contigs_hint', ctypes.c_uint32), ('n_types_hint', ctypes.c_uint32), ('max_pos_hint', ctypes.c_uint32),
+                ('max_span_hint', ctypes.c_uint32), ('reserved', ctypes.c_uint32),
+                ('max_dist', ctypes.c_double), ('normalizer', ctypes.c_double),
+                ('mark_contig', ctypes.c_void_p), ('mark_type', ctypes.c_void_p), ('mark_pos', ctypes.c_void_p),
+                ('mark_span', ctypes.c_void_p)]
+
+
+class ClusterResult(ctypes.Structure):
+    _fields_ = [('order', ctypes.c_void_p), ('cand_off', ctypes.c_void_p), ('cand_contig', ctypes.c_void_p),
+                ('cand_type', ctypes.c_void_p), ('cand_pos', ctypes.c_void_p), ('cand_span', ctypes.c_void_p),
+                ('n_cands', ctypes.c_void_p)]
 
 
 class DuetLibraryError(RuntimeError):
@@ -80,6 +95,9 @@ def load():
                                      ctypes.c_void_p, ctypes.POINTER(EfStats)]
     lib.duet_ef_profile_collect.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfStats)]
     lib.duet_ef_get_seed_ps.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    lib.duet_cluster_run_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ClusterProblem),
+                                            ctypes.POINTER(ClusterResult), ctypes.c_void_p]
+    lib.duet_cluster_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ClusterProblem), ctypes.POINTER(ClusterResult)]
     _lib = lib
     return lib
 
@@ -154,6 +172,41 @@ class Context(object):
         if rc:
             self._raise(rc)
         return st
+
+    # -- stage A0: span-position clustering ---------------------------------------------------------
+    def cluster_host(self, contig, mtype, pos, span, max_dist=0.9, part_gap=1000, part_max=100, normalizer=900.0,
+                     hints=True):
+        """Cluster SV marks (host numpy arrays) into candidates on the GPU.
+        -> dict(order, cand_off, cand_contig, cand_type, cand_pos, cand_span) trimmed to the candidate count."""
+        contig = np.ascontiguousarray(contig, dtype=np.uint16)
+        mtype = np.ascontiguousarray(mtype, dtype=np.uint8)
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        span = np.ascontiguousarray(span, dtype=np.uint32)
+        M = len(pos)
+        prob = ClusterProblem()
+        prob.n_marks, prob.part_gap, prob.part_max = M, int(part_gap), int(part_max)
+        if hints and M:
+            prob.n_contigs_hint = int(contig.max()) + 1
+            prob.n_types_hint = int(mtype.max()) + 1
+            prob.max_pos_hint = int(pos.max())
+            prob.max_span_hint = max(int(span.max()), 1)
+        prob.max_dist, prob.normalizer = float(max_dist), float(normalizer)
+        prob.mark_contig, prob.mark_type, prob.mark_pos, prob.mark_span = [
+            a.ctypes.data if a.size else None for a in (contig, mtype, pos, span)]
+        out = dict(order=np.zeros(max(M, 1), dtype=np.uint32), cand_off=np.zeros(M + 1, dtype=np.uint32),
+                   cand_contig=np.zeros(max(M, 1), dtype=np.uint16), cand_type=np.zeros(max(M, 1), dtype=np.uint8),
+                   cand_pos=np.zeros(max(M, 1), dtype=np.uint32), cand_span=np.zeros(max(M, 1), dtype=np.uint32))
+        n = ctypes.c_uint32(0)
+        res = ClusterResult()
+        for k in ('order', 'cand_off', 'cand_contig', 'cand_type', 'cand_pos', 'cand_span'):
+            setattr(res, k, out[k].ctypes.data)
+        res.n_cands = ctypes.addressof(n)
+        rc = self.lib.duet_cluster_run_host(self.handle, ctypes.byref(prob), ctypes.byref(res))
+        if rc:
+            self._raise(rc)
+        N = n.value
+        return dict(order=out['order'][:M], cand_off=out['cand_off'][:N + 1], cand_contig=out['cand_contig'][:N],
+                    cand_type=out['cand_type'][:N], cand_pos=out['cand_pos'][:N], cand_span=out['cand_span'][:N])
 
     def seed_ps(self, contig, cap=1 << 20):
         out = np.zeros(cap, dtype=np.uint32)

@@ -1,0 +1,588 @@
+// duet_cluster.hip -- gfx950 kernels and C ABI for stage A0: span-position clustering of SV marks into
+// candidates (what `--cluster_max_distance` controls).
+//
+// The reference delegates this stage to the external `svim alignment` binary (src/duet/sv_calling.py:13-15),
+// so there is no reference code to follow; the rule implemented here is this repository's own deterministic
+// statement of the published SVIM 1.4.2 scheme, normative text in oracle/cluster_oracle.c / DESIGN.md section 9.
+//
+// Pipeline (all on one stream):
+//   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, val = mark index
+//   radix sort     stable LSD, 8-bit digits: rx_hist -> scan -> rx_scatter per pass (ballot-ranked, no atomics
+//                  on the data path, so the order is deterministic)
+//   cl_heads1/2    partition starts: contig/type change, centre gap > part_gap, or part_max marks reached
+//   cl_parts       partition start list (from an exclusive scan of the head flags)
+//   cl_cluster     one wavefront per partition: span-position distances into an LDS triangle (fp64),
+//                  average-linkage agglomeration by repeated wave-wide argmin + Lance-Williams update
+//   cl_emit        per partition: clusters by smallest member, members in sorted order -> order[], cand_*[]
+//
+// Bit-exactness vs the oracle: distances and updates are the same binary64 expressions in the same order
+// (-ffp-contract=off); the argmin breaks ties by the smallest (first, second) index pair.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "duet_ef.h"
+#include "duet_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kRxThreads = 256;
+constexpr int kRxItems = 16;
+constexpr int kRxTile = kRxThreads * kRxItems;        // keys per radix block
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+struct ClParams {
+    uint32_t M;
+    uint32_t part_gap, part_max;
+    double max_dist, normalizer;
+    uint32_t centre_bits, type_bits;                  // key = ((contig << type_bits | type) << centre_bits) | centre
+    const uint16_t *contig;
+    const uint8_t *type;
+    const uint32_t *pos, *span;
+    const uint32_t *sorted;                           // mark index at each sorted position
+    const uint32_t *part_start;                       // [P+1]
+    const uint32_t *n_parts;                          // device scalar
+    uint8_t *label;                                   // [M] root (index inside its partition) of each sorted position
+    uint32_t *pc;                                     // [P] clusters per partition
+    const uint32_t *cbase;                            // [M] at a partition's start position: its first candidate
+    // outputs
+    uint32_t *order, *cand_off, *cand_pos, *cand_span;
+    uint16_t *cand_contig;
+    uint8_t *cand_type;
+};
+
+__device__ __forceinline__ uint64_t centre_of(uint32_t pos, uint32_t span) { return (uint64_t)pos + (span >> 1); }
+
+// ---------------------------------------------------------------------------------------------
+// keys + radix sort
+// ---------------------------------------------------------------------------------------------
+
+__global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.M) return;
+    const uint64_t hi = ((uint64_t)p.contig[i] << p.type_bits) | (uint64_t)p.type[i];
+    keys[i] = (hi << p.centre_bits) | centre_of(p.pos[i], p.span[i]);
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t nb,
+                                                      uint32_t *hist /* [256][nb] */)
+{
+    __shared__ uint32_t s_h[256];
+    const uint32_t tid = threadIdx.x;
+    s_h[tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRxTile;
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        const uint32_t i = base + it * kRxThreads + tid;
+        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)tid * nb + blockIdx.x] = s_h[tid];
+}
+
+// generic block-tiled scan: op 0 = exclusive sum, op 1 = inclusive max
+template <int OP>
+__device__ __forceinline__ uint32_t scan_op(uint32_t a, uint32_t b) { return OP == 0 ? a + b : (a > b ? a : b); }
+
+template <int OP>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce(const uint32_t *in, uint32_t n, uint32_t *part)
+{
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+        if (base + j < n) acc = scan_op<OP>(acc, in[base + j]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc = scan_op<OP>(acc, __shfl_xor(acc, d, 64));
+    if ((tid & 63) == 0) s_w[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kScanThreads / 64; ++w) t = scan_op<OP>(t, s_w[w]);
+        part[blockIdx.x] = t;
+    }
+}
+
+// single block: part[i] <- combination of part[0..i) (exclusive); *total <- combination of everything
+template <int OP>
+__global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, uint32_t *total)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? part[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if ((int)lane >= d) x = scan_op<OP>(x, y);
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (uint32_t w = 0; w < wave; ++w) before = scan_op<OP>(before, s_w[w]);
+        // exclusive value for element i: everything before it
+        uint32_t excl = before;
+        const uint32_t prev_in_wave = __shfl_up(x, 1, 64);
+        if (lane > 0) excl = scan_op<OP>(before, prev_in_wave);
+        if (i < n) part[i] = excl;
+        __syncthreads();
+        if (tid == 1023) s_carry = scan_op<OP>(before, x);
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = s_carry;
+}
+
+// out[i] = exclusive sum (OP 0) / inclusive max (OP 1) of in[0..i] given the per-tile carries in part[]
+template <int OP>
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *in, uint32_t n, const uint32_t *part,
+                                                           uint32_t *out)
+{
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = base + j < n ? in[base + j] : 0u;
+        acc = scan_op<OP>(acc, v[j]);
+    }
+    uint32_t x = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x = scan_op<OP>(x, y);
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t run = part[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) run = scan_op<OP>(run, s_w[w]);
+    const uint32_t prev = __shfl_up(x, 1, 64);
+    if (lane > 0) run = scan_op<OP>(run, prev);
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (OP == 0) {
+            if (base + j < n) out[base + j] = run;
+            run += v[j];
+        } else {
+            run = scan_op<OP>(run, v[j]);
+            if (base + j < n) out[base + j] = run;
+        }
+    }
+}
+
+// stable scatter of one 8-bit digit; hist holds the scanned (digit-major) offsets
+__global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in, const uint32_t *vals_in, uint32_t n,
+                                                         uint32_t shift, uint32_t nb, const uint32_t *hist,
+                                                         uint64_t *keys_out, uint32_t *vals_out)
+{
+    __shared__ uint32_t s_base[256];
+    __shared__ uint32_t s_wcnt[kRxThreads / 64][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    s_base[tid] = hist[(size_t)tid * nb + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kRxThreads / 64; ++w) s_wcnt[w][tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRxTile;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int it = 0; it < kRxItems; ++it) {
+        const uint32_t i = base + it * kRxThreads + tid;
+        const bool valid = i < n;
+        const uint64_t key = valid ? keys_in[i] : 0ull;
+        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bm = __ballot(bit);
+            same &= bit ? bm : ~bm;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & lt);
+        if (valid && rank == 0) s_wcnt[wave][d] = (uint32_t)__popcll(same);
+        __syncthreads();
+        if (valid) {
+            uint32_t at = s_base[d] + rank;
+            for (uint32_t w = 0; w < wave; ++w) at += s_wcnt[w][d];
+            keys_out[at] = key;
+            vals_out[at] = val;
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kRxThreads / 64; ++w) {
+            tot += s_wcnt[w][tid];
+            s_wcnt[w][tid] = 0;
+        }
+        s_base[tid] += tot;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// partitions
+// ---------------------------------------------------------------------------------------------
+
+// headpos[i] = i if sorted position i starts a natural partition (contig/type change or centre gap), else 0
+__global__ void cl_heads1(const ClParams p, uint32_t *headpos)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.M) return;
+    uint32_t h = 0;
+    if (i > 0) {
+        const uint32_t a = p.sorted[i - 1], b = p.sorted[i];
+        const bool cut = p.contig[a] != p.contig[b] || p.type[a] != p.type[b] ||
+                         centre_of(p.pos[b], p.span[b]) - centre_of(p.pos[a], p.span[a]) > (uint64_t)p.part_gap;
+        h = cut ? i : 0u;
+    }
+    headpos[i] = h;
+}
+
+// flag[i] = 1 if i starts a partition: natural head, or every part_max marks after it
+__global__ void cl_heads2(const ClParams p, const uint32_t *head_of, uint32_t *flag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.M) return;
+    flag[i] = ((i - head_of[i]) % p.part_max) == 0 ? 1u : 0u;
+}
+
+__global__ void cl_parts(const ClParams p, const uint32_t *flag, const uint32_t *pid, uint32_t *part_start,
+                         const uint32_t *n_parts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.M && flag[i]) part_start[pid[i]] = i;
+    if (i == 0) part_start[*n_parts] = p.M;
+}
+
+// pcat[i] = clusters of the partition that starts at sorted position i, 0 elsewhere (may alias flag)
+__global__ void cl_pcat(const ClParams p, const uint32_t *flag, const uint32_t *pid, uint32_t *pcat)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.M) return;
+    pcat[i] = flag[i] ? p.pc[pid[i]] : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// agglomeration: one wavefront (64-thread workgroup) per partition
+// ---------------------------------------------------------------------------------------------
+
+template <int NMAX, int NMIN>
+__global__ __launch_bounds__(64) void cl_cluster(const ClParams p)
+{
+    constexpr int TRI = NMAX * (NMAX - 1) / 2;
+    __shared__ double s_d[TRI];
+    __shared__ uint32_t s_pos[NMAX], s_span[NMAX], s_lab[NMAX], s_size[NMAX];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t P = *p.n_parts;
+    const double inf = __builtin_inf();
+    for (uint32_t part = blockIdx.x; part < P; part += gridDim.x) {
+        const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
+        if (n <= (uint32_t)NMIN || n > (uint32_t)NMAX) continue;
+        if (n == 1) {
+            if (lane == 0) { p.label[s] = 0; p.pc[part] = 1; }
+            continue;
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t a = p.sorted[s + i];
+            s_pos[i] = p.pos[a];
+            s_span[i] = p.span[a];
+            s_lab[i] = i;
+            s_size[i] = 1;
+        }
+        __syncthreads();
+        // span-position distance, upper triangle: row i holds j = i+1 .. n-1 at i*n - i(i+1)/2 + (j-i-1)
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+            const uint64_t si = s_pos[i], ei = (uint64_t)s_pos[i] + s_span[i], ci = centre_of(s_pos[i], s_span[i]);
+            const uint32_t row = i * n - i * (i + 1) / 2;
+            for (uint32_t j = i + 1 + lane; j < n; j += 64) {
+                const uint64_t sj = s_pos[j], ej = (uint64_t)s_pos[j] + s_span[j], cj = centre_of(s_pos[j], s_span[j]);
+                uint64_t m = si > sj ? si - sj : sj - si;
+                const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
+                m = m2 < m ? m2 : m;
+                m = m3 < m ? m3 : m;
+                const uint32_t sa = s_span[i], sb = s_span[j];
+                const uint32_t smax = sa > sb ? sa : sb, sdif = sa > sb ? sa - sb : sb - sa;
+                const double dp = (double)m / p.normalizer;
+                const double ds = smax ? (double)sdif / (double)smax : 0.0;
+                s_d[row + (j - i - 1)] = dp + ds;
+            }
+        }
+        __syncthreads();
+        const uint32_t pairs = n * (n - 1) / 2;
+        for (uint32_t merges = 0; merges + 1 < n; ++merges) {
+            // wave-wide argmin over the triangle; inactive pairs hold +inf; ties -> smallest index
+            double bd = inf;
+            uint32_t bq = 0xFFFFFFFFu;
+            for (uint32_t q = lane; q < pairs; q += 64) {
+                const double v = s_d[q];
+                if (v < bd) { bd = v; bq = q; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(bd, off, 64);
+                const uint32_t oq = __shfl_xor(bq, off, 64);
+                if (od < bd || (od == bd && oq < bq)) { bd = od; bq = oq; }
+            }
+            if (!(bd <= p.max_dist)) break;
+            // row a of pair bq: rs(a) <= bq < rs(a) + (n-1-a)
+            uint32_t a = 0;
+            {
+                bool hit0 = false, hit1 = false;
+                const uint32_t a0 = lane, a1 = lane + 64;
+                if (a0 + 1 < n) { const uint32_t rs = a0 * n - a0 * (a0 + 1) / 2; hit0 = rs <= bq && bq < rs + (n - 1 - a0); }
+                if (a1 + 1 < n) { const uint32_t rs = a1 * n - a1 * (a1 + 1) / 2; hit1 = rs <= bq && bq < rs + (n - 1 - a1); }
+                const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+                a = m0 ? (uint32_t)__ffsll((long long)m0) - 1u : 64u + (uint32_t)__ffsll((long long)m1) - 1u;
+            }
+            const uint32_t rsa = a * n - a * (a + 1) / 2;
+            const uint32_t b = a + 1 + (bq - rsa);
+            const double na = (double)s_size[a], nb = (double)s_size[b];
+            __syncthreads();
+            for (uint32_t k = lane; k < n; k += 64) {
+                if (k == a || k == b) continue;
+                const uint32_t lo_a = k < a ? k : a, hi_a = k < a ? a : k;
+                const uint32_t lo_b = k < b ? k : b, hi_b = k < b ? b : k;
+                const uint32_t qa = lo_a * n - lo_a * (lo_a + 1) / 2 + (hi_a - lo_a - 1);
+                const uint32_t qb = lo_b * n - lo_b * (lo_b + 1) / 2 + (hi_b - lo_b - 1);
+                const double da = s_d[qa], db = s_d[qb];
+                if (da == inf) continue;                       // k already merged away
+                s_d[qa] = (na * da + nb * db) / (na + nb);
+                s_d[qb] = inf;
+            }
+            if (lane == 0) {
+                s_d[bq] = inf;
+                s_size[a] += s_size[b];
+            }
+            for (uint32_t k = lane; k < n; k += 64)
+                if (s_lab[k] == b) s_lab[k] = a;
+            __syncthreads();
+        }
+        __syncthreads();
+        uint32_t roots = 0;
+        for (uint32_t k = lane; k < n; k += 64) {
+            p.label[s + k] = (uint8_t)s_lab[k];
+            roots += s_lab[k] == k;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
+        if (lane == 0) p.pc[part] = roots;
+    }
+}
+
+// one wavefront per partition: clusters by smallest member, members in sorted order
+__global__ __launch_bounds__(64) void cl_emit(const ClParams p)
+{
+    __shared__ uint32_t s_lab[128], s_pos[128], s_span[128];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t P = *p.n_parts;
+    for (uint32_t part = blockIdx.x; part < P; part += gridDim.x) {
+        const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
+        const uint32_t cb = p.cbase[s];
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t a = p.sorted[s + i];
+            s_lab[i] = p.label[s + i];
+            s_pos[i] = p.pos[a];
+            s_span[i] = p.span[a];
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t my = s_lab[i];
+            uint32_t cr = 0, before = 0, same_before = 0, size = 0;
+            uint64_t sp = 0, ss = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t lj = s_lab[j];
+                cr += (lj == j && j < my);
+                before += lj < my;
+                same_before += (lj == my && j < i);
+                if (lj == my) { ++size; sp += s_pos[j]; ss += s_span[j]; }
+            }
+            const uint32_t a = p.sorted[s + i];
+            p.order[s + before + same_before] = a;
+            if (my == i) {
+                const uint32_t cand = cb + cr;
+                p.cand_off[cand + 1] = s + before + size;
+                p.cand_contig[cand] = p.contig[a];
+                p.cand_type[cand] = p.type[a];
+                p.cand_pos[cand] = (uint32_t)(sp / size);
+                p.cand_span[cand] = (uint32_t)(ss / size);
+            }
+        }
+        if (part == 0 && lane == 0) p.cand_off[0] = 0;
+    }
+}
+
+uint32_t bits_for(uint64_t max_value)
+{
+    uint32_t b = 0;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b ? b : 1;
+}
+
+template <int OP>
+void launch_scan(const uint32_t *in, uint32_t n, uint32_t *part, uint32_t *out, uint32_t *total, hipStream_t st)
+{
+    const uint32_t nb = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(scan_reduce<OP>, dim3(nb), dim3(kScanThreads), 0, st, in, n, part);
+    hipLaunchKernelGGL(scan_spine<OP>, dim3(1), dim3(1024), 0, st, part, nb, total);
+    hipLaunchKernelGGL(scan_apply<OP>, dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluster_result *res, void *stream_)
+{
+    if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
+    if (!pr || !res) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
+    if (pr->part_max < 1 || pr->part_max > 128) return duet_fail(ctx, DUET_ERR_INVALID, "part_max must be in 1..128");
+    if (!(pr->normalizer > 0)) return duet_fail(ctx, DUET_ERR_INVALID, "normalizer must be positive");
+    if (!res->n_cands) return duet_fail(ctx, DUET_ERR_INVALID, "null n_cands");
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t M = pr->n_marks;
+    if (M == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(res->n_cands, 0, 4, st));
+        return DUET_OK;
+    }
+    if (!pr->mark_contig || !pr->mark_type || !pr->mark_pos || !pr->mark_span || !res->order || !res->cand_off ||
+        !res->cand_contig || !res->cand_type || !res->cand_pos || !res->cand_span)
+        return duet_fail(ctx, DUET_ERR_INVALID, "null array");
+
+    const uint32_t nb_rx = (M + kRxTile - 1) / kRxTile;
+    const uint32_t nb_sc = (M + kScanTile - 1) / kScanTile;
+    const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
+    const size_t sizes[12] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
+                              ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
+                              ((size_t)M + 1) * 4, (size_t)M, (size_t)M * 4, 64};
+    int rc;
+    for (int i = 0; i < 12; ++i)
+        if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
+    uint64_t *keysA = (uint64_t *)ctx->cl_ws[0].ptr, *keysB = (uint64_t *)ctx->cl_ws[1].ptr;
+    uint32_t *valsA = (uint32_t *)ctx->cl_ws[2].ptr, *valsB = (uint32_t *)ctx->cl_ws[3].ptr;
+    uint32_t *hist = (uint32_t *)ctx->cl_ws[4].ptr;
+    uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr, *tmpB = (uint32_t *)ctx->cl_ws[6].ptr;
+    uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
+    uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
+    uint8_t *label = (uint8_t *)ctx->cl_ws[9].ptr;
+    uint32_t *pc = (uint32_t *)ctx->cl_ws[10].ptr;
+    uint32_t *scal = (uint32_t *)ctx->cl_ws[11].ptr;      // [0] = n_parts
+
+    ClParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.part_gap = pr->part_gap; p.part_max = pr->part_max;
+    p.max_dist = pr->max_dist; p.normalizer = pr->normalizer;
+    const uint64_t max_centre = pr->max_pos_hint ? (uint64_t)pr->max_pos_hint + (pr->max_span_hint ? pr->max_span_hint : 0xFFFFFFFFull) / 2
+                                                 : 0x17FFFFFFFull;
+    p.centre_bits = bits_for(max_centre);
+    p.type_bits = bits_for(pr->n_types_hint ? pr->n_types_hint - 1 : 255);
+    const uint32_t contig_bits = bits_for(pr->n_contigs_hint ? pr->n_contigs_hint - 1 : 65535);
+    const uint32_t key_bits = p.centre_bits + p.type_bits + contig_bits;
+    if (key_bits > 64) return duet_fail(ctx, DUET_ERR_INVALID, "sort key does not fit 64 bits");
+    p.contig = pr->mark_contig; p.type = pr->mark_type; p.pos = pr->mark_pos; p.span = pr->mark_span;
+
+    const dim3 g256((M + 255) / 256), b256(256);
+    hipLaunchKernelGGL(cl_keys, g256, b256, 0, st, p, keysA, valsA);
+    uint64_t *kin = keysA, *kout = keysB;
+    uint32_t *vin = valsA, *vout = valsB;
+    const uint32_t nh = 256 * nb_rx;
+    for (uint32_t shift = 0; shift < key_bits; shift += 8) {
+        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, M, shift, nb_rx, hist);
+        launch_scan<0>(hist, nh, spart, hist, nullptr, st);      // in place: scan_apply reads a tile before writing it
+        hipLaunchKernelGGL(rx_scatter, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin,
+                           (const uint32_t *)vin, M, shift, nb_rx, (const uint32_t *)hist, kout, vout);
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *tv = vin; vin = vout; vout = tv;
+    }
+    p.sorted = vin;
+    hipLaunchKernelGGL(cl_heads1, g256, b256, 0, st, p, tmpA);
+    launch_scan<1>(tmpA, M, spart, tmpB, nullptr, st);            // tmpB[i] = start of i's natural partition
+    hipLaunchKernelGGL(cl_heads2, g256, b256, 0, st, p, (const uint32_t *)tmpB, tmpA);     // tmpA = head flags
+    launch_scan<0>(tmpA, M, spart, tmpB, scal, st);               // tmpB = partition id, scal[0] = #partitions
+    hipLaunchKernelGGL(cl_parts, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, part_start,
+                       (const uint32_t *)scal);
+    p.part_start = part_start; p.n_parts = scal; p.label = label; p.pc = pc;
+    const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
+    hipLaunchKernelGGL((cl_cluster<48, 0>), dim3(grid), dim3(64), 0, st, p);
+    hipLaunchKernelGGL((cl_cluster<128, 48>), dim3(grid < 1024u ? grid : 1024u), dim3(64), 0, st, p);
+    // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
+    // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
+    hipLaunchKernelGGL(cl_pcat, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, tmpA);
+    launch_scan<0>(tmpA, M, spart, tmpB, res->n_cands, st);       // tmpB[s] = first candidate of the partition at s
+    p.cbase = tmpB;
+    p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
+    p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
+    hipLaunchKernelGGL(cl_emit, dim3(grid), dim3(64), 0, st, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return DUET_OK;
+}
+
+int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluster_result *res)
+{
+    if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
+    if (!pr || !res || !res->n_cands) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t M = pr->n_marks;
+    if (M == 0) {
+        *res->n_cands = 0;
+        return DUET_OK;
+    }
+    hipStream_t s = ctx->own_stream;
+    int rc;
+    const void *src[4] = {pr->mark_contig, pr->mark_type, pr->mark_pos, pr->mark_span};
+    const size_t ib[4] = {(size_t)M * 2, (size_t)M, (size_t)M * 4, (size_t)M * 4};
+    for (int i = 0; i < 4; ++i) {
+        if (!src[i]) return duet_fail(ctx, DUET_ERR_INVALID, "null array");
+        if ((rc = duet_reserve(ctx, ctx->cl_in[i], ib[i]))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->cl_in[i].ptr, src[i], ib[i], hipMemcpyHostToDevice, s));
+    }
+    const size_t ob[6] = {(size_t)M * 4, ((size_t)M + 1) * 4 + 16, (size_t)M * 2, (size_t)M, (size_t)M * 4, (size_t)M * 4};
+    for (int i = 0; i < 6; ++i)
+        if ((rc = duet_reserve(ctx, ctx->cl_out[i], ob[i]))) return rc;
+    duet_cluster_problem d = *pr;
+    d.mark_contig = (const uint16_t *)ctx->cl_in[0].ptr;
+    d.mark_type = (const uint8_t *)ctx->cl_in[1].ptr;
+    d.mark_pos = (const uint32_t *)ctx->cl_in[2].ptr;
+    d.mark_span = (const uint32_t *)ctx->cl_in[3].ptr;
+    duet_cluster_result r;
+    r.order = (uint32_t *)ctx->cl_out[0].ptr;
+    r.cand_off = (uint32_t *)ctx->cl_out[1].ptr;
+    r.cand_contig = (uint16_t *)ctx->cl_out[2].ptr;
+    r.cand_type = (uint8_t *)ctx->cl_out[3].ptr;
+    r.cand_pos = (uint32_t *)ctx->cl_out[4].ptr;
+    r.cand_span = (uint32_t *)ctx->cl_out[5].ptr;
+    r.n_cands = (uint32_t *)((char *)ctx->cl_out[1].ptr + ((size_t)M + 1) * 4);        // spare word after cand_off
+    if ((rc = duet_cluster_run_device(ctx, &d, &r, s))) return rc;
+    uint32_t n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, r.n_cands, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *res->n_cands = n;
+    HIP_TRY(ctx, hipMemcpy(res->order, r.order, (size_t)M * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_off, r.cand_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_contig, r.cand_contig, (size_t)n * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_type, r.cand_type, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_pos, r.cand_pos, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_span, r.cand_span, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return DUET_OK;
+}
+
+}  // extern "C"

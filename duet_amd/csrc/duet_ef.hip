@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "duet_ef.h"
+#include "duet_internal.h"
 
 #pragma clang fp contract(off)
 
@@ -760,66 +761,14 @@ __global__ void plan_mark_starts(const uint32_t *ctg_off, uint32_t K, uint8_t *c
 // host side
 // ---------------------------------------------------------------------------------------------
 
-thread_local std::string g_last_error;
-
-struct DevBuf {
-    void *ptr = nullptr;
-    size_t cap = 0;
-};
-
 }  // namespace
 
-struct duet_ctx {
-    int device = 0;
-    std::string err;
-    int profiling = 0;                     // 0 off, 1 events around ef_classify only, 2 around every kernel
-    int ev_mode = 0;                       // mode the pooled events were recorded with
-    uint32_t dbg = 0;
-    unsigned long long *d_stamps = nullptr;
-    hipStream_t own_stream = nullptr;
-    // plan (workspace keyed by the contig layout)
-    std::vector<uint32_t> plan_off;        // cached cand_ctg_off
-    uint32_t plan_C = 0;
-    DevBuf ws_small;                        // ctg_off | n_one | status | blk_ctg | blk_cnt
-    DevBuf ws_start, ws_ent, ws_one, ws_tmp, ws_c2;
-    uint32_t *d_ctg_off = nullptr, *d_n_one = nullptr, *d_status = nullptr, *d_blk_ctg = nullptr,
-             *d_blk_cnt = nullptr;
-    // host-run staging
-    DevBuf h_in[9], h_out[2];
-    // profiling events: 4 per run
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    bool pending_check = false;
-};
+thread_local std::string duet_g_last_error;
 
 namespace {
 
-int fail(duet_ctx *ctx, int code, const std::string &msg)
-{
-    if (ctx) ctx->err = msg;
-    g_last_error = msg;
-    return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                      \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? DUET_ERR_OOM : DUET_ERR_HIP,           \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
-    } while (0)
-
-int reserve(duet_ctx *ctx, DevBuf &b, size_t bytes)
-{
-    if (bytes <= b.cap) return DUET_OK;
-    if (b.ptr) HIP_TRY(ctx, hipFree(b.ptr));
-    b.ptr = nullptr;
-    b.cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
-    HIP_TRY(ctx, hipMalloc(&b.ptr, want));
-    b.cap = want;
-    return DUET_OK;
-}
+inline int fail(duet_ctx *ctx, int code, const std::string &msg) { return duet_fail(ctx, code, msg); }
+inline int reserve(duet_ctx *ctx, DevBuf &b, size_t bytes) { return duet_reserve(ctx, b, bytes); }
 
 // (re)build the workspace for this contig layout; a no-op when it matches the cached plan
 int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
@@ -895,37 +844,37 @@ extern "C" {
 
 int duet_abi_version(void) { return DUET_ABI_VERSION; }
 
-const char *duet_last_error(const duet_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+const char *duet_last_error(const duet_ctx *ctx) { return ctx ? ctx->err.c_str() : duet_g_last_error.c_str(); }
 
 duet_ctx *duet_ctx_create(int device_id)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
-        g_last_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        duet_g_last_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
         return nullptr;
     }
     if (device_id < 0 || device_id >= n) {
-        g_last_error = "device id out of range";
+        duet_g_last_error = "device id out of range";
         return nullptr;
     }
     if ((e = hipSetDevice(device_id)) != hipSuccess) {
-        g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        duet_g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
         return nullptr;
     }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
-        g_last_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        duet_g_last_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
         return nullptr;
     }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        g_last_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        duet_g_last_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
         return nullptr;
     }
     duet_ctx *ctx = new duet_ctx();
     ctx->device = device_id;
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
-        g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        duet_g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         delete ctx;
         return nullptr;
     }
@@ -942,6 +891,9 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf *b : all) if (b->ptr) (void)hipFree(b->ptr);
     for (DevBuf &b : ctx->h_in) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->h_out) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->cl_ws) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->cl_in) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->cl_out) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -1,0 +1,71 @@
+// duet_internal.h -- host-side state shared by the translation units of libduet_ef.so (not part of the ABI).
+#ifndef DUET_INTERNAL_H
+#define DUET_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "duet_ef.h"
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct duet_ctx {
+    int device = 0;
+    std::string err;
+    int profiling = 0;                     // 0 off, 1 events around ef_classify only, 2 around every kernel
+    int ev_mode = 0;                       // mode the pooled events were recorded with
+    uint32_t dbg = 0;
+    unsigned long long *d_stamps = nullptr;
+    hipStream_t own_stream = nullptr;
+    // E/F plan (workspace keyed by the contig layout)
+    std::vector<uint32_t> plan_off;        // cached cand_ctg_off
+    uint32_t plan_C = 0;
+    DevBuf ws_small;                        // ctg_off | n_one | status | blk_ctg | blk_cnt
+    DevBuf ws_start, ws_ent, ws_one, ws_tmp, ws_c2;
+    uint32_t *d_ctg_off = nullptr, *d_n_one = nullptr, *d_status = nullptr, *d_blk_ctg = nullptr,
+             *d_blk_cnt = nullptr;
+    // host-run staging
+    DevBuf h_in[9], h_out[2];
+    // clustering (A0) workspace and host-run staging
+    DevBuf cl_ws[12], cl_in[4], cl_out[6];
+    // profiling events: 6 per run
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    bool pending_check = false;
+};
+
+extern thread_local std::string duet_g_last_error;
+
+inline int duet_fail(duet_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    duet_g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return duet_fail(ctx, e_ == hipErrorOutOfMemory ? DUET_ERR_OOM : DUET_ERR_HIP,      \
+                             std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+inline int duet_reserve(duet_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return DUET_OK;
+    if (b.ptr) HIP_TRY(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(ctx, hipMalloc(&b.ptr, want));
+    b.cap = want;
+    return DUET_OK;
+}
+
+#endif

@@ -233,6 +233,42 @@ def bench_genome(n_marks_target, seed, labels=None, reads_per_mark=0.2, mean_deg
     return out
 
 
+MARK_TYPES = {'DEL': 0, 'INS': 1, 'INV': 2, 'DUP': 3}
+
+
+def raw_marks(contigs, seed, pos_jitter=40, span_jitter_pct=6, shuffle=True):
+    """Raw SV marks (signatures) for the A0 clustering stage: every support-read mark of every candidate
+    becomes one (contig, type, pos, span) record near its candidate -- pos +- pos_jitter, span within
+    +- span_jitter_pct % of the candidate's |SVLEN| -- in shuffled order (a BAM scan emits them read by read).
+    -> dict(contig u16[M], type u8[M], pos u32[M], span u32[M], truth int64[M] (global candidate index))"""
+    rng = SplitMix(0xC1050000 + seed)
+    parts = {k: [] for k in ('contig', 'type', 'pos', 'span', 'truth')}
+    base = 0
+    for ci, c in enumerate(contigs):
+        deg = np.diff(c.cand_off)
+        M = int(c.cand_off[-1])
+        cand = np.repeat(np.arange(len(deg)), deg)
+        mag = np.abs(np.where(c.cand_svlen == -(1 << 62), 60, c.cand_svlen))
+        tcode = np.array([MARK_TYPES.get(t.split(':')[0], 2) for t in c.cand_svtype], dtype=np.int64)
+        jit = rng.between(M, -pos_jitter, pos_jitter)
+        pos = np.maximum(c.cand_pos[cand] + jit, 1)
+        sp = mag[cand]
+        sj = (sp * rng.between(M, -span_jitter_pct, span_jitter_pct)) // 100
+        span = np.maximum(sp + sj, 1)
+        parts['contig'].append(np.full(M, ci, dtype=np.int64))
+        parts['type'].append(tcode[cand])
+        parts['pos'].append(pos)
+        parts['span'].append(span)
+        parts['truth'].append(cand + base)
+        base += len(deg)
+    out = {k: np.concatenate(v) if v else np.zeros(0, dtype=np.int64) for k, v in parts.items()}
+    if shuffle and len(out['pos']):
+        perm = np.argsort(rng.u64(len(out['pos'])), kind='stable')
+        out = {k: v[perm] for k, v in out.items()}
+    return dict(contig=out['contig'].astype(np.uint16), type=out['type'].astype(np.uint8),
+                pos=out['pos'].astype(np.uint32), span=out['span'].astype(np.uint32), truth=out['truth'])
+
+
 # ------------------------------------------------------------------------------------------
 # adversarial small cases
 # ------------------------------------------------------------------------------------------

@@ -133,6 +133,52 @@ int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
  * return its length (or a negative status). */
 int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t cap);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Stage A0: span-position clustering of SV marks into candidates.
+ *
+ * Replaces what the reference delegates to the external `svim alignment ... --cluster_max_distance c`
+ * (src/duet/sv_calling.py:13-15; help text src/duet/utils.py:27-28).  svim is not part of the reference
+ * tree, so this stage follows this repository's own deterministic rule (oracle/cluster_oracle.c, DESIGN.md
+ * section 9), modelled on SVIM 1.4.2: marks ordered by (contig, type, centre = pos + span/2); partitions
+ * cut at a centre gap > part_gap or after part_max marks; span-position distance
+ *     min(|dpos|, |dend|, |dcentre|) / normalizer + |dspan| / max(span)
+ * in binary64; average linkage, merged while the closest pair is <= max_dist.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct duet_cluster_problem {
+    uint32_t n_marks;               /* M */
+    uint32_t part_gap;              /* 1000 */
+    uint32_t part_max;              /* 100 (1..128) */
+    uint32_t n_contigs_hint;        /* 0 = unknown; only narrows the sort key */
+    uint32_t n_types_hint;          /* 0 = unknown */
+    uint32_t max_pos_hint;          /* 0 = unknown */
+    uint32_t max_span_hint;         /* 0 = unknown */
+    uint32_t reserved;
+    double max_dist;                /* -c / --cluster_max_distance (0.9) */
+    double normalizer;              /* 900 */
+    const uint16_t *mark_contig;    /* [M] */
+    const uint8_t *mark_type;       /* [M] caller-defined SV type code */
+    const uint32_t *mark_pos;       /* [M] */
+    const uint32_t *mark_span;      /* [M] */
+} duet_cluster_problem;
+
+/* Candidates in (contig, type, centre) order; members of candidate j are
+ * order[cand_off[j] .. cand_off[j+1]) (mark indices, sorted order); cand_pos / cand_span are floor means.
+ * All arrays need room for M entries (cand_off: M+1).  n_cands is a device word for duet_cluster_run_device
+ * and a host word for duet_cluster_run_host. */
+typedef struct duet_cluster_result {
+    uint32_t *order;
+    uint32_t *cand_off;
+    uint16_t *cand_contig;
+    uint8_t *cand_type;
+    uint32_t *cand_pos;
+    uint32_t *cand_span;
+    uint32_t *n_cands;
+} duet_cluster_result;
+
+int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res,
+                            void *stream);
+int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res);
+
 #ifdef __cplusplus
 }
 #endif

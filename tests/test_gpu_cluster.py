@@ -1,0 +1,87 @@
+# coding=utf-8
+"""-m gpu: stage A0 (span-position clustering) through the C ABI against oracle/cluster_oracle.c, field
+for field (order, CSR offsets, candidate contig/type/pos/span)."""
+import numpy as np
+import pytest
+
+from duet_amd import _lib, synth
+from oracle import c_oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ('order', 'cand_off', 'cand_contig', 'cand_type', 'cand_pos', 'cand_span')
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def check(ctx, marks, **kw):
+    want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
+    for hints in (True, False):
+        got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
+        for f in FIELDS:
+            assert got[f].shape == want[f].shape, (f, got[f].shape, want[f].shape)
+            bad = np.nonzero(got[f] != want[f])[0]
+            assert bad.size == 0, (f, bad[:5], got[f][bad[:5]], want[f][bad[:5]])
+    return want
+
+
+def random_marks(seed, M, clumps=40, contigs=3, types=3, spread=60, span_lo=50, span_hi=2000):
+    rng = synth.SplitMix(7000 + seed)
+    pos = rng.between(M, 0, clumps) * 1500 + rng.between(M, 0, spread) + 1
+    span = rng.between(M, span_lo, span_hi)
+    span = np.where(rng.chance(M, 1, 2), (span // 100) * 100 + rng.between(M, 0, 8), span)
+    return dict(contig=rng.below(M, contigs).astype(np.uint16), type=rng.below(M, types).astype(np.uint8),
+                pos=pos.astype(np.uint32), span=span.astype(np.uint32))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_marks(ctx, seed):
+    marks = random_marks(seed, 3000 + 700 * seed)
+    check(ctx, marks, max_dist=[0.3, 0.5, 0.9, 1.4, 0.9, 0.05][seed])
+
+
+def test_edge_sizes(ctx):
+    for M in (1, 2, 3, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097):
+        check(ctx, random_marks(M, M, clumps=3))
+
+
+def test_big_partitions_hit_the_cap(ctx):
+    """Hundreds of marks within one gap-free stretch: partitions are cut every part_max marks and the large
+    (49..128 marks) kernel variant runs."""
+    rng = synth.SplitMix(42)
+    M = 5000
+    pos = 100000 + rng.between(M, 0, 3000)
+    marks = dict(contig=np.zeros(M, dtype=np.uint16), type=np.zeros(M, dtype=np.uint8), pos=pos.astype(np.uint32),
+                 span=rng.between(M, 100, 140).astype(np.uint32))
+    want = check(ctx, marks)
+    check(ctx, marks, part_max=128, max_dist=0.4)
+    check(ctx, marks, part_max=37, part_gap=5)
+    assert len(want['cand_off']) - 1 < M
+
+
+def test_zero_spans_and_identical_marks(ctx):
+    M = 600
+    marks = dict(contig=np.zeros(M, dtype=np.uint16), type=(np.arange(M) % 2).astype(np.uint8),
+                 pos=np.full(M, 777, dtype=np.uint32), span=np.zeros(M, dtype=np.uint32))
+    check(ctx, marks)
+
+
+def test_config2_marks_recover_candidates(ctx):
+    """The raw marks behind BASELINE config 2 (1.0M marks): full size, GPU == oracle, and clustering groups
+    the marks of a candidate together whenever candidates are far apart."""
+    contigs = H.case_contigs('config2', 1)
+    marks = synth.raw_marks(contigs, 1)
+    assert 990000 < len(marks['pos']) < 1010000
+    want = check(ctx, marks)
+    assert 60000 < len(want['cand_off']) - 1 < 140000
+
+
+def test_genome_marks(ctx):
+    marks = synth.raw_marks(synth.bench_genome(400000, 3), 3)
+    check(ctx, marks)
