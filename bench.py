@@ -224,6 +224,7 @@ def main():
             out['cpu_baseline_python'] = python_baseline([contig])
         if world == 1 and not args.no_extra:
             out['extra'] = extra_points(ctx, torch, engine, synth, DeviceProblem, args.large)
+            out['extra']['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
         print(json.dumps(out))
         sys.stdout.flush()
 
@@ -231,6 +232,33 @@ def main():
         dist_mod.barrier()
         dist_mod.destroy_process_group()
     ctx.close()
+
+
+def cluster_point(ctx, torch, synth, contigs):
+    """Stage A0 (span-position clustering, SVIM-mode) on the raw marks behind the same workload: jittered
+    (pos, span) per support read, shuffled; sort + partition + average linkage + emit, resident in HBM.
+    Reported beside the E/F number, not inside `value`: the reference computes A0 in an external binary."""
+    from duet_amd.devmem import DeviceCluster
+    from oracle import c_oracle
+    marks = synth.raw_marks(contigs, 1)
+    dc = DeviceCluster(marks)
+    for _ in range(3):
+        dc.run(ctx)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        dc.run(ctx)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'])
+    cpu = time.perf_counter() - t0
+    M = len(marks['pos'])
+    return {'marks': M, 'candidates_found': dc.n_cands(), 'candidates_oracle': int(len(want['cand_off']) - 1),
+            'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'algorithmic_bytes_18_per_mark': 18 * M,
+            'GBs_vs_B_A0': 18 * M / dt / 1e9, 'cpu_oracle_ms_1core': cpu * 1e3,
+            'note': 'launch-bound at this size: ~30 small launches (5 radix passes x 5 kernels + scans)'}
 
 
 def extra_points(ctx, torch, engine, synth, DeviceProblem, large):

@@ -240,16 +240,17 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
 // partitions
 // ---------------------------------------------------------------------------------------------
 
-// headpos[i] = i if sorted position i starts a natural partition (contig/type change or centre gap), else 0
-__global__ void cl_heads1(const ClParams p, uint32_t *headpos)
+// headpos[i] = i if sorted position i starts a natural partition (contig/type change or centre gap), else 0.
+// Everything needed is in the sorted keys: (contig, type) in the high bits, the centre in the low bits.
+__global__ void cl_heads1(const ClParams p, const uint64_t *keys, uint32_t *headpos)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.M) return;
     uint32_t h = 0;
     if (i > 0) {
-        const uint32_t a = p.sorted[i - 1], b = p.sorted[i];
-        const bool cut = p.contig[a] != p.contig[b] || p.type[a] != p.type[b] ||
-                         centre_of(p.pos[b], p.span[b]) - centre_of(p.pos[a], p.span[a]) > (uint64_t)p.part_gap;
+        const uint64_t a = keys[i - 1], b = keys[i];
+        const uint64_t cm = (1ull << p.centre_bits) - 1ull;
+        const bool cut = (a >> p.centre_bits) != (b >> p.centre_bits) || (b & cm) - (a & cm) > (uint64_t)p.part_gap;
         h = cut ? i : 0u;
     }
     headpos[i] = h;
@@ -271,6 +272,28 @@ __global__ void cl_parts(const ClParams p, const uint32_t *flag, const uint32_t 
     if (i == 0) part_start[*n_parts] = p.M;
 }
 
+// work lists by partition size (which agglomeration kernel variant takes it); list order is irrelevant --
+// every partition writes to its own fixed output range -- so a (wave-aggregated) atomic append is fine
+constexpr int kClasses = 4;
+__device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <= 48 ? 2 : 3); }   // class 1 unused
+
+__global__ void cl_classes(const ClParams p, uint32_t *lists /* [kClasses][M] */, uint32_t *counts /* [kClasses] */)
+{
+    const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = part < *p.n_parts;
+    const int cls = live ? size_class(p.part_start[part + 1] - p.part_start[part]) : -1;
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (!m) continue;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (cls == c) lists[(size_t)c * p.M + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = part;
+    }
+}
+
 // pcat[i] = clusters of the partition that starts at sorted position i, 0 elsewhere (may alias flag)
 __global__ void cl_pcat(const ClParams p, const uint32_t *flag, const uint32_t *pid, uint32_t *pcat)
 {
@@ -283,18 +306,32 @@ __global__ void cl_pcat(const ClParams p, const uint32_t *flag, const uint32_t *
 // agglomeration: one wavefront (64-thread workgroup) per partition
 // ---------------------------------------------------------------------------------------------
 
-template <int NMAX, int NMIN>
-__global__ __launch_bounds__(64) void cl_cluster(const ClParams p)
+// pair index q of the upper triangle (row i: j = i+1..n-1, rows in order) -> (i, j)
+__device__ __forceinline__ uint32_t tri_row_start(uint32_t i, uint32_t n) { return i * n - i * (i + 1) / 2; }
+
+__device__ __forceinline__ void tri_decode(uint32_t q, uint32_t n, uint32_t pairs, uint32_t &i, uint32_t &j)
+{
+    // rows counted from the end have lengths 1, 2, 3, ...: the pair's distance from the end picks the row
+    const uint32_t r = pairs - 1 - q;
+    uint32_t t = (uint32_t)((__fsqrt_rn(8.0f * (float)r + 1.0f) - 1.0f) * 0.5f);
+    while ((t + 1) * (t + 2) / 2 <= r) ++t;
+    while (t * (t + 1) / 2 > r) --t;
+    i = n - 2 - t;
+    j = i + 1 + (q - tri_row_start(i, n));
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(64) void cl_cluster(const ClParams p, const uint32_t *list, const uint32_t *count)
 {
     constexpr int TRI = NMAX * (NMAX - 1) / 2;
     __shared__ double s_d[TRI];
     __shared__ uint32_t s_pos[NMAX], s_span[NMAX], s_lab[NMAX], s_size[NMAX];
     const uint32_t lane = threadIdx.x;
-    const uint32_t P = *p.n_parts;
+    const uint32_t L = *count;
     const double inf = __builtin_inf();
-    for (uint32_t part = blockIdx.x; part < P; part += gridDim.x) {
+    for (uint32_t li = blockIdx.x; li < L; li += gridDim.x) {
+        const uint32_t part = list[li];
         const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
-        if (n <= (uint32_t)NMIN || n > (uint32_t)NMAX) continue;
         if (n == 1) {
             if (lane == 0) { p.label[s] = 0; p.pc[part] = 1; }
             continue;
@@ -308,60 +345,55 @@ __global__ __launch_bounds__(64) void cl_cluster(const ClParams p)
             s_size[i] = 1;
         }
         __syncthreads();
-        // span-position distance, upper triangle: row i holds j = i+1 .. n-1 at i*n - i(i+1)/2 + (j-i-1)
-        for (uint32_t i = 0; i + 1 < n; ++i) {
+        const uint32_t pairs = n * (n - 1) / 2;
+        // span-position distance of every pair, one pass over the triangle
+        for (uint32_t q = lane; q < pairs; q += 64) {
+            uint32_t i, j;
+            tri_decode(q, n, pairs, i, j);
             const uint64_t si = s_pos[i], ei = (uint64_t)s_pos[i] + s_span[i], ci = centre_of(s_pos[i], s_span[i]);
-            const uint32_t row = i * n - i * (i + 1) / 2;
-            for (uint32_t j = i + 1 + lane; j < n; j += 64) {
-                const uint64_t sj = s_pos[j], ej = (uint64_t)s_pos[j] + s_span[j], cj = centre_of(s_pos[j], s_span[j]);
-                uint64_t m = si > sj ? si - sj : sj - si;
-                const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
-                m = m2 < m ? m2 : m;
-                m = m3 < m ? m3 : m;
-                const uint32_t sa = s_span[i], sb = s_span[j];
-                const uint32_t smax = sa > sb ? sa : sb, sdif = sa > sb ? sa - sb : sb - sa;
-                const double dp = (double)m / p.normalizer;
-                const double ds = smax ? (double)sdif / (double)smax : 0.0;
-                s_d[row + (j - i - 1)] = dp + ds;
-            }
+            const uint64_t sj = s_pos[j], ej = (uint64_t)s_pos[j] + s_span[j], cj = centre_of(s_pos[j], s_span[j]);
+            uint64_t m = si > sj ? si - sj : sj - si;
+            const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
+            m = m2 < m ? m2 : m;
+            m = m3 < m ? m3 : m;
+            const uint32_t sa = s_span[i], sb = s_span[j];
+            const uint32_t smax = sa > sb ? sa : sb, sdif = sa > sb ? sa - sb : sb - sa;
+            const double dp = (double)m / p.normalizer;
+            const double ds = smax ? (double)sdif / (double)smax : 0.0;
+            s_d[q] = dp + ds;
         }
         __syncthreads();
-        const uint32_t pairs = n * (n - 1) / 2;
+        // each lane owns a contiguous run of pairs, so lane order is pair order
+        const uint32_t per = (pairs + 63) / 64;
+        const uint32_t q_lo = min(pairs, lane * per), q_hi = min(pairs, q_lo + per);
         for (uint32_t merges = 0; merges + 1 < n; ++merges) {
-            // wave-wide argmin over the triangle; inactive pairs hold +inf; ties -> smallest index
+            // wave-wide argmin over the triangle; inactive pairs hold +inf; ties -> smallest pair index
             double bd = inf;
             uint32_t bq = 0xFFFFFFFFu;
-            for (uint32_t q = lane; q < pairs; q += 64) {
+            for (uint32_t q = q_lo; q < q_hi; ++q) {
                 const double v = s_d[q];
                 if (v < bd) { bd = v; bq = q; }
             }
+            double md = bd;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(bd, off, 64);
-                const uint32_t oq = __shfl_xor(bq, off, 64);
-                if (od < bd || (od == bd && oq < bq)) { bd = od; bq = oq; }
+                const double od = __shfl_xor(md, off, 64);
+                md = od < md ? od : md;
             }
-            if (!(bd <= p.max_dist)) break;
-            // row a of pair bq: rs(a) <= bq < rs(a) + (n-1-a)
-            uint32_t a = 0;
-            {
-                bool hit0 = false, hit1 = false;
-                const uint32_t a0 = lane, a1 = lane + 64;
-                if (a0 + 1 < n) { const uint32_t rs = a0 * n - a0 * (a0 + 1) / 2; hit0 = rs <= bq && bq < rs + (n - 1 - a0); }
-                if (a1 + 1 < n) { const uint32_t rs = a1 * n - a1 * (a1 + 1) / 2; hit1 = rs <= bq && bq < rs + (n - 1 - a1); }
-                const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-                a = m0 ? (uint32_t)__ffsll((long long)m0) - 1u : 64u + (uint32_t)__ffsll((long long)m1) - 1u;
-            }
-            const uint32_t rsa = a * n - a * (a + 1) / 2;
-            const uint32_t b = a + 1 + (bq - rsa);
+            if (!(md <= p.max_dist)) break;
+            const unsigned long long tie = __ballot(bd == md);
+            bq = __shfl(bq, __ffsll((long long)tie) - 1, 64);
+            // row a of pair bq
+            uint32_t a, b;
+            tri_decode(bq, n, pairs, a, b);
             const double na = (double)s_size[a], nb = (double)s_size[b];
             __syncthreads();
             for (uint32_t k = lane; k < n; k += 64) {
                 if (k == a || k == b) continue;
                 const uint32_t lo_a = k < a ? k : a, hi_a = k < a ? a : k;
                 const uint32_t lo_b = k < b ? k : b, hi_b = k < b ? b : k;
-                const uint32_t qa = lo_a * n - lo_a * (lo_a + 1) / 2 + (hi_a - lo_a - 1);
-                const uint32_t qb = lo_b * n - lo_b * (lo_b + 1) / 2 + (hi_b - lo_b - 1);
+                const uint32_t qa = tri_row_start(lo_a, n) + (hi_a - lo_a - 1);
+                const uint32_t qb = tri_row_start(lo_b, n) + (hi_b - lo_b - 1);
                 const double da = s_d[qa], db = s_d[qb];
                 if (da == inf) continue;                       // k already merged away
                 s_d[qa] = (na * da + nb * db) / (na + nb);
@@ -384,6 +416,87 @@ __global__ __launch_bounds__(64) void cl_cluster(const ClParams p)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
         if (lane == 0) p.pc[part] = roots;
+    }
+}
+
+// Small partitions (n <= NS): one LANE per partition.  Each lane runs the whole agglomeration on its own
+// triangle, stored transposed in LDS ([entry][lane]) so that the 64 lanes of a wave hit 64 different banks.
+// Same arithmetic, same pair order, same tie-break as the wave-per-partition kernel.
+template <int NS>
+__global__ __launch_bounds__(64) void cl_cluster_small(const ClParams p, const uint32_t *list, const uint32_t *count)
+{
+    constexpr int TRI = NS * (NS - 1) / 2;
+    __shared__ double s_d[TRI][64];
+    __shared__ uint32_t s_pos[NS][64], s_span[NS][64];
+    __shared__ uint8_t s_lab[NS][64], s_size[NS][64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t L = *count;
+    const double inf = __builtin_inf();
+    for (uint32_t base = blockIdx.x * 64u; base < L; base += gridDim.x * 64u) {
+        const uint32_t li = base + lane;
+        if (li >= L) continue;
+        const uint32_t part = list[li];
+        const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t a = p.sorted[s + i];
+            s_pos[i][lane] = p.pos[a];
+            s_span[i][lane] = p.span[a];
+            s_lab[i][lane] = (uint8_t)i;
+            s_size[i][lane] = 1;
+        }
+        uint32_t q = 0;
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+            const uint32_t pi = s_pos[i][lane], spi = s_span[i][lane];
+            const uint64_t si = pi, ei = (uint64_t)pi + spi, ci = centre_of(pi, spi);
+            for (uint32_t j = i + 1; j < n; ++j, ++q) {
+                const uint32_t pj = s_pos[j][lane], spj = s_span[j][lane];
+                const uint64_t sj = pj, ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
+                uint64_t m = si > sj ? si - sj : sj - si;
+                const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
+                m = m2 < m ? m2 : m;
+                m = m3 < m ? m3 : m;
+                const uint32_t smax = spi > spj ? spi : spj, sdif = spi > spj ? spi - spj : spj - spi;
+                const double dp = (double)m / p.normalizer;
+                const double ds = smax ? (double)sdif / (double)smax : 0.0;
+                s_d[q][lane] = dp + ds;
+            }
+        }
+        const uint32_t pairs = q;
+        for (uint32_t merges = 0; merges + 1 < n; ++merges) {
+            double bd = inf;
+            uint32_t ba = 0, bb = 0, bq = 0;
+            q = 0;
+            for (uint32_t i = 0; i + 1 < n; ++i)
+                for (uint32_t j = i + 1; j < n; ++j, ++q) {
+                    const double v = s_d[q][lane];
+                    if (v < bd) { bd = v; ba = i; bb = j; bq = q; }
+                }
+            if (!(bd <= p.max_dist)) break;
+            const double na = (double)s_size[ba][lane], nb = (double)s_size[bb][lane];
+            for (uint32_t k = 0; k < n; ++k) {
+                if (k == ba || k == bb) continue;
+                const uint32_t lo_a = k < ba ? k : ba, hi_a = k < ba ? ba : k;
+                const uint32_t lo_b = k < bb ? k : bb, hi_b = k < bb ? bb : k;
+                const uint32_t qa = tri_row_start(lo_a, n) + (hi_a - lo_a - 1);
+                const uint32_t qb = tri_row_start(lo_b, n) + (hi_b - lo_b - 1);
+                const double da = s_d[qa][lane], db = s_d[qb][lane];
+                if (da == inf) continue;
+                s_d[qa][lane] = (na * da + nb * db) / (na + nb);
+                s_d[qb][lane] = inf;
+            }
+            s_d[bq][lane] = inf;
+            s_size[ba][lane] = (uint8_t)(s_size[ba][lane] + s_size[bb][lane]);
+            for (uint32_t k = 0; k < n; ++k)
+                if (s_lab[k][lane] == bb) s_lab[k][lane] = (uint8_t)ba;
+        }
+        (void)pairs;
+        uint32_t roots = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t l = s_lab[k][lane];
+            p.label[s + k] = (uint8_t)l;
+            roots += l == k;
+        }
+        p.pc[part] = roots;
     }
 }
 
@@ -471,11 +584,11 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     const uint32_t nb_rx = (M + kRxTile - 1) / kRxTile;
     const uint32_t nb_sc = (M + kScanTile - 1) / kScanTile;
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
-    const size_t sizes[12] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
+    const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M, (size_t)M * 4, 64};
+                              ((size_t)M + 1) * 4, (size_t)M, (size_t)M * 4, 64, (size_t)M * 4 * kClasses, 16};
     int rc;
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 14; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
     uint64_t *keysA = (uint64_t *)ctx->cl_ws[0].ptr, *keysB = (uint64_t *)ctx->cl_ws[1].ptr;
     uint32_t *valsA = (uint32_t *)ctx->cl_ws[2].ptr, *valsB = (uint32_t *)ctx->cl_ws[3].ptr;
@@ -514,7 +627,7 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
         uint32_t *tv = vin; vin = vout; vout = tv;
     }
     p.sorted = vin;
-    hipLaunchKernelGGL(cl_heads1, g256, b256, 0, st, p, tmpA);
+    hipLaunchKernelGGL(cl_heads1, g256, b256, 0, st, p, (const uint64_t *)kin, tmpA);
     launch_scan<1>(tmpA, M, spart, tmpB, nullptr, st);            // tmpB[i] = start of i's natural partition
     hipLaunchKernelGGL(cl_heads2, g256, b256, 0, st, p, (const uint32_t *)tmpB, tmpA);     // tmpA = head flags
     launch_scan<0>(tmpA, M, spart, tmpB, scal, st);               // tmpB = partition id, scal[0] = #partitions
@@ -522,8 +635,23 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
                        (const uint32_t *)scal);
     p.part_start = part_start; p.n_parts = scal; p.label = label; p.pc = pc;
     const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
-    hipLaunchKernelGGL((cl_cluster<48, 0>), dim3(grid), dim3(64), 0, st, p);
-    hipLaunchKernelGGL((cl_cluster<128, 48>), dim3(grid < 1024u ? grid : 1024u), dim3(64), 0, st, p);
+    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M]
+    uint32_t *cnts = scal + 2;
+    HIP_TRY(ctx, hipMemsetAsync(cnts, 0, 4 * kClasses, st));
+    hipLaunchKernelGGL(cl_classes, g256, b256, 0, st, p, lists, cnts);
+    // the few large partitions (49..128 marks) take long, serial agglomerations: run them on a side stream
+    // beside the bulk
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side, ctx->cl_fork, 0));
+    hipLaunchKernelGGL((cl_cluster<128>), dim3(grid < 1024u ? grid : 1024u), dim3(64), 0, ctx->cl_side, p,
+                       (const uint32_t *)(lists + 3 * (size_t)M), (const uint32_t *)(cnts + 3));
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_join, ctx->cl_side));
+    const uint32_t g_lane = (M + 63) / 64 < 4096u ? (M + 63) / 64 : 4096u;
+    hipLaunchKernelGGL((cl_cluster_small<8>), dim3(g_lane), dim3(64), 0, st, p, (const uint32_t *)lists,
+                       (const uint32_t *)(cnts + 0));
+    hipLaunchKernelGGL((cl_cluster<48>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
+                       (const uint32_t *)(cnts + 2));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join, 0));
     // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
     hipLaunchKernelGGL(cl_pcat, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, tmpA);

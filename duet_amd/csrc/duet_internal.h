@@ -32,7 +32,9 @@ struct duet_ctx {
     // host-run staging
     DevBuf h_in[9], h_out[2];
     // clustering (A0) workspace and host-run staging
-    DevBuf cl_ws[12], cl_in[4], cl_out[6];
+    DevBuf cl_ws[14], cl_in[4], cl_out[6];
+    hipStream_t cl_side = nullptr;         // side stream + fork/join events for the large-partition kernel
+    hipEvent_t cl_fork = nullptr, cl_join = nullptr;
     // profiling events: 6 per run
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;

@@ -47,3 +47,57 @@ class DeviceProblem(object):
         """-> (pred u8[C], ps u32[C]) on the host (synchronises)."""
         from duet_amd.dist import unpack_block
         return unpack_block(self.out_block.cpu().numpy(), self.n_max, self.soa.n_cands)
+
+
+class DeviceCluster(object):
+    """Raw SV marks uploaded once + result buffers, for repeated duet_cluster_run_device (stage A0)."""
+
+    def __init__(self, marks, max_dist=0.9, part_gap=1000, part_max=100, normalizer=900.0, device='cuda:0'):
+        import ctypes
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        M = len(marks['pos'])
+        self.M = M
+        self.keep = {}
+
+        def up(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            t = torch.zeros(a.nbytes + 64, dtype=torch.uint8, device=self.device)
+            if a.nbytes:
+                t[:a.nbytes] = torch.from_numpy(np.frombuffer(a.tobytes(), dtype=np.uint8).copy()).to(self.device)
+            return t
+
+        p = _lib.ClusterProblem()
+        p.n_marks, p.part_gap, p.part_max = M, int(part_gap), int(part_max)
+        p.max_dist, p.normalizer = float(max_dist), float(normalizer)
+        if M:
+            p.n_contigs_hint = int(np.max(marks['contig'])) + 1
+            p.n_types_hint = int(np.max(marks['type'])) + 1
+            p.max_pos_hint = int(np.max(marks['pos']))
+            p.max_span_hint = max(int(np.max(marks['span'])), 1)
+        for field, key, dt in (('mark_contig', 'contig', np.uint16), ('mark_type', 'type', np.uint8),
+                               ('mark_pos', 'pos', np.uint32), ('mark_span', 'span', np.uint32)):
+            self.keep[field] = up(marks[key], dt)
+            setattr(p, field, self.keep[field].data_ptr())
+        self.problem = p
+        r = _lib.ClusterResult()
+        sizes = dict(order=4 * M, cand_off=4 * (M + 1), cand_contig=2 * M, cand_type=M, cand_pos=4 * M, cand_span=4 * M,
+                     n_cands=4)
+        for k, nbytes in sizes.items():
+            self.keep['out_' + k] = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)
+            setattr(r, k, self.keep['out_' + k].data_ptr())
+        self.result = r
+        self._ct = ctypes
+
+    def run(self, ctx, stream=None):
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        ct = self._ct
+        rc = ctx.lib.duet_cluster_run_device(ctx.handle, ct.byref(self.problem), ct.byref(self.result),
+                                             ct.c_void_p(stream))
+        if rc:
+            ctx._raise(rc)
+
+    def n_cands(self):
+        return int(self.keep['out_n_cands'][:4].cpu().numpy().view(np.uint32)[0])
