@@ -1,0 +1,718 @@
+// duet_ingest.cpp -- native host-side ingest and row emission for Duet's step E/F (see include/duet_ingest.h).
+// Plain C++17 + zlib; no GPU code.  Every rule below restates the reference's Python for well-formed
+// ASCII input and bails out with DUET_INGEST_UNSUPPORTED otherwise, so that the Python host path (which
+// mirrors upstream's exceptions) takes over.
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "duet_ingest.h"
+
+namespace {
+
+constexpr uint32_t kAbsent = 0xFFFFFFFFu;
+constexpr uint32_t kPcSat = (1u << 30) - 2;
+
+struct Span {
+    const char *p;
+    size_t n;
+};
+
+inline bool is_py_space(unsigned char c)
+{   // str.split() / str.strip() whitespace, ASCII part
+    return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f);
+}
+
+// Python int(text) for plain ASCII decimals: [+-]digits, single underscores between digits.
+bool py_int(const char *s, size_t n, long long &out)
+{
+    size_t i = 0;
+    bool neg = false;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
+    if (i >= n) return false;
+    unsigned long long v = 0;
+    bool prev_digit = false;
+    int digits = 0;
+    for (; i < n; ++i) {
+        const char c = s[i];
+        if (c >= '0' && c <= '9') {
+            if (++digits > 18) return false;
+            v = v * 10 + (unsigned)(c - '0');
+            prev_digit = true;
+        } else if (c == '_' && prev_digit && i + 1 < n && s[i + 1] >= '0' && s[i + 1] <= '9') {
+            prev_digit = false;
+        } else {
+            return false;
+        }
+    }
+    out = neg ? -(long long)v : (long long)v;
+    return true;
+}
+
+const char *find_sub(const char *hay, size_t hn, const char *needle, size_t nn)
+{
+    if (nn > hn) return nullptr;
+    return (const char *)memmem(hay, hn, needle, nn);
+}
+
+inline bool contains(Span s, const char *needle) { return find_sub(s.p, s.n, needle, strlen(needle)) != nullptr; }
+
+// first ';'-separated item of `info` containing any of the needles
+bool first_item_with(Span info, const char *const *needles, int nn, Span &item)
+{
+    size_t i = 0;
+    while (i <= info.n) {
+        size_t j = i;
+        while (j < info.n && info.p[j] != ';') ++j;
+        Span it{info.p + i, j - i};
+        for (int k = 0; k < nn; ++k)
+            if (contains(it, needles[k])) { item = it; return true; }
+        i = j + 1;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// read-name -> index table (open addressing over an arena of names)
+// ---------------------------------------------------------------------------------------------
+struct NameTable {
+    std::vector<char> arena;
+    std::vector<uint32_t> off, len;
+    std::vector<uint32_t> slots;      // index + 1, 0 = empty
+    uint32_t mask = 0;
+
+    static uint64_t hash(const char *s, size_t n)
+    {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 1099511628211ull; }
+        return h ^ (h >> 29);
+    }
+    void grow()
+    {
+        const uint32_t cap = slots.empty() ? 1024u : (uint32_t)slots.size() * 2u;
+        std::vector<uint32_t> ns(cap, 0);
+        mask = cap - 1;
+        for (uint32_t i = 0; i < off.size(); ++i) {
+            uint32_t s = (uint32_t)hash(arena.data() + off[i], len[i]) & mask;
+            while (ns[s]) s = (s + 1) & mask;
+            ns[s] = i + 1;
+        }
+        slots.swap(ns);
+    }
+    int find(const char *s, size_t n) const
+    {
+        if (slots.empty()) return -1;
+        uint32_t h = (uint32_t)hash(s, n) & mask;
+        for (;;) {
+            const uint32_t v = slots[h];
+            if (!v) return -1;
+            const uint32_t i = v - 1;
+            if (len[i] == n && memcmp(arena.data() + off[i], s, n) == 0) return (int)i;
+            h = (h + 1) & mask;
+        }
+    }
+    uint32_t find_or_add(const char *s, size_t n, bool &added)
+    {
+        if ((off.size() + 1) * 2 > slots.size()) grow();
+        uint32_t h = (uint32_t)hash(s, n) & mask;
+        for (;;) {
+            const uint32_t v = slots[h];
+            if (!v) break;
+            const uint32_t i = v - 1;
+            if (len[i] == n && memcmp(arena.data() + off[i], s, n) == 0) { added = false; return i; }
+            h = (h + 1) & mask;
+        }
+        const uint32_t idx = (uint32_t)off.size();
+        off.push_back((uint32_t)arena.size());
+        len.push_back((uint32_t)n);
+        arena.insert(arena.end(), s, s + n);
+        slots[h] = idx + 1;
+        added = true;
+        return idx;
+    }
+};
+
+bool read_file(const char *path, std::vector<char> &buf)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize(sz > 0 ? (size_t)sz : 0);
+    const size_t got = sz > 0 ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    return got == buf.size();
+}
+
+}  // namespace
+
+struct duet_ingest {
+    std::vector<std::string> contigs;
+    std::unordered_map<std::string, int> owner;
+    bool alias = false;
+    std::vector<NameTable> tables;
+    std::vector<std::vector<uint64_t>> tags;
+    std::string err;
+    // VCF
+    std::vector<char> vcf;
+    std::vector<Span> contig_lines;               // first tokens containing '##contig=<ID='
+    std::vector<uint32_t> cand_ctg_off, read_off, cand_pos, cand_svlen, cand_svread, cand_refread, cand_off, mark_read;
+    std::vector<uint8_t> cand_gt_ok, cand_plus;   // cand_plus: svtype is exactly INS or DUP (sign rule, :225)
+    std::vector<uint64_t> read_tag;
+    std::vector<Span> c_chrom, c_ref, c_alt, c_type;
+    bool parsed = false;
+};
+
+namespace {
+
+int unsupported(duet_ingest *g, const std::string &why)
+{
+    g->err = why;
+    return DUET_INGEST_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BGZF / BAM
+// ---------------------------------------------------------------------------------------------
+struct Block {
+    size_t in_off, in_len, out_off, out_len;
+};
+
+int inflate_bgzf(duet_ingest *g, const std::vector<char> &file, std::vector<unsigned char> &out, int threads)
+{
+    std::vector<Block> blocks;
+    size_t p = 0, total = 0;
+    const unsigned char *d = (const unsigned char *)file.data();
+    while (p < file.size()) {
+        if (p + 18 > file.size() || d[p] != 31 || d[p + 1] != 139 || d[p + 2] != 8 || !(d[p + 3] & 4))
+            return unsupported(g, "not a BGZF stream");
+        const unsigned xlen = d[p + 10] | (d[p + 11] << 8);
+        size_t q = p + 12, xend = p + 12 + xlen;
+        int bsize = -1;
+        while (q + 4 <= xend && xend <= file.size()) {
+            const unsigned slen = d[q + 2] | (d[q + 3] << 8);
+            if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2) bsize = d[q + 4] | (d[q + 5] << 8);
+            q += 4 + slen;
+        }
+        if (bsize < 0) return unsupported(g, "gzip member without BGZF block size");
+        const size_t blen = (size_t)bsize + 1;
+        if (p + blen > file.size() || blen < xlen + 20) return unsupported(g, "truncated BGZF block");
+        const unsigned char *tail = d + p + blen - 4;
+        const size_t isize = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((size_t)tail[3] << 24);
+        blocks.push_back(Block{p + 12 + xlen, blen - xlen - 20, total, isize});
+        total += isize;
+        p += blen;
+    }
+    out.resize(total);
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        z_stream zs;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= blocks.size() || bad.load()) return;
+            const Block &b = blocks[i];
+            if (b.out_len == 0) continue;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+            zs.next_in = (Bytef *)(d + b.in_off);
+            zs.avail_in = (uInt)b.in_len;
+            zs.next_out = out.data() + b.out_off;
+            zs.avail_out = (uInt)b.out_len;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; return; }
+        }
+    };
+    int nt = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if (blocks.size() < 8) nt = 1;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (bad.load()) return unsupported(g, "BGZF inflate failed");
+    return DUET_INGEST_OK;
+}
+
+struct Aux {
+    char tag[2];
+    unsigned char type;
+    size_t val_off;          // offset of the value bytes
+    size_t next;
+};
+
+// length of one aux field's value; 0 on error
+bool aux_step(const unsigned char *b, size_t p, size_t end, Aux &a)
+{
+    if (p + 3 > end) return false;
+    a.tag[0] = (char)b[p];
+    a.tag[1] = (char)b[p + 1];
+    a.type = b[p + 2];
+    a.val_off = p + 3;
+    size_t q = p + 3;
+    switch (a.type) {
+        case 'c': case 'C': case 'A': q += 1; break;
+        case 's': case 'S': q += 2; break;
+        case 'i': case 'I': case 'f': q += 4; break;
+        case 'Z': case 'H':
+            while (q < end && b[q]) ++q;
+            if (q >= end) return false;
+            ++q;
+            break;
+        case 'B': {
+            if (q + 5 > end) return false;
+            const unsigned char sub = b[q];
+            const size_t cnt = b[q + 1] | (b[q + 2] << 8) | (b[q + 3] << 16) | ((size_t)b[q + 4] << 24);
+            const size_t w = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+            q += 5 + w * cnt;
+            break;
+        }
+        default: return false;
+    }
+    if (q > end) return false;
+    a.next = q;
+    return true;
+}
+
+inline bool aux_is_int(unsigned char t) { return t == 'c' || t == 'C' || t == 's' || t == 'S' || t == 'i' || t == 'I'; }
+
+long long aux_int(const unsigned char *b, const Aux &a)
+{
+    const unsigned char *v = b + a.val_off;
+    switch (a.type) {
+        case 'c': return (int8_t)v[0];
+        case 'C': return v[0];
+        case 's': return (int16_t)(v[0] | (v[1] << 8));
+        case 'S': return (uint16_t)(v[0] | (v[1] << 8));
+        case 'i': return (int32_t)(v[0] | (v[1] << 8) | (v[2] << 16) | ((uint32_t)v[3] << 24));
+        default: return (uint32_t)(v[0] | (v[1] << 8) | (v[2] << 16) | ((uint32_t)v[3] << 24));
+    }
+}
+
+bool aux_has_space(const unsigned char *b, const Aux &a)
+{
+    if (a.type == 'A') return is_py_space(b[a.val_off]);
+    if (a.type == 'Z' || a.type == 'H') {
+        for (size_t q = a.val_off; b[q]; ++q)
+            if (is_py_space(b[q])) return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+duet_ingest *duet_ingest_create(int n_contigs, const char *const *contig_names)
+{
+    if (n_contigs < 0 || (n_contigs > 0 && !contig_names)) return nullptr;
+    duet_ingest *g = new duet_ingest();
+    g->contigs.reserve(n_contigs);
+    for (int k = 0; k < n_contigs; ++k) {
+        g->contigs.emplace_back(contig_names[k] ? contig_names[k] : "");
+        const std::string &c = g->contigs.back();
+        for (const std::string &nm : {std::string("chr") + c, c}) {
+            auto it = g->owner.find(nm);
+            if (it == g->owner.end()) g->owner.emplace(nm, k);
+            else if (it->second != k) g->alias = true;
+        }
+    }
+    g->tables.resize(n_contigs);
+    g->tags.resize(n_contigs);
+    return g;
+}
+
+void duet_ingest_destroy(duet_ingest *g) { delete g; }
+const char *duet_ingest_error(const duet_ingest *g) { return g ? g->err.c_str() : "null"; }
+void duet_ingest_free(void *p) { free(p); }
+
+int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int threads)
+{
+    if (!g || contig < 0 || contig >= (int)g->contigs.size() || !path) return DUET_INGEST_INVALID;
+    std::vector<char> file;
+    if (!read_file(path, file)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+    if (file.empty()) return DUET_INGEST_OK;                       // an empty file prints nothing (no alignments)
+    std::vector<unsigned char> buf;
+    int rc = inflate_bgzf(g, file, buf, threads);
+    if (rc) return rc;
+    const unsigned char *b = buf.data();
+    const size_t n = buf.size();
+    auto u32 = [&](size_t p) { return (uint32_t)(b[p] | (b[p + 1] << 8) | (b[p + 2] << 16) | ((uint32_t)b[p + 3] << 24)); };
+    if (n < 12 || memcmp(b, "BAM\1", 4) != 0) return unsupported(g, "not a BAM file");
+    size_t p = 8 + (size_t)u32(4);
+    if (p + 4 > n) return unsupported(g, "truncated BAM header");
+    const uint32_t n_ref = u32(p);
+    p += 4;
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (p + 4 > n) return unsupported(g, "truncated BAM header");
+        p += 4 + (size_t)u32(p) + 4;
+    }
+    NameTable &tab = g->tables[contig];
+    std::vector<uint64_t> &tags = g->tags[contig];
+    while (p + 4 <= n) {
+        const size_t bs = u32(p), end = p + 4 + bs;
+        if (end > n || bs < 32) return unsupported(g, "truncated BAM record");
+        const unsigned l_name = b[p + 12];
+        const unsigned n_cig = b[p + 16] | (b[p + 17] << 8);
+        const size_t l_seq = u32(p + 20);
+        size_t q = p + 36;
+        const char *name = (const char *)b + q;
+        const size_t name_len = l_name ? l_name - 1 : 0;
+        q += l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+        if (q > end) return unsupported(g, "corrupt BAM record");
+        // the last three aux fields are the last three whitespace tokens of the text line -- provided there
+        // are at least three and none of them contains whitespace
+        Aux last[3];
+        int n_aux = 0;
+        while (q < end) {
+            Aux a;
+            if (!aux_step(b, q, end, a)) return unsupported(g, "corrupt aux field");
+            last[0] = last[1]; last[1] = last[2]; last[2] = a;
+            ++n_aux;
+            q = a.next;
+        }
+        if (n_aux < 3) {
+            // The last three tokens then reach into the mandatory columns (..., SEQ, QUAL, aux...): tok[-2] is
+            // aux[0] (2 aux fields), QUAL (1) or SEQ (0).  Such a line is skipped unless tok[-2] contains
+            // 'PC:i:', in which case upstream goes on to int() a column that is not a tag -- left to Python.
+            bool maybe = false;
+            if (n_aux == 2) {
+                const Aux &a0 = last[1];
+                maybe = (aux_is_int(a0.type) && a0.tag[0] == 'P' && a0.tag[1] == 'C') || a0.type == 'Z' || a0.type == 'H' ||
+                        aux_has_space(b, last[1]) || aux_has_space(b, last[2]);
+            } else if (n_aux == 1) {
+                static const unsigned char pat[5] = {'P' - 33, 'C' - 33, ':' - 33, 'i' - 33, ':' - 33};
+                const unsigned char *ql = b + (p + 36 + l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2);
+                maybe = l_seq >= 5 && ql[0] != 255 && memmem(ql, l_seq, pat, 5) != nullptr;
+                maybe = maybe || aux_has_space(b, last[2]);
+            }
+            if (maybe) return unsupported(g, "alignment with fewer than three aux fields and a PC-like column");
+            p = end;
+            continue;
+        }
+        // 'PC:i:' in tok[-2]
+        const Aux &t2 = last[1];
+        bool hit = aux_is_int(t2.type) && t2.tag[0] == 'P' && t2.tag[1] == 'C';
+        if (!hit && (t2.type == 'Z' || t2.type == 'H')) {
+            const char *v = (const char *)b + t2.val_off;
+            if (strstr(v, "PC:i:")) return unsupported(g, "string aux value containing 'PC:i:'");
+        }
+        if (hit) {
+            if (!aux_is_int(last[0].type) || !aux_is_int(last[2].type))
+                return unsupported(g, "HP/PS neighbours of PC are not integers");
+            const long long hap = aux_int(b, last[0]), pc = aux_int(b, t2), ps = aux_int(b, last[2]);
+            if (pc < 0 || ps < 0 || ps > 0xFFFFFFFELL) return unsupported(g, "PC/PS out of range");
+            for (size_t i = 0; i < name_len; ++i)
+                if ((unsigned char)name[i] >= 0x80) return unsupported(g, "non-ASCII read name");
+            const uint64_t code = (hap == 1 || hap == 2) ? (uint64_t)hap : 3ull;
+            const uint64_t pcc = pc > (long long)kPcSat ? kPcSat : (uint64_t)pc;
+            const uint64_t word = (code << 62) | (pcc << 32) | (uint64_t)ps;
+            bool added;
+            const uint32_t idx = tab.find_or_add(name, name_len, added);
+            if (added) tags.push_back(word); else tags[idx] = word;      // later lines win (:29)
+        }
+        p = end;
+    }
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_parse_vcf(duet_ingest *g, const char *path)
+{
+    if (!g || !path) return DUET_INGEST_INVALID;
+    if (g->alias) return unsupported(g, "contig list names a contig twice");
+    if (!read_file(path, g->vcf)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+    const char *d = g->vcf.data();
+    const size_t n = g->vcf.size();
+    for (size_t i = 0; i < n; ++i)
+        if ((unsigned char)d[i] >= 0x80 || d[i] == 0) return unsupported(g, "non-ASCII byte in the VCF");
+    const int K = (int)g->contigs.size();
+
+    struct Rec { Span tok[10]; };
+    std::vector<std::vector<Rec>> per(K);
+    g->contig_lines.clear();
+    size_t p = 0;
+    std::string key;
+    while (p < n) {
+        size_t e = p;
+        while (e < n && d[e] != '\n' && d[e] != '\r') ++e;          // universal newlines
+        // tokens of the line
+        Rec r;
+        int nt = 0;
+        size_t i = p;
+        while (i < e) {
+            while (i < e && is_py_space((unsigned char)d[i])) ++i;
+            if (i >= e) break;
+            size_t j = i;
+            while (j < e && !is_py_space((unsigned char)d[j])) ++j;
+            if (nt < 10) r.tok[nt] = Span{d + i, j - i};
+            ++nt;
+            i = j;
+        }
+        if (nt == 0) {
+            // a blank line raises IndexError upstream (read_file.py:30) -- except the empty string after a final
+            // line break, which readlines() does not produce
+            const bool at_end = e >= n;
+            if (!(at_end && p == e)) return unsupported(g, "blank line in the VCF");
+        } else {
+            if (contains(r.tok[0], "##contig=<ID=")) g->contig_lines.push_back(r.tok[0]);
+            key.assign(r.tok[0].p, r.tok[0].n);
+            auto it = g->owner.find(key);
+            if (it != g->owner.end()) {
+                if (nt < 10) return unsupported(g, "record with fewer than 10 columns");
+                per[it->second].push_back(r);
+            }
+        }
+        p = e + 1;
+        if (e < n && d[e] == '\r' && p < n && d[p] == '\n') ++p;
+    }
+
+    size_t C = 0;
+    for (auto &v : per) C += v.size();
+    g->cand_ctg_off.assign(K + 1, 0);
+    g->read_off.assign(K + 1, 0);
+    for (auto *v : {&g->cand_pos, &g->cand_svlen, &g->cand_svread, &g->cand_refread}) { v->clear(); v->reserve(C); }
+    g->cand_gt_ok.clear(); g->cand_plus.clear(); g->cand_off.assign(1, 0); g->mark_read.clear();
+    g->c_chrom.clear(); g->c_ref.clear(); g->c_alt.clear(); g->c_type.clear();
+    g->read_tag.clear();
+    for (int k = 0; k < K; ++k) {
+        g->read_off[k + 1] = g->read_off[k] + (uint32_t)g->tags[k].size();
+        g->read_tag.insert(g->read_tag.end(), g->tags[k].begin(), g->tags[k].end());
+    }
+
+    static const char *const kSupp[] = {"SUPPORT=", "SR=", "RE="};
+    static const char *const kNames[] = {"RNAMES=", "READS="};
+    static const char *const kLen[] = {"SVLEN="};
+    static const char *const kType[] = {"SVTYPE="};
+    for (int k = 0; k < K; ++k) {
+        const std::vector<Rec> &recs = per[k];
+        if (!recs.empty()) {
+            // layout switches from the contig's FIRST record (read_file.py:41,49,57,63,65)
+            Span it;
+            if (!first_item_with(recs[0].tok[7], kSupp, 3, it)) return unsupported(g, "first record without a support count");
+            const size_t supp_cut = contains(it, "SUPPORT=") ? 8 : 3;
+            if (!first_item_with(recs[0].tok[7], kNames, 2, it)) return unsupported(g, "first record without read names");
+            const size_t rn_cut = contains(it, "RNAMES=") ? 7 : 6;
+            int fmt_kind;
+            {
+                const Span s = recs[0].tok[9];
+                int nsub = 1;
+                size_t last = 0;
+                for (size_t i = 0; i < s.n; ++i)
+                    if (s.p[i] == ':') { ++nsub; last = i + 1; }
+                if (nsub < 3) return unsupported(g, "sample column with fewer than three fields");
+                if (nsub > 4) fmt_kind = 0;
+                else fmt_kind = memchr(s.p + last, ',', s.n - last) ? 2 : 1;
+            }
+            const NameTable &tab = g->tables[k];
+            const uint32_t rbase = g->read_off[k];
+            for (const Rec &r : recs) {
+                long long v;
+                if (!py_int(r.tok[1].p, r.tok[1].n, v) || v < 0 || v > 0xFFFFFFFFLL) return unsupported(g, "POS");
+                g->cand_pos.push_back((uint32_t)v);
+                // SVLEN: first item containing 'SVLEN='; missing or exactly 'SVLEN=.' -> 0; '>' anywhere -> skip 7
+                long long svlen = 0;
+                if (first_item_with(r.tok[7], kLen, 1, it) && !(it.n == 7 && memcmp(it.p, "SVLEN=.", 7) == 0)) {
+                    const size_t cut = memchr(it.p, '>', it.n) ? 7 : 6;
+                    if (it.n < cut || !py_int(it.p + cut, it.n - cut, svlen)) return unsupported(g, "SVLEN");
+                }
+                if (svlen < 0) svlen = -svlen;
+                if (svlen > 0xFFFFFFFFLL) return unsupported(g, "SVLEN range");
+                g->cand_svlen.push_back((uint32_t)svlen);
+                if (!first_item_with(r.tok[7], kType, 1, it) || it.n < 7) return unsupported(g, "SVTYPE");
+                const Span ty{it.p + 7, it.n - 7};
+                g->c_type.push_back(ty);
+                g->cand_plus.push_back((ty.n == 3 && (memcmp(ty.p, "INS", 3) == 0 || memcmp(ty.p, "DUP", 3) == 0)) ? 1 : 0);
+                if (!first_item_with(r.tok[7], kSupp, 3, it) || it.n < supp_cut ||
+                    !py_int(it.p + supp_cut, it.n - supp_cut, v) || v < 0 || v > 0xFFFFFFFFLL)
+                    return unsupported(g, "support count");
+                g->cand_svread.push_back((uint32_t)v);
+                if (!first_item_with(r.tok[7], kNames, 2, it) || it.n < rn_cut) return unsupported(g, "read names");
+                {   // ','.split keeps empty names
+                    const char *s = it.p + rn_cut;
+                    const size_t sn = it.n - rn_cut;
+                    size_t i = 0;
+                    for (;;) {
+                        size_t j = i;
+                        while (j < sn && s[j] != ',') ++j;
+                        const int idx = tab.find(s + i, j - i);
+                        g->mark_read.push_back(idx < 0 ? kAbsent : rbase + (uint32_t)idx);
+                        if (j >= sn) break;
+                        i = j + 1;
+                    }
+                }
+                if (g->mark_read.size() > 0xFFFFFFF0ull) return unsupported(g, "too many marks");
+                g->cand_off.push_back((uint32_t)g->mark_read.size());
+                // sample column
+                const Span s = r.tok[9];
+                std::vector<Span> sub;
+                {
+                    size_t i = 0;
+                    for (;;) {
+                        size_t j = i;
+                        while (j < s.n && s.p[j] != ':') ++j;
+                        sub.push_back(Span{s.p + i, j - i});
+                        if (j >= s.n) break;
+                        i = j + 1;
+                    }
+                }
+                g->cand_gt_ok.push_back((sub[0].n == 3 && memcmp(sub[0].p, "./.", 3) == 0) ? 0 : 1);
+                auto opt_int = [&](Span x, long long &o) {
+                    if (x.n == 1 && x.p[0] == '.') { o = 0; return true; }
+                    return py_int(x.p, x.n, o);
+                };
+                long long ref = 0, other = 0;
+                if (fmt_kind == 2) {
+                    const Span l = sub.back();
+                    const char *c = (const char *)memchr(l.p, ',', l.n);
+                    // upstream: k = find(','); with k == -1 it slices [: -1] / [0:] -- leave that to the Python path
+                    if (!c) return unsupported(g, "AD without a comma");
+                    if (!opt_int(Span{l.p, (size_t)(c - l.p)}, ref) || !opt_int(Span{c + 1, l.n - (size_t)(c - l.p) - 1}, other))
+                        return unsupported(g, "AD");
+                } else {
+                    if (sub.size() < 3 || !opt_int(sub[1], ref) || !opt_int(sub[2], other)) return unsupported(g, "sample counts");
+                }
+                if (ref < 0 || ref > 0xFFFFFFFFLL) return unsupported(g, "reference-read count range");
+                g->cand_refread.push_back((uint32_t)ref);
+                g->c_chrom.push_back(r.tok[0]);
+                g->c_ref.push_back(r.tok[3]);
+                g->c_alt.push_back(r.tok[4]);
+            }
+        }
+        g->cand_ctg_off[k + 1] = (uint32_t)g->cand_pos.size();
+    }
+    g->parsed = true;
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_get_arrays(const duet_ingest *g, duet_ingest_arrays *o)
+{
+    if (!g || !o || !g->parsed) return DUET_INGEST_INVALID;
+    o->n_contigs = (uint32_t)g->contigs.size();
+    o->n_cands = (uint32_t)g->cand_pos.size();
+    o->n_marks = (uint32_t)g->mark_read.size();
+    o->n_reads = (uint32_t)g->read_tag.size();
+    o->cand_ctg_off = g->cand_ctg_off.data();
+    o->read_off = g->read_off.data();
+    o->read_tag = g->read_tag.data();
+    o->cand_pos = g->cand_pos.data();
+    o->cand_svlen = g->cand_svlen.data();
+    o->cand_svread = g->cand_svread.data();
+    o->cand_refread = g->cand_refread.data();
+    o->cand_gt_ok = g->cand_gt_ok.data();
+    o->cand_off = g->cand_off.data();
+    o->mark_read = g->mark_read.data();
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, int include_all_ctgs, char **text,
+                     uint64_t *len)
+{
+    if (!g || !g->parsed || !text || !len) return DUET_INGEST_INVALID;
+    const size_t C = g->cand_pos.size();
+    if (C && (!pred || !ps)) return DUET_INGEST_INVALID;
+    std::string out;
+    out.reserve(4096 + C * 48);
+    out +=
+        "##fileformat=VCFv4.2\n"
+        "##source=Duet\n"
+        "##ALT=<ID=INS,Description=\"Insertion of novel sequence relative to the reference\">\n"
+        "##ALT=<ID=DEL,Description=\"Deletion relative to the reference\">\n"
+        "##FILTER=<ID=PASS,Description=\"SV calls passed phasing criterion\">\n"
+        "##INFO=<ID=SVLEN,Number=1,Type=Integer,Description=\"Estimated length of the variant\">\n"
+        "##FORMAT=<ID=HP,Number=1,Type=String,Description=\"Haplotype of the SV call\">\n"
+        "##FORMAT=<ID=PS,Number=1,Type=String,Description=\"Phase set which the SV call belongs to\">\n";
+    if (include_all_ctgs) {
+        for (const Span &l : g->contig_lines) { out.append(l.p, l.n); out += '\n'; }
+    } else {
+        const size_t lim = std::min<size_t>(24, g->contigs.size());
+        if (g->contigs.size() < 24) return unsupported(g, "default mode walks 24 contigs");   // upstream: IndexError
+        for (size_t k = 0; k < lim; ++k) {
+            const std::string a = "##contig=<ID=chr" + g->contigs[k] + ",", b = "##contig=<ID=" + g->contigs[k] + ",";
+            for (const Span &l : g->contig_lines)
+                if (find_sub(l.p, l.n, a.data(), a.size()) || find_sub(l.p, l.n, b.data(), b.size())) {
+                    out.append(l.p, l.n);
+                    out += '\n';
+                }
+        }
+    }
+    out += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tVALUE\n";
+
+    // emission order (:206-228): contig, PS-class 0/1/2, file order; candidates are already contig-major
+    std::vector<uint32_t> idx;
+    std::vector<uint8_t> cls;
+    for (size_t c = 0; c < C; ++c) {
+        if (!pred[c]) continue;
+        int n_ps = 0;
+        uint32_t first = 0;
+        for (uint32_t m = g->cand_off[c]; m < g->cand_off[c + 1]; ++m) {
+            const uint32_t r = g->mark_read[m];
+            if (r == kAbsent) continue;
+            const uint32_t p = (uint32_t)g->read_tag[r];
+            if (n_ps == 0) { n_ps = 1; first = p; }
+            else if (p != first) { n_ps = 2; break; }
+        }
+        idx.push_back((uint32_t)c);
+        cls.push_back((uint8_t)n_ps);
+    }
+    std::vector<uint32_t> ord(idx.size());
+    for (uint32_t i = 0; i < ord.size(); ++i) ord[i] = i;
+    const int K = (int)g->contigs.size();
+    std::vector<uint32_t> ctg_of(idx.size());
+    {
+        int k = 0;
+        for (size_t i = 0; i < idx.size(); ++i) {
+            while (k < K && idx[i] >= g->cand_ctg_off[k + 1]) ++k;
+            ctg_of[i] = (uint32_t)k;
+        }
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+        if (ctg_of[a] != ctg_of[b]) return ctg_of[a] < ctg_of[b];
+        return cls[a] < cls[b];
+    });
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {      // (:229) chrom as text, pos as int
+        const Span &x = g->c_chrom[idx[a]], &y = g->c_chrom[idx[b]];
+        const int c = memcmp(x.p, y.p, std::min(x.n, y.n));
+        if (c) return c < 0;
+        if (x.n != y.n) return x.n < y.n;
+        return g->cand_pos[idx[a]] < g->cand_pos[idx[b]];
+    });
+    static const char *const kHp[4] = {"", "1|0", "0|1", "1|1"};
+    char num[64];
+    uint64_t row = 0;
+    for (uint32_t oi : ord) {
+        const uint32_t c = idx[oi];
+        ++row;
+        out.append(g->c_chrom[c].p, g->c_chrom[c].n);
+        int w = snprintf(num, sizeof(num), "\t%u\tDuet.%llu\t", g->cand_pos[c], (unsigned long long)row);
+        out.append(num, w);
+        out.append(g->c_ref[c].p, g->c_ref[c].n);
+        out += '\t';
+        out.append(g->c_alt[c].p, g->c_alt[c].n);
+        const uint32_t mag = g->cand_svlen[c];
+        if (g->cand_plus[c] || mag == 0) w = snprintf(num, sizeof(num), "\t.\tPASS\tSVLEN=%u;SVTYPE=<", mag);
+        else w = snprintf(num, sizeof(num), "\t.\tPASS\tSVLEN=-%u;SVTYPE=<", mag);
+        out.append(num, w);
+        out.append(g->c_type[c].p, g->c_type[c].n);
+        w = snprintf(num, sizeof(num), ">\tHP:PS\t%s:%u\n", kHp[pred[c] & 3], ps[c]);
+        out.append(num, w);
+    }
+    char *buf = (char *)malloc(out.size() + 1);
+    if (!buf) return DUET_INGEST_INVALID;
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    *text = buf;
+    *len = out.size();
+    return DUET_INGEST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+# coding=utf-8
+"""ctypes binding of include/duet_ingest.h (libduet_ingest.so): native VCF/BAM ingest into the SoA problem and
+native row emission.  `NativeIngest.load()` returns None when the input is something the native code does not
+vouch for (it says so instead of guessing); callers then use the Python host path, which mirrors upstream's
+exceptions."""
+
+import ctypes
+import os
+
+import numpy as np
+
+from duet_amd import engine
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libduet_ingest.so')
+
+OK, UNSUPPORTED = 0, 1
+
+EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam',
+           'duet_ingest_parse_vcf', 'duet_ingest_get_arrays', 'duet_ingest_emit', 'duet_ingest_free')
+
+
+class IngestArrays(ctypes.Structure):
+    _fields_ = [('n_contigs', ctypes.c_uint32), ('n_cands', ctypes.c_uint32), ('n_marks', ctypes.c_uint32),
+                ('n_reads', ctypes.c_uint32)] + \
+               [(n, ctypes.c_void_p) for n in ('cand_ctg_off', 'read_off', 'read_tag', 'cand_pos', 'cand_svlen',
+                                               'cand_svread', 'cand_refread', 'cand_gt_ok', 'cand_off', 'mark_read')]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            return None
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.duet_ingest_create.restype = ctypes.c_void_p
+        lib.duet_ingest_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+        lib.duet_ingest_destroy.argtypes = [ctypes.c_void_p]
+        lib.duet_ingest_destroy.restype = None
+        lib.duet_ingest_error.restype = ctypes.c_char_p
+        lib.duet_ingest_error.argtypes = [ctypes.c_void_p]
+        lib.duet_ingest_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        lib.duet_ingest_parse_vcf.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        lib.duet_ingest_get_arrays.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestArrays)]
+        lib.duet_ingest_emit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+        lib.duet_ingest_free.argtypes = [ctypes.c_void_p]
+        lib.duet_ingest_free.restype = None
+        _lib = lib
+    return _lib
+
+
+def _view(ptr, n, dtype):
+    if not n or not ptr:
+        return np.zeros(0, dtype=dtype)
+    ct = {np.uint8: ctypes.c_uint8, np.uint32: ctypes.c_uint32, np.uint64: ctypes.c_uint64}[dtype]
+    return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(n,))
+
+
+class NativeIngest(object):
+    """One ingest: tag dicts per contig + caller VCF -> EfSoA (arrays stay owned by the native object)."""
+
+    def __init__(self, handle, lib, soa, why=None):
+        self.handle, self.lib, self.soa, self.why = handle, lib, soa, why
+
+    @classmethod
+    def load(cls, vcf_path, sam_home, chrom_list, thread=4):
+        """-> NativeIngest, or None when the native library is missing / declines the input (reason logged by
+        the caller through .why of the returned tuple)."""
+        lib = load()
+        if lib is None:
+            return None
+        names = (ctypes.c_char_p * len(chrom_list))(*[c.encode('utf-8') for c in chrom_list])
+        h = lib.duet_ingest_create(len(chrom_list), names)
+        if not h:
+            return None
+
+        def decline():
+            why = lib.duet_ingest_error(h).decode('utf-8', 'replace')
+            lib.duet_ingest_destroy(h)
+            return cls(None, lib, None, why)
+
+        for k, c in enumerate(chrom_list):
+            for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
+                if os.path.exists(cand):
+                    if lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) != OK:
+                        return decline()
+                    break
+        if lib.duet_ingest_parse_vcf(h, vcf_path.encode()) != OK:
+            return decline()
+        a = IngestArrays()
+        if lib.duet_ingest_get_arrays(h, ctypes.byref(a)) != OK:
+            return decline()
+        K, C, M, R = a.n_contigs, a.n_cands, a.n_marks, a.n_reads
+        soa = engine.EfSoA(cand_ctg_off=_view(a.cand_ctg_off, K + 1, np.uint32), read_off=_view(a.read_off, K + 1, np.uint32),
+                           read_tag=_view(a.read_tag, R, np.uint64), cand_pos=_view(a.cand_pos, C, np.uint32),
+                           cand_svlen=_view(a.cand_svlen, C, np.uint32), cand_svread=_view(a.cand_svread, C, np.uint32),
+                           cand_refread=_view(a.cand_refread, C, np.uint32), cand_gt_ok=_view(a.cand_gt_ok, C, np.uint8),
+                           cand_off=_view(a.cand_off, C + 1, np.uint32), mark_read=_view(a.mark_read, M, np.uint32))
+        return cls(h, lib, soa)
+
+    def emit(self, pred, ps, include_all_ctgs):
+        """Full text of phased_sv.vcf (header + rows) as bytes."""
+        pred = np.ascontiguousarray(pred, dtype=np.uint8)
+        ps = np.ascontiguousarray(ps, dtype=np.uint32)
+        text = ctypes.c_void_p()
+        n = ctypes.c_uint64()
+        rc = self.lib.duet_ingest_emit(self.handle, pred.ctypes.data, ps.ctypes.data, 1 if include_all_ctgs else 0,
+                                       ctypes.byref(text), ctypes.byref(n))
+        if rc != OK:
+            raise RuntimeError('duet_ingest_emit: ' + self.lib.duet_ingest_error(self.handle).decode('utf-8', 'replace'))
+        try:
+            return ctypes.string_at(text.value, n.value)
+        finally:
+            self.lib.duet_ingest_free(text)
+
+    def close(self):
+        if self.handle:
+            self.soa = None
+            self.lib.duet_ingest_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

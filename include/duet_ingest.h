@@ -1,0 +1,65 @@
+/*
+ * duet_ingest.h -- C ABI of the native host-side ingest/emit of Duet's step E/F (libduet_ingest.so, plain C++,
+ * no GPU dependency): caller VCF + per-contig haplotagged BAMs -> the structure-of-arrays problem of
+ * duet_ef.h, and (pred, ps) -> the rows of phased_sv.vcf.
+ *
+ * It restates, for well-formed ASCII input, what the reference does in Python:
+ *     read_hap_bam        src/duet/sv_phasing_fn.py:11-34   (tag dict per contig, later lines win)
+ *     parse_vcf           src/duet/read_file.py:25-77       (three caller dialects, first-record layout)
+ *     generate_callinfo   src/duet/sv_phasing_fn.py:36-68   (join of mark names, callset order)
+ *     emission + sort     src/duet/sv_phasing_fn.py:213-229
+ *     print_sv_header/print_sv  src/duet/write_file.py:6-45
+ * Anything it is not sure to reproduce exactly (non-ASCII bytes, blank lines, malformed numbers, missing
+ * fields, out-of-range values ...) makes the call return DUET_INGEST_UNSUPPORTED; the Python host path
+ * (duet_amd/read_file.py, sv_phasing_fn.py) then handles the input and raises what upstream would raise.
+ */
+#ifndef DUET_INGEST_H
+#define DUET_INGEST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUET_INGEST_OK 0
+#define DUET_INGEST_UNSUPPORTED 1      /* fall back to the Python path */
+#define DUET_INGEST_IO (-1)            /* file could not be read */
+#define DUET_INGEST_INVALID (-2)       /* bad argument / call order */
+
+typedef struct duet_ingest duet_ingest;
+
+typedef struct duet_ingest_arrays {     /* views into memory owned by the duet_ingest object */
+    uint32_t n_contigs, n_cands, n_marks, n_reads;
+    const uint32_t *cand_ctg_off;       /* [K+1] */
+    const uint32_t *read_off;           /* [K+1] */
+    const uint64_t *read_tag;           /* [R]   */
+    const uint32_t *cand_pos, *cand_svlen, *cand_svread, *cand_refread;   /* [C] */
+    const uint8_t *cand_gt_ok;          /* [C]   */
+    const uint32_t *cand_off;           /* [C+1] */
+    const uint32_t *mark_read;          /* [M]   */
+} duet_ingest_arrays;
+
+/* contig_names: the chrom list (read_file.py:6-16), n_contigs entries. */
+duet_ingest *duet_ingest_create(int n_contigs, const char *const *contig_names);
+void duet_ingest_destroy(duet_ingest *ing);
+const char *duet_ingest_error(const duet_ingest *ing);
+
+/* Tag dict of contig k from a BAM file (built-in BGZF/BAM reader, `threads` inflate workers). */
+int duet_ingest_add_bam(duet_ingest *ing, int contig, const char *bam_path, int threads);
+
+/* Parse the caller VCF and join its mark names against the tag dicts added so far. */
+int duet_ingest_parse_vcf(duet_ingest *ing, const char *vcf_path);
+int duet_ingest_get_arrays(const duet_ingest *ing, duet_ingest_arrays *out);
+
+/* Text of phased_sv.vcf: header (write_file.py:19-45; include_all_ctgs selects which ##contig lines are
+ * copied) followed by the rows of every candidate with pred != 0.  Returns a malloc'ed buffer in *text
+ * (free with duet_ingest_free) and its length in *len. */
+int duet_ingest_emit(duet_ingest *ing, const uint8_t *pred, const uint32_t *ps, int include_all_ctgs,
+                     char **text, uint64_t *len);
+void duet_ingest_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -34,10 +34,24 @@ def check_against_c_oracle(ctx, soa, svlen_thres=50, suppread_thres=2):
     return pred, ps
 
 
-def run_product(home, svlen_thres, suppread_thres):
-    sv_phasing(home, svlen_thres, suppread_thres, 4, False)
-    with open(os.path.join(home, 'phased_sv.vcf')) as f:
-        return f.read()
+def run_product(home, svlen_thres, suppread_thres, python_path=None):
+    """sv_phasing through the native host path (default) or the Python host path; both end in the HIP kernels.
+    With python_path=None both are run and must agree."""
+    outs = []
+    for force_py in ((False, True) if python_path is None else (python_path,)):
+        old = os.environ.get('DUET_NATIVE_INGEST')
+        os.environ['DUET_NATIVE_INGEST'] = '0' if force_py else '1'
+        try:
+            sv_phasing(home, svlen_thres, suppread_thres, 4, False)
+        finally:
+            if old is None:
+                del os.environ['DUET_NATIVE_INGEST']
+            else:
+                os.environ['DUET_NATIVE_INGEST'] = old
+        with open(os.path.join(home, 'phased_sv.vcf')) as f:
+            outs.append(f.read())
+    assert all(o == outs[0] for o in outs)
+    return outs[0]
 
 
 @pytest.mark.parametrize('name,src,params', H.full_cases(), ids=[c[0] for c in H.full_cases()])
@@ -57,7 +71,7 @@ def test_seeded_cases_sha(tmp_path):
             continue
         home = str(tmp_path / ('%s_%d_%s' % (p['kind'], p['seed'], p['dialect'])))
         H.build_case(home, p['kind'], p['seed'], p['dialect'], write_sam=False)
-        got = run_product(home, p['svlen_thres'], p['suppread_thres'])
+        got = run_product(home, p['svlen_thres'], p['suppread_thres'], python_path=bool(p['seed'] % 2))
         assert H.sha256_bytes(got.encode()) == p['output_sha256'], p
         shutil.rmtree(home)
 

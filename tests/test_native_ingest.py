@@ -1,0 +1,97 @@
+# coding=utf-8
+"""libduet_ingest.so (native VCF/BAM ingest + row emission) against the Python host path and the goldens.
+The C oracle stands in for the GPU here (tests only)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from duet_amd import engine, native
+from duet_amd import sv_phasing_fn as F
+from duet_amd.read_file import init_chrom_list
+from oracle import c_oracle
+from tests import helpers as H
+from tests.test_c_oracle import materialise_bams
+
+CHROMS = init_chrom_list(False, '')
+
+
+def native_text(home, svlen_thres, suppread_thres):
+    ing = native.NativeIngest.load(home + '/sv_calling/variants.vcf', home + '/snp_phasing/', CHROMS, 4)
+    assert ing is not None and ing.handle, getattr(ing, 'why', 'library missing')
+    rc, pred, ps = c_oracle.ef(ing.soa, svlen_thres, suppread_thres)
+    assert rc == 0
+    text = ing.emit(pred, ps, False).decode('ascii')
+    return text, ing
+
+
+def test_library_exports():
+    import ctypes
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in native.EXPORTS:
+        assert hasattr(lib, name)
+
+
+@pytest.mark.parametrize('name,src,params', H.full_cases(), ids=[c[0] for c in H.full_cases()])
+def test_full_cases_bytes_and_arrays(name, src, params, tmp_path):
+    home = str(tmp_path / name)
+    shutil.copytree(src, home)
+    materialise_bams(home)
+    with open(os.path.join(src, 'phased_sv.vcf')) as f:
+        want = f.read()
+    got, ing = native_text(home, params['svlen_thres'], params['suppread_thres'])
+    assert got == want
+    # field-for-field identical to the Python ingest (same read numbering: order of first appearance)
+    tab, soa = F.generate_callinfo(home + '/sv_calling/variants.vcf', F.read_hap_bam(home + '/snp_phasing/', 4, False), False)
+    for field, _ in engine.EfSoA.FIELDS:
+        assert np.array_equal(getattr(ing.soa, field), getattr(soa, field)), field
+    ing.close()
+
+
+def test_seeded_cases(tmp_path):
+    n = 0
+    for p in H.seeded_plan():
+        if p['kind'] == 'config2' or (p['kind'] == 'fuzz' and p['seed'] % 3):
+            continue
+        home = str(tmp_path / ('%s_%d_%s' % (p['kind'], p['seed'], p['dialect'])))
+        H.build_case(home, p['kind'], p['seed'], p['dialect'], write_sam=False)
+        got, ing = native_text(home, p['svlen_thres'], p['suppread_thres'])
+        ing.close()
+        assert H.sha256_bytes(got.encode()) == p['output_sha256'], p
+        shutil.rmtree(home)
+        n += 1
+    assert n >= 60
+
+
+def _tiny_case(tmp_path, vcf_lines, sam_lines):
+    from duet_amd import bamio
+    home = str(tmp_path / 'w')
+    os.makedirs(home + '/sv_calling')
+    os.makedirs(home + '/snp_phasing')
+    with open(home + '/sv_calling/variants.vcf', 'w') as f:
+        f.write('\n'.join(vcf_lines) + '\n')
+    bamio.write_bam_from_sam_lines(home + '/snp_phasing/chr1.bam', [('chr1', 1000000)], sam_lines)
+    return home
+
+
+REC = 'chr1\t100\tid\tN\t<DEL>\t.\tPASS\tPRECISE;SVTYPE=DEL;SVLEN=-80;END=180;RE=5;RNAMES=a,b;STRAND=+-\tGT:DR:DV:PL:GQ\t0/1:3:5:1,2,3:9'
+SAM = ['a\t0\tchr1\t90\t60\t*\t*\t0\t0\t*\t*\tNM:i:1\tHP:i:1\tPC:i:100\tPS:i:50']
+
+
+def test_declines_what_it_cannot_vouch_for(tmp_path):
+    """Blank lines, non-ASCII bytes, malformed numbers -> the native path says UNSUPPORTED (Python takes over)."""
+    for i, bad in enumerate(([REC, '', REC], [REC.replace('id', 'ié')], [REC.replace('RE=5', 'RE=five')],
+                             [REC.replace('\t100\t', '\t1e2\t')], [REC.replace('GT:DR:DV:PL:GQ\t0/1:3:5:1,2,3:9', 'GT\t0/1')])):
+        home = _tiny_case(tmp_path / str(i), bad, SAM)
+        ing = native.NativeIngest.load(home + '/sv_calling/variants.vcf', home + '/snp_phasing/', CHROMS, 1)
+        assert ing is not None and ing.handle is None and ing.why, bad
+
+
+def test_python_int_forms_accepted(tmp_path):
+    home = _tiny_case(tmp_path, [REC.replace('\t100\t', '\t+1_00\t').replace('RE=5', 'RE=0_5')], SAM)
+    ing = native.NativeIngest.load(home + '/sv_calling/variants.vcf', home + '/snp_phasing/', CHROMS, 1)
+    assert ing.handle and int(ing.soa.cand_pos[0]) == 100 and int(ing.soa.cand_svread[0]) == 5
+    tab, soa = F.generate_callinfo(home + '/sv_calling/variants.vcf', F.read_hap_bam(home + '/snp_phasing/', 1, False), False)
+    assert int(soa.cand_pos[0]) == 100 and int(soa.cand_svread[0]) == 5
+    ing.close()
