@@ -152,12 +152,20 @@ def main():
     from duet_amd import _lib, dist, engine, synth
     from duet_amd.devmem import DeviceProblem
 
+    # DUET_BENCH_ONE_GPU=1 (plumbing test on a 1-GPU box only): every rank uses device 0 and the collective
+    # goes through gloo instead of RCCL; never set for a measurement.
+    one_gpu = os.environ.get('DUET_BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist_mod = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist_mod.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if one_gpu:
+            dist_mod.init_process_group('gloo')
+        else:
+            dist_mod.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     ctx = _lib.Context(local_rank)
 
@@ -205,6 +213,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32/u64 integer + f64 threshold compares',
             'data': 'synthetic',
+            'plumbing_test_one_gpu': one_gpu,
             'config': {'workload': 'BASELINE configs[1]: synthetic 1 contig per GPU, %d SV marks / %d candidates / '
                                    '%d tagged reads per contig, resident in HBM; step = classify+seed_sort+finalize%s'
                                    % (soa.n_marks, soa.n_cands, soa.n_reads,

@@ -22,7 +22,7 @@ KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
 
 # every symbol include/duet_ef.h declares (checked by tests/test_abi.py)
 EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
-           'duet_ctx_set_profiling', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
+           'duet_ctx_set_profiling', 'duet_ctx_set_debug', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
            'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host')
 
 
@@ -88,6 +88,7 @@ def load():
     lib.duet_last_error.restype = ctypes.c_char_p
     lib.duet_last_error.argtypes = [ctypes.c_void_p]
     lib.duet_ctx_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.duet_ctx_set_debug.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
     lib.duet_ef_run_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfProblem), ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]
     lib.duet_ef_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -137,6 +138,11 @@ class Context(object):
     def set_profiling(self, mode):
         """0 off, 1 (or True) events around ef_classify only, 2 around every kernel."""
         rc = self.lib.duet_ctx_set_profiling(self.handle, int(mode))
+        if rc:
+            self._raise(rc)
+
+    def set_debug(self, flags):
+        rc = self.lib.duet_ctx_set_debug(self.handle, int(flags))
         if rc:
             self._raise(rc)
 

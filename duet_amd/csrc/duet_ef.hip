@@ -146,21 +146,217 @@ struct Params {
 // kernel 1: join + filter + PS-class + seeds + one-PS vote/decision + multi-PS group summaries
 // ---------------------------------------------------------------------------------------------
 
+// Per-candidate running state over its marks in list order.
+struct CandState {
+    uint32_t n_ps = 0, first_ps = 0;          // distinct PS among tagged marks: 0, 1, 2(=many)   (:191-194)
+    uint32_t seed = kEmpty;                   // PS of first voter (:199-203)
+    uint32_t last_ps = 0;                     // PS of last voter (:77)
+    // voters grouped by PS, first two groups in first-seen order (A, B); a third group sets `more`.
+    // With one PS (class 1) group A is the whole vote (:74-84); with several it feeds :85-105.
+    uint32_t ps_a = 0, ps_b = 0, n_a = 0, n_b = 0, nv = 0;
+    uint32_t a1 = 0, a2 = 0, b1 = 0, b2 = 0;  // hap-1 / hap-2 counts per group
+    uint32_t ta1 = 0, ta2 = 0, tb1 = 0, tb2 = 0;   // PC sums; A's are per-chunk partials folded into TA1/TA2
+    uint64_t TA1 = 0, TA2 = 0;
+    bool more = false;
+};
+
+// thread walks marks [lo, hi) of its candidate; tags of mark m sit at s_tag[m - cs]   (branch-light)
+__device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs)
+{
+    for (uint32_t m = lo; m < hi; ++m) {
+        const uint64_t tag = s_tag[m - cs];
+        const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
+        const bool tagged = w != 0xFFFFFFFFu;           // an absent mark is all ones
+        const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
+        const bool voter = pc <= kPcMax;                // absent marks have pc = 2^30-1: never voters
+        const bool fresh = tagged && st.n_ps == 0;
+        st.first_ps = fresh ? ps : st.first_ps;
+        st.n_ps = tagged ? (ps != st.first_ps ? 2u : max(st.n_ps, 1u)) : st.n_ps;
+        st.seed = (voter && st.seed == kEmpty) ? ps : st.seed;
+        st.last_ps = voter ? ps : st.last_ps;
+        st.nv += voter;
+        st.ps_a = (voter && st.n_a == 0) ? ps : st.ps_a;
+        const bool in_a = voter && ps == st.ps_a;
+        st.ps_b = (voter && !in_a && st.n_b == 0) ? ps : st.ps_b;
+        const bool in_b = voter && !in_a && ps == st.ps_b;
+        st.more = st.more || (voter && !in_a && !in_b);
+        const bool is1 = hap == 1, is2 = hap == 2;
+        st.n_a += in_a; st.n_b += in_b;
+        st.a1 += in_a && is1; st.a2 += in_a && is2;
+        st.b1 += in_b && is1; st.b2 += in_b && is2;
+        st.ta1 += (in_a && is1) ? pc : 0u; st.ta2 += (in_a && is2) ? pc : 0u;
+        st.tb1 += (in_b && is1) ? pc : 0u; st.tb2 += (in_b && is2) ? pc : 0u;
+    }
+    st.TA1 += st.ta1; st.TA2 += st.ta2; st.ta1 = 0; st.ta2 = 0;
+}
+
+struct TileShared {
+    uint32_t seed[kCandPerBlock];
+    uint32_t wcnt[kCandPerBlock / 64], wlast[kCandPerBlock / 64], wclean[kCandPerBlock / 64];
+    uint32_t c2n;                             // summary slots handed out in this tile (reset by the caller)
+};
+
+// decision + outputs + seed entries of one 256-candidate tile.  All 256 threads call it (it synchronises).
+__device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uint32_t tile, uint32_t tid, bool live, uint32_t c,
+                                            bool active, bool divzero, const CandState &st, uint32_t deg,
+                                            uint32_t svread, uint32_t refread, uint32_t is_start)
+{
+    uint8_t code = 0;
+    uint32_t ps_out = 0;
+    bool want_seed = false;
+    // multi-PS candidates get a summary slot (first two voter groups) unless a third group exists or
+    // the PC sums could leave 32 bits; those few are re-gathered by ef_finalize
+    const bool c2 = active && st.n_ps == 2;
+    const bool c2_fast = c2 && !st.more && deg < 500000u;
+    const uint32_t rank = c2_fast ? atomicAdd(&sh.c2n, 1u) : kC2Quota;
+    if (live) {
+        if (divzero) {
+            code = kDivZero;
+        } else if (active) {
+            want_seed = (st.n_ps == 1) && st.seed != kEmpty;                                       // :198-203
+            if (c2) {
+                if (rank < kC2Quota) {
+                    const uint32_t slot = tile * kC2Quota + rank;
+                    uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
+                    const uint32_t ng = (st.n_a != 0) + (st.n_b != 0);
+                    rec[0] = st.nv; rec[1] = ng;
+                    rec[2] = st.ps_a; rec[3] = st.n_a; rec[4] = st.a1; rec[5] = st.a2;
+                    rec[6] = (uint32_t)st.TA1; rec[7] = (uint32_t)st.TA2;
+                    rec[8] = st.ps_b; rec[9] = st.n_b; rec[10] = st.b1; rec[11] = st.b2; rec[12] = st.tb1; rec[13] = st.tb2;
+                    code = kClass2;
+                    ps_out = slot;
+                } else {
+                    code = kClass2Slow;
+                }
+            } else {
+                Vote v;
+                v.hap1 = st.a1; v.hap2 = st.a2; v.hap0 = 0;
+                v.allhap = st.a1 + st.a2;
+                v.t1 = st.TA1; v.t2 = st.TA2;
+                code = (p.dbg & 2) ? 0 : (uint8_t)decide((int)st.n_ps, v, deg, svread, refread);
+                ps_out = st.last_ps;
+                if (st.n_ps == 0 || (st.a1 == 0 && st.a2 == 0)) code |= kNeedNearest;              // :106
+            }
+        }
+        p.out_pred[c] = code;
+        p.out_ps[c] = ps_out;
+    }
+
+    // ---- seeds of this tile, compacted.  A seed equal to the seed of the previous seed-bearing
+    // candidate is dropped, unless a contig starts in between (seed sets are per contig).  Only the
+    // set matters downstream, so dropping duplicates early just shortens ef_seed_sort's input.
+    if (p.dbg & 1) want_seed = false;
+    const uint32_t seed = st.seed;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long wmask = __ballot(want_seed);
+    const unsigned long long smask = __ballot(is_start != 0);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);    // lanes 0..lane
+    sh.seed[tid] = want_seed ? seed : kEmpty;
+    __syncthreads();
+    if (lane == 0) {
+        if (wmask) {
+            const uint32_t li = 63u - (uint32_t)__clzll(wmask);
+            sh.wlast[wave] = sh.seed[wave * 64 + li];
+            sh.wclean[wave] = (li == 63 || (smask >> (li + 1)) == 0) ? 1u : 0u;   // no contig start after it
+        } else {
+            sh.wlast[wave] = kEmpty;
+            sh.wclean[wave] = 0;
+        }
+    }
+    __syncthreads();
+    bool keep = want_seed;
+    if (want_seed) {
+        const unsigned long long lower = wmask & (upto >> 1);                   // seed lanes below this one
+        if (lower) {
+            const uint32_t pl = 63u - (uint32_t)__clzll(lower);
+            const unsigned long long between = smask & upto & ~((1ull << (pl + 1)) - 1ull);   // starts in (pl, lane]
+            keep = !(between == 0 && sh.seed[wave * 64 + pl] == seed);
+        } else if (wave > 0) {
+            keep = !((smask & upto) == 0 && sh.wclean[wave - 1] && sh.wlast[wave - 1] == seed);
+        }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) sh.wcnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kCandPerBlock / 64; ++w) {
+        before += w < wave ? sh.wcnt[w] : 0u;
+        total += sh.wcnt[w];
+    }
+    if (keep) {
+        const uint32_t at = before + (uint32_t)__popcll(mask & (upto >> 1));
+        p.seed_ent[(size_t)tile * kCandPerBlock + at] = ((uint64_t)c << 32) | seed;
+    }
+    if (tid == 0) p.blk_cnt[tile] = total;
+}
+
+// ---- staging pieces: 16 marks per thread and pass, 4 x (16-byte index load -> 4 tag gathers) ----------
+// Index loads are branch-free and their values are not touched here: a conditional load, or any use of the
+// loaded registers, makes the compiler wait on the spot, which would serialise the four loads and break the
+// software pipeline.  The mark array is 16-byte aligned on this path, so an aligned 16-byte load that starts
+// inside it stays inside its last 16-byte granule even when M is not a multiple of 4; lanes past m_end read
+// a harmless in-range address.  stage_gather masks both cases when it finally consumes the indices.
+__device__ __forceinline__ void stage_load_marks(const Params &p, uint4 (&r)[4], uint32_t cs, uint32_t m_end, uint32_t tid)
+{
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t m = cs + 4u * (tid + it * kCandPerBlock);
+        r[it] = *reinterpret_cast<const uint4 *>(p.mark_read + (m < m_end ? m : cs));
+    }
+}
+
+// Tag gathers, branch-free for the same reason: absent / out-of-range marks read entry 0 (the host makes sure
+// read_tag always points at >= 1 readable word) and `valid` remembers which of the 16 are real; stage_store
+// substitutes the "untagged" word when the values are finally consumed.
+__device__ __forceinline__ void stage_gather(const Params &p, uint64_t (&t)[16], uint32_t &valid, const uint4 (&r)[4],
+                                             uint32_t cs, uint32_t m_end, uint32_t tid)
+{
+    valid = 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t m = cs + 4u * (tid + it * kCandPerBlock);
+        const bool in = m < m_end;
+        const uint32_t idx[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = in && m + j < p.M && idx[j] != kEmpty;
+            valid |= ok ? (1u << (4 * it + j)) : 0u;
+            t[4 * it + j] = p.read_tag[ok ? idx[j] : 0u];
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_store(uint64_t *s_tag, const uint64_t (&t)[16], uint32_t valid, uint32_t cs,
+                                            uint32_t m_end, uint32_t tid)
+{
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t i = 4u * (tid + it * kCandPerBlock);
+        if (cs + i < m_end) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_tag[i + j] = ((valid >> (4 * it + j)) & 1u) ? t[4 * it + j] : kUntagged;
+        }
+    }
+}
+
+// One tile (256 candidates) per workgroup.  (A persistent variant that software-pipelined the two staging
+// round trips of tile i+1 / i+2 under the LDS walk of tile i was measured at 2e7 marks and was NOT faster --
+// 80 us vs 72 us: with four workgroups per CU in different phases the staging latency is already hidden and
+// the kernel is bound by the sum of VALU issue (consume + fp64 decision) and memory time; see DESIGN.md.)
 template <bool VEC>
 __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
 {
     __shared__ uint64_t s_tag[kChunk];
     __shared__ uint32_t s_off[kCandPerBlock + 1];
-    __shared__ uint32_t s_seed[kCandPerBlock];
-    __shared__ uint32_t s_wcnt[kCandPerBlock / 64], s_wlast[kCandPerBlock / 64], s_wclean[kCandPerBlock / 64];
-    __shared__ uint32_t s_c2n;
+    __shared__ TileShared sh;
 
     const uint32_t tid = threadIdx.x;
     STAMP(0, 0);
     const uint32_t c0 = blockIdx.x * kCandPerBlock;
     const uint32_t nc = min((uint32_t)kCandPerBlock, p.C - c0);
     for (uint32_t i = tid; i <= nc; i += kCandPerBlock) s_off[i] = p.cand_off[c0 + i];
-    if (tid == 0) s_c2n = 0;
+    if (tid == 0) sh.c2n = 0;
 
     // candidate scalars, coalesced
     const bool live = tid < nc;
@@ -180,20 +376,7 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
     STAMP(0, 1);
     const uint32_t m_begin = s_off[0], m_end = s_off[nc];
     const uint32_t my_b = live ? s_off[tid] : 0, my_e = live ? s_off[tid + 1] : 0;
-
-    // per-candidate running state over marks in list order
-    uint32_t n_ps = 0, first_ps = 0;          // distinct PS among tagged marks: 0, 1, 2(=many)
-    uint32_t seed = kEmpty;                   // PS of first voter (:199-203)
-    uint32_t last_ps = 0;                     // PS of last voter (:77)
-    // voters grouped by PS, first two groups in first-seen order (A, B); a third group sets `more`.
-    // With one PS (class 1) group A is the whole vote (:74-84); with several it feeds :85-105.
-    uint32_t ps_a = 0, ps_b = 0, n_a = 0, n_b = 0, nv = 0;
-    uint32_t a1 = 0, a2 = 0, b1 = 0, b2 = 0;          // hap-1 / hap-2 counts per group
-    uint32_t ta1 = 0, ta2 = 0, tb1 = 0, tb2 = 0;      // PC sums; A's are per-chunk partials folded into TA1/TA2
-    uint64_t TA1 = 0, TA2 = 0;
-    bool more = false;
-    uint8_t code = 0;
-    uint32_t ps_out = 0;
+    CandState st;
 
     const uint32_t base = VEC ? (m_begin & ~3u) : m_begin;
     for (uint32_t cs = base; cs < m_end; cs += kChunk) {
@@ -201,37 +384,10 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         if (VEC) {
             uint4 r[4];
             uint64_t t[16];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const uint32_t m = cs + 4u * (tid + it * kCandPerBlock);
-                r[it] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
-                if (m < m_end) {
-                    if (m + 3 < p.M) {
-                        r[it] = *reinterpret_cast<const uint4 *>(p.mark_read + m);
-                    } else {
-                        r[it].x = p.mark_read[m];
-                        if (m + 1 < p.M) r[it].y = p.mark_read[m + 1];
-                        if (m + 2 < p.M) r[it].z = p.mark_read[m + 2];
-                    }
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                t[4 * it + 0] = r[it].x == kEmpty ? kUntagged : p.read_tag[r[it].x];
-                t[4 * it + 1] = r[it].y == kEmpty ? kUntagged : p.read_tag[r[it].y];
-                t[4 * it + 2] = r[it].z == kEmpty ? kUntagged : p.read_tag[r[it].z];
-                t[4 * it + 3] = r[it].w == kEmpty ? kUntagged : p.read_tag[r[it].w];
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const uint32_t i = 4u * (tid + it * kCandPerBlock);
-                if (cs + i < m_end) {
-                    s_tag[i + 0] = t[4 * it + 0];
-                    s_tag[i + 1] = t[4 * it + 1];
-                    s_tag[i + 2] = t[4 * it + 2];
-                    s_tag[i + 3] = t[4 * it + 3];
-                }
-            }
+            uint32_t valid;
+            stage_load_marks(p, r, cs, m_end, tid);
+            stage_gather(p, t, valid, r, cs, m_end, tid);
+            stage_store(s_tag, t, valid, cs, m_end, tid);
         } else {
             for (uint32_t i = tid; i < kChunk && cs + i < m_end; i += kCandPerBlock) {
                 const uint32_t r = p.mark_read[cs + i];
@@ -240,126 +396,16 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         }
         __syncthreads();
         STAMP(0, 2);
-        // ---- consume: each thread walks its candidate's part of this chunk (branch-light) ------
+        // ---- consume: each thread walks its candidate's part of this chunk ----------------------
         uint32_t lo = max(my_b, cs);
         const uint32_t hi = min(my_e, cs + (uint32_t)kChunk);
         if (!active || (p.dbg & 4)) lo = hi;
-        for (uint32_t m = lo; m < hi; ++m) {
-            const uint64_t tag = s_tag[m - cs];
-            const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
-            const bool tagged = w != 0xFFFFFFFFu;           // an absent mark is all ones
-            const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
-            const bool voter = pc <= kPcMax;                // absent marks have pc = 2^30-1: never voters
-            const bool fresh = tagged && n_ps == 0;
-            first_ps = fresh ? ps : first_ps;
-            n_ps = tagged ? (ps != first_ps ? 2u : max(n_ps, 1u)) : n_ps;
-            seed = (voter && seed == kEmpty) ? ps : seed;
-            last_ps = voter ? ps : last_ps;
-            nv += voter;
-            ps_a = (voter && n_a == 0) ? ps : ps_a;
-            const bool in_a = voter && ps == ps_a;
-            ps_b = (voter && !in_a && n_b == 0) ? ps : ps_b;
-            const bool in_b = voter && !in_a && ps == ps_b;
-            more = more || (voter && !in_a && !in_b);
-            const bool is1 = hap == 1, is2 = hap == 2;
-            n_a += in_a; n_b += in_b;
-            a1 += in_a && is1; a2 += in_a && is2;
-            b1 += in_b && is1; b2 += in_b && is2;
-            ta1 += (in_a && is1) ? pc : 0u; ta2 += (in_a && is2) ? pc : 0u;
-            tb1 += (in_b && is1) ? pc : 0u; tb2 += (in_b && is2) ? pc : 0u;
-        }
-        TA1 += ta1; TA2 += ta2; ta1 = 0; ta2 = 0;
+        consume_range(st, s_tag, lo, hi, cs);
         STAMP(0, 3);
         __syncthreads();
     }
-
     STAMP(0, 4);
-    // ---- per-candidate result ------------------------------------------------------------------
-    bool want_seed = false;
-    // multi-PS candidates get a summary slot (first two voter groups) unless a third group exists or
-    // the PC sums could leave 32 bits; those few are re-gathered by ef_finalize
-    const bool c2 = active && n_ps == 2;
-    const bool c2_fast = c2 && !more && (my_e - my_b) < 500000u;
-    const uint32_t rank = c2_fast ? atomicAdd(&s_c2n, 1u) : kC2Quota;
-    if (live) {
-        if (divzero) {
-            code = kDivZero;
-        } else if (active) {
-            want_seed = (n_ps == 1) && seed != kEmpty;                                             // :198-203
-            if (c2) {
-                if (rank < kC2Quota) {
-                    const uint32_t slot = blockIdx.x * kC2Quota + rank;
-                    uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
-                    const uint32_t ng = (n_a != 0) + (n_b != 0);
-                    rec[0] = nv; rec[1] = ng;
-                    rec[2] = ps_a; rec[3] = n_a; rec[4] = a1; rec[5] = a2; rec[6] = (uint32_t)TA1; rec[7] = (uint32_t)TA2;
-                    rec[8] = ps_b; rec[9] = n_b; rec[10] = b1; rec[11] = b2; rec[12] = tb1; rec[13] = tb2;
-                    code = kClass2;
-                    ps_out = slot;
-                } else {
-                    code = kClass2Slow;
-                }
-            } else {
-                Vote v;
-                v.hap1 = a1; v.hap2 = a2; v.hap0 = 0;
-                v.allhap = a1 + a2;
-                v.t1 = TA1; v.t2 = TA2;
-                code = (p.dbg & 2) ? 0 : (uint8_t)decide((int)n_ps, v, my_e - my_b, svread, refread);
-                ps_out = last_ps;
-                if (n_ps == 0 || (a1 == 0 && a2 == 0)) code |= kNeedNearest;                       // :106
-            }
-        }
-        p.out_pred[c] = code;
-        p.out_ps[c] = ps_out;
-    }
-
-    STAMP(0, 5);
-    // ---- seeds of this block, compacted.  A seed equal to the seed of the previous seed-bearing
-    // candidate is dropped, unless a contig starts in between (seed sets are per contig).  Only the
-    // set matters downstream, so dropping duplicates early just shortens ef_seed_sort's input.
-    if (p.dbg & 1) want_seed = false;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const unsigned long long wmask = __ballot(want_seed);
-    const unsigned long long smask = __ballot(is_start != 0);
-    const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);    // lanes 0..lane
-    s_seed[tid] = want_seed ? seed : kEmpty;
-    __syncthreads();
-    if (lane == 0) {
-        if (wmask) {
-            const uint32_t li = 63u - (uint32_t)__clzll(wmask);
-            s_wlast[wave] = s_seed[wave * 64 + li];
-            s_wclean[wave] = (li == 63 || (smask >> (li + 1)) == 0) ? 1u : 0u;   // no contig start after it
-        } else {
-            s_wlast[wave] = kEmpty;
-            s_wclean[wave] = 0;
-        }
-    }
-    __syncthreads();
-    bool keep = want_seed;
-    if (want_seed) {
-        const unsigned long long lower = wmask & (upto >> 1);                   // seed lanes below this one
-        if (lower) {
-            const uint32_t pl = 63u - (uint32_t)__clzll(lower);
-            const unsigned long long between = smask & upto & ~((1ull << (pl + 1)) - 1ull);   // starts in (pl, lane]
-            keep = !(between == 0 && s_seed[wave * 64 + pl] == seed);
-        } else if (wave > 0) {
-            keep = !((smask & upto) == 0 && s_wclean[wave - 1] && s_wlast[wave - 1] == seed);
-        }
-    }
-    const unsigned long long mask = __ballot(keep);
-    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kCandPerBlock / 64; ++w) {
-        before += w < wave ? s_wcnt[w] : 0u;
-        total += s_wcnt[w];
-    }
-    if (keep) {
-        const uint32_t at = before + (uint32_t)__popcll(mask & (upto >> 1));
-        p.seed_ent[(size_t)blockIdx.x * kCandPerBlock + at] = ((uint64_t)c << 32) | seed;
-    }
-    if (tid == 0) p.blk_cnt[blockIdx.x] = total;
+    finish_tile(p, sh, blockIdx.x, tid, live, c, active, divzero, st, my_e - my_b, svread, refread, is_start);
     STAMP(0, 6);
 }
 
@@ -941,7 +987,7 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
 
     Params p;
     p.K = pr->n_contigs; p.C = pr->n_cands; p.M = pr->n_marks;
-    p.read_tag = pr->read_tag;
+    p.read_tag = pr->n_reads ? pr->read_tag : (const uint64_t *)ctx->d_n_one;   // always >= 1 readable word
     p.cand_pos = pr->cand_pos; p.cand_svlen = pr->cand_svlen; p.cand_svread = pr->cand_svread;
     p.cand_refread = pr->cand_refread; p.cand_gt_ok = pr->cand_gt_ok;
     p.cand_off = pr->cand_off; p.mark_read = pr->mark_read;

@@ -129,6 +129,9 @@ int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pr
  * collect into *stats, and reset. */
 int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 
+/* Diagnostics: low bits ablate kernel phases (tools/ablate.py).  0 in production. */
+int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags);
+
 /* Debug/inspection: copy contig k's sorted seed-PS array of the LAST run to `out` (capacity `cap`),
  * return its length (or a negative status). */
 int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t cap);

@@ -97,8 +97,8 @@ def test_config2_soa_vs_oracle(ctx):
 
 
 def test_config3_shape_soa_vs_oracle(ctx):
-    """24 contigs, 2e6 marks (a tenth of config 3; the full size runs in bench.py)."""
-    soa = engine.soa_from_synth(synth.bench_genome(2000000, 3))
+    """24 contigs, 8e6 marks (config 3's shape at 40 % of its size; the full size runs in bench.py)."""
+    soa = engine.soa_from_synth(synth.bench_genome(8000000, 3))
     assert soa.n_contigs == 24
     check_against_c_oracle(ctx, soa)
 
