@@ -13,7 +13,8 @@ DEVICE_FIELDS = ('read_tag', 'cand_pos', 'cand_svlen', 'cand_svread', 'cand_refr
 class DeviceProblem(object):
     """An EfSoA uploaded once to HBM, plus output buffers, ready for repeated duet_ef_run_device."""
 
-    def __init__(self, soa, svlen_thres, suppread_thres, device='cuda:0', misalign_marks=0, n_cands_max=None):
+    def __init__(self, soa, svlen_thres, suppread_thres, device='cuda:0', misalign_marks=0, n_cands_max=None,
+                 n_out=1):
         import torch
         self.torch = torch
         self.soa = soa
@@ -32,21 +33,23 @@ class DeviceProblem(object):
         # hand the whole block to a single all-gather (duet_amd/dist.py)
         from duet_amd.dist import record_bytes
         self.n_max = max(int(n_cands_max or soa.n_cands), soa.n_cands, 1)
-        self.out_block = torch.zeros(record_bytes(self.n_max), dtype=torch.uint8, device=self.device)
-        self.out_ps_ptr = self.out_block.data_ptr()
-        self.out_pred_ptr = self.out_block.data_ptr() + 4 * self.n_max
+        # n_out > 1: rotating result blocks, so that the all-gather of one job can run beside the kernels of the next
+        self.out_blocks = [torch.zeros(record_bytes(self.n_max), dtype=torch.uint8, device=self.device)
+                           for _ in range(max(1, n_out))]
+        self.out_block = self.out_blocks[0]
         self.problem = _lib.problem_from_device(soa, ptrs, svlen_thres, suppread_thres)
 
-    def run(self, ctx, stream=None):
+    def run(self, ctx, stream=None, slot=0):
         if stream is None:
             stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        ctx.run_device(self.problem, self.out_pred_ptr, self.out_ps_ptr, stream)
+        blk = self.out_blocks[slot]
+        ctx.run_device(self.problem, blk.data_ptr() + 4 * self.n_max, blk.data_ptr(), stream)
         return stream
 
-    def results(self):
+    def results(self, slot=0):
         """-> (pred u8[C], ps u32[C]) on the host (synchronises)."""
         from duet_amd.dist import unpack_block
-        return unpack_block(self.out_block.cpu().numpy(), self.n_max, self.soa.n_cands)
+        return unpack_block(self.out_blocks[slot].cpu().numpy(), self.n_max, self.soa.n_cands)
 
 
 class DeviceCluster(object):
