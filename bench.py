@@ -125,7 +125,7 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
         one(i)
     drain()
     ctx.check(stream)
-    ctx.set_profiling(1)                 # two HIP events per step, on ef_classify's own dispatch
+    ctx.set_profiling(3)                 # HIP start/stop events on ef_classify's own dispatch, every 8th step
     ctx.profile_collect()
     if world > 1:
         dist_mod.barrier()
@@ -248,6 +248,7 @@ def main():
             'roofline': {'kernel': kname, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(soa),
                          'algorithmic_bytes_per_launch': abytes, 'launch_ms': k_ms,
+                         'launches_timed': int(prof.n_profiled_runs),
                          'note': 'config 2 is 14.6 MB per launch (~1.8 us at peak): launch-latency bound; '
                                  'see extra.* for the bandwidth-bound sizes'},
         }

@@ -54,6 +54,7 @@ constexpr uint8_t kDivZero = 32;                  // kept candidate with svread 
 
 constexpr int kCandPerBlock = 256;
 constexpr int kChunk = 4096;                      // marks staged in LDS per pass (32 KiB of tags)
+constexpr int kSmallK = 64;
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB)
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
@@ -129,15 +130,18 @@ struct Params {
     const uint8_t *ctg_start;         // [C]   1 where a candidate is the first of its contig
     const uint32_t *blk_ctg;          // [B]   contig of candidate 256*b
     // workspace (per run)
-    uint32_t *blk_cnt;                // [B]   seed entries emitted by classify block b
-    uint64_t *seed_ent;               // [B*256] (candidate << 32 | seed PS), compacted per block
-    uint32_t *onebuf;                 // [C]   per contig (at ctg_off[k]): ascending distinct seed PS
+    uint64_t *blk_rec;                // [B][4] per classify block: {entry count, entry 0, entry 1, entry 2}
+    uint64_t *seed_ent;               // [B*256] entries 3.. of a block: (candidate << 32 | seed PS)
+    uint32_t *onebuf;                 // [C+K] per contig at ctg_off[k]+k: {n, ascending distinct seed PS...}
+    uint32_t one_cap;                 // C + K
     uint32_t *tmpbuf;                 // [C]   scratch of the out-of-LDS seed sort
     uint32_t *n_one;                  // [K]   length of contig k's seed array
     uint32_t *c2rec;                  // [B*kC2Quota*kC2Words] group summaries of multi-PS candidates
     uint32_t *status;                 // [0] = div-zero flag
     uint8_t *out_pred;
     uint32_t *out_ps;
+    uint32_t n_small;                 // K when K <= kSmallK: the contig offsets then also ride in the kernel arguments
+    uint32_t ctg_small[kSmallK + 1];  //   (scalar loads instead of a dependent HBM round trip)
     uint32_t dbg;                     // diagnostic ablation bits (0 in production)
     unsigned long long *stamps;       // diagnostic build only: [kernel][block][8] wall-clock stamps
 };
@@ -163,8 +167,12 @@ struct CandState {
 // thread walks marks [lo, hi) of its candidate; tags of mark m sit at s_tag[m - cs]   (branch-light)
 __device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs)
 {
+    // the LDS read of mark m+1 is issued before mark m is processed, so its latency hides under the ~45 VALU
+    // instructions of the body even when the SIMD has no other wave to switch to (small problems)
+    uint64_t next = lo < hi ? s_tag[lo - cs] : 0ull;
     for (uint32_t m = lo; m < hi; ++m) {
-        const uint64_t tag = s_tag[m - cs];
+        const uint64_t tag = next;
+        next = s_tag[min(m + 1, hi - 1) - cs];
         const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
         const bool tagged = w != 0xFFFFFFFFu;           // an absent mark is all ones
         const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
@@ -285,10 +293,14 @@ __device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uin
         total += sh.wcnt[w];
     }
     if (keep) {
+        // the first three entries sit beside the count (one 32-byte record per tile: ef_seed_sort reads count and
+        // entries in a single round trip); the rest go to the tile's overflow slots
         const uint32_t at = before + (uint32_t)__popcll(mask & (upto >> 1));
-        p.seed_ent[(size_t)tile * kCandPerBlock + at] = ((uint64_t)c << 32) | seed;
+        const uint64_t e = ((uint64_t)c << 32) | seed;
+        if (at < 3) p.blk_rec[(size_t)tile * 4 + 1 + at] = e;
+        else p.seed_ent[(size_t)tile * kCandPerBlock + at] = e;
     }
-    if (tid == 0) p.blk_cnt[tile] = total;
+    if (tid == 0) p.blk_rec[(size_t)tile * 4] = total;
 }
 
 // ---- staging pieces: 16 marks per thread and pass, 4 x (16-byte index load -> 4 tag gathers) ----------
@@ -512,37 +524,40 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     __shared__ uint32_t s_unsorted;
     const uint32_t k = blockIdx.x, tid = threadIdx.x;
     STAMP(1, 0);
-    const uint32_t c_lo = p.ctg_off[k], c_hi = p.ctg_off[k + 1];
+    const uint32_t c_lo = p.n_small ? p.ctg_small[k] : p.ctg_off[k];
+    const uint32_t c_hi = p.n_small ? p.ctg_small[k + 1] : p.ctg_off[k + 1];
+    uint32_t *region = p.onebuf + c_lo + k;                  // {n, seeds...}; capacity 1 + (c_hi - c_lo)
     if (c_lo == c_hi) {
-        if (tid == 0) p.n_one[k] = 0;
+        if (tid == 0) { p.n_one[k] = 0; region[0] = 0; }
         return;
     }
     if (tid == 0) s_unsorted = 0;
-    // Seed entries of the classify blocks that overlap this contig, in candidate order: thread t owns
-    // a contiguous run of blocks, counts the entries it will keep, and an exclusive scan gives its
+    // Seed entries of the classify tiles that overlap this contig, in candidate order: thread t owns
+    // a contiguous run of tiles, counts the entries it will keep, and an exclusive scan gives its
     // output position -- so a position-sorted VCF yields an (almost always) already ascending list.
     const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
     const uint32_t nb = b_hi - b_lo + 1;
     const uint32_t per = (nb + kSortThreads - 1) / kSortThreads;
     const uint32_t my_lo = min(b_lo + tid * per, b_hi + 1), my_hi = min(my_lo + per, b_hi + 1);
-    uint32_t *glist = p.onebuf + c_lo;                       // capacity c_hi - c_lo >= number of entries
-    uint32_t mine = 0;
-    // common case: one classify block per thread with at most 4 entries -> read once, keep in registers
-    const bool small = per == 1;
-    uint32_t cnt0 = 0, prev0 = kEmpty;
-    uint64_t e0[4] = {0, 0, 0, 0};
-    if (small && my_lo < my_hi) {
-        cnt0 = p.blk_cnt[my_lo];
-        const uint32_t pcnt = my_lo > b_lo ? p.blk_cnt[my_lo - 1] : 0u;
-        const uint64_t *ent = p.seed_ent + (size_t)my_lo * kCandPerBlock;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if ((uint32_t)j < cnt0) e0[j] = ent[j];
-        if (pcnt) {
-            const uint64_t pe = p.seed_ent[(size_t)(my_lo - 1) * kCandPerBlock + pcnt - 1];
-            if ((uint32_t)(pe >> 32) >= c_lo) prev0 = (uint32_t)pe;
-        }
+    uint32_t *glist = region + 1;
+    // entry j of tile b, given the tile's record
+    auto entry = [&](uint32_t b, uint32_t j, const ulonglong4 &rec) -> uint64_t {
+        return j == 0 ? rec.y : (j == 1 ? rec.z : (j == 2 ? rec.w : p.seed_ent[(size_t)b * kCandPerBlock + j]));
+    };
+    const ulonglong4 *recs = reinterpret_cast<const ulonglong4 *>(p.blk_rec);
+    // records of my first tile and of the tile before it (whose last entry, if it belongs to this contig,
+    // absorbs an equal first entry): both loads are independent -> one round trip
+    ulonglong4 rec0 = {0, 0, 0, 0}, recp = {0, 0, 0, 0};
+    if (my_lo < my_hi) {
+        rec0 = recs[my_lo];
+        if (my_lo > b_lo) recp = recs[my_lo - 1];
     }
-    const bool cached = small && cnt0 <= 4;
+    uint32_t prev0 = kEmpty;
+    if (my_lo < my_hi && my_lo > b_lo && (uint32_t)recp.x) {
+        const uint64_t pe = entry(my_lo - 1, (uint32_t)recp.x - 1, recp);
+        if ((uint32_t)(pe >> 32) >= c_lo) prev0 = (uint32_t)pe;
+    }
+    uint32_t mine = 0;
     for (int pass = 0; pass < 2; ++pass) {
         uint32_t at = 0;
         if (pass == 1) {
@@ -550,38 +565,12 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
             at = block_exscan(mine, tid, s_part, kSortThreads, &total);
             if (tid == 0) s_part[kSortThreads / 64] = total;
         }
-        // the last entry of the previous block, if it belongs to this contig, absorbs an equal first entry
-        uint32_t prev_ps = kEmpty;
-        if (cached) {
-            prev_ps = prev0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if ((uint32_t)j >= cnt0) continue;
-                const uint32_t c = (uint32_t)(e0[j] >> 32), ps = (uint32_t)e0[j];
-                if (c < c_lo || c >= c_hi || ps == prev_ps) continue;
-                if (pass == 0) {
-                    ++mine;
-                } else {
-                    if (at < kSortLds) s_key[at] = ps;
-                    glist[at] = ps;
-                    ++at;
-                }
-                prev_ps = ps;
-            }
-            continue;
-        }
-        if (my_lo < my_hi && my_lo > b_lo) {
-            const uint32_t pcnt = p.blk_cnt[my_lo - 1];
-            if (pcnt) {
-                const uint64_t pe = p.seed_ent[(size_t)(my_lo - 1) * kCandPerBlock + pcnt - 1];
-                if ((uint32_t)(pe >> 32) >= c_lo) prev_ps = (uint32_t)pe;
-            }
-        }
+        uint32_t prev_ps = prev0;
         for (uint32_t b = my_lo; b < my_hi; ++b) {
-            const uint32_t cnt = p.blk_cnt[b];
-            const uint64_t *ent = p.seed_ent + (size_t)b * kCandPerBlock;
+            const ulonglong4 rec = b == my_lo ? rec0 : recs[b];
+            const uint32_t cnt = (uint32_t)rec.x;
             for (uint32_t j = 0; j < cnt; ++j) {
-                const uint64_t e = ent[j];
+                const uint64_t e = entry(b, j, rec);
                 const uint32_t c = (uint32_t)(e >> 32), ps = (uint32_t)e;
                 if (c < c_lo || c >= c_hi) continue;
                 if (ps == prev_ps) continue;                  // same contig (both candidates in [c_lo, c_hi))
@@ -618,12 +607,12 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         // more seeds than LDS holds (unsorted input with very many phase sets): work in HBM
         __threadfence_block();
         if (unsorted) bitonic_sort(glist, n, tid, kSortThreads);
-        uint32_t *tmp = p.tmpbuf + c_lo;
+        uint32_t *tmp = p.tmpbuf + c_lo + k + 1;
         n_one = unique_copy(glist, n, tmp, tid, kSortThreads, s_part);
         __syncthreads();
         for (uint32_t i = tid; i < n_one; i += kSortThreads) glist[i] = tmp[i];
     }
-    if (tid == 0) p.n_one[k] = n_one;
+    if (tid == 0) { p.n_one[k] = n_one; region[0] = n_one; }
     STAMP(1, 3);
 }
 
@@ -705,7 +694,7 @@ __device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *o
 __global__ __launch_bounds__(256) void ef_finalize(const Params p)
 {
     __shared__ uint32_t s_one[kOneLds];
-    __shared__ uint32_t s_meta[4];                             // k0, n_one[k0] or ~0 (not LDS mode), any_empty, ctg_off[k0]
+    __shared__ uint32_t s_meta[4];                             // k0, n_one[k0] or ~0 (not LDS mode), any_empty, seed base of k0
     const uint32_t tid = threadIdx.x;
     STAMP(2, 0);
     const uint32_t c0 = blockIdx.x * 256u;
@@ -724,7 +713,7 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         s_meta[0] = k0;
         s_meta[1] = (k0 == k1 && n0 > 0 && n0 <= kOneLds) ? n0 : kEmpty;
         s_meta[2] = any;
-        s_meta[3] = p.ctg_off[k0];
+        s_meta[3] = p.ctg_off[k0] + k0 + 1;
     }
     __syncthreads();
     STAMP(2, 1);
@@ -747,7 +736,7 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         uint32_t k = k0;
         while (c >= p.ctg_off[k + 1]) ++k;
         n_one = p.n_one[k];
-        one = p.onebuf + p.ctg_off[k];
+        one = p.onebuf + p.ctg_off[k] + k + 1;
     }
     if (n_one == 0) {                                          // :209-210
         if (code != 0) p.out_pred[c] = 0;
@@ -834,22 +823,23 @@ int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
             blk_ctg[b] = k;
         }
     }
-    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B * 2;
+    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
     int rc;
     // the previous plan's buffers may still be in use by work queued on a stream
     HIP_TRY(ctx, hipDeviceSynchronize());
     if ((rc = reserve(ctx, ctx->ws_small, small_words * 4))) return rc;
     if ((rc = reserve(ctx, ctx->ws_start, C))) return rc;
     if ((rc = reserve(ctx, ctx->ws_ent, (size_t)B * kCandPerBlock * 8))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_one, (size_t)C * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_tmp, (size_t)C * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->ws_one, ((size_t)C + K + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->ws_tmp, ((size_t)C + K + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->ws_c2, (size_t)B * kC2Quota * kC2Words * 4))) return rc;
     uint32_t *w = (uint32_t *)ctx->ws_small.ptr;
     ctx->d_ctg_off = w;            w += K + 1;
     ctx->d_n_one = w;              w += K;
     ctx->d_status = w;             w += 8;
     ctx->d_blk_ctg = w;            w += B;
-    ctx->d_blk_cnt = w;
+    w += ((uintptr_t)w & 31) ? (32 - ((uintptr_t)w & 31)) / 4 : 0;        // 32-byte aligned tile records
+    ctx->d_blk_cnt = w;            // B records of 4 x u64
     HIP_TRY(ctx, hipMemcpy(ctx->d_ctg_off, pr->cand_ctg_off, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_blk_ctg, blk_ctg.data(), sizeof(uint32_t) * B, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemset(ctx->d_n_one, 0, sizeof(uint32_t) * ((size_t)K + 8)));
@@ -953,8 +943,10 @@ void duet_ctx_destroy(duet_ctx *ctx)
 int duet_ctx_set_profiling(duet_ctx *ctx, int enabled)
 {
     if (!ctx) return fail(nullptr, DUET_ERR_INVALID, "null context");
-    if (ctx->ev_used && ctx->ev_mode != enabled) return fail(ctx, DUET_ERR_INVALID, "collect the pending profile before changing the mode");
-    ctx->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    if (ctx->ev_used && ctx->ev_mode != (enabled == 3 ? 1 : enabled))
+        return fail(ctx, DUET_ERR_INVALID, "collect the pending profile before changing the mode");
+    ctx->profiling = enabled < 0 ? 0 : (enabled > 3 ? 3 : enabled);
+    ctx->prof_tick = 0;
     return DUET_OK;
 }
 
@@ -993,7 +985,10 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     p.cand_off = pr->cand_off; p.mark_read = pr->mark_read;
     p.svlen_thres = pr->svlen_thres; p.suppread_thres = pr->suppread_thres;
     p.ctg_off = ctx->d_ctg_off; p.ctg_start = (const uint8_t *)ctx->ws_start.ptr; p.blk_ctg = ctx->d_blk_ctg;
-    p.blk_cnt = ctx->d_blk_cnt; p.seed_ent = (uint64_t *)ctx->ws_ent.ptr;
+    p.blk_rec = (uint64_t *)ctx->d_blk_cnt; p.seed_ent = (uint64_t *)ctx->ws_ent.ptr;
+    p.one_cap = pr->n_cands + pr->n_contigs;
+    p.n_small = pr->n_contigs <= (uint32_t)kSmallK ? pr->n_contigs : 0;
+    for (uint32_t k = 0; k <= p.n_small && p.n_small; ++k) p.ctg_small[k] = pr->cand_ctg_off[k];
     p.onebuf = (uint32_t *)ctx->ws_one.ptr; p.tmpbuf = (uint32_t *)ctx->ws_tmp.ptr;
     p.n_one = ctx->d_n_one; p.c2rec = (uint32_t *)ctx->ws_c2.ptr; p.status = ctx->d_status;
     p.out_pred = out_pred; p.out_ps = out_ps;
@@ -1004,9 +999,10 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     // so hipEventElapsedTime is the kernel's execution time as rocprofv3 --kernel-trace reports it.
     // 6 events per run: {start, stop} x {classify, seed_sort, finalize}; mode 1 uses the first pair only.
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const int prof = ctx->profiling;
+    int prof = ctx->profiling;
+    if (prof == 3) prof = (ctx->prof_tick++ % 8u == 0) ? 1 : 0;       // sampled: every 8th run carries the two events
     if (prof) {
-        ctx->ev_mode = prof;
+        ctx->ev_mode = prof;                                        // 1 or 2 (a sampled run records like mode 1)
         while (ctx->ev_pool.size() < ctx->ev_used + 6) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreate(&e));
@@ -1082,7 +1078,7 @@ int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t 
     HIP_TRY(ctx, hipMemcpy(&n, ctx->d_n_one + contig, 4, hipMemcpyDeviceToHost));
     const uint32_t take = n < cap ? n : cap;
     if (take && out)
-        HIP_TRY(ctx, hipMemcpy(out, (uint32_t *)ctx->ws_one.ptr + ctx->plan_off[contig], (size_t)take * 4,
+        HIP_TRY(ctx, hipMemcpy(out, (uint32_t *)ctx->ws_one.ptr + ctx->plan_off[contig] + contig + 1, (size_t)take * 4,
                                hipMemcpyDeviceToHost));
     return (int)n;
 }

@@ -17,8 +17,9 @@ struct DevBuf {
 struct duet_ctx {
     int device = 0;
     std::string err;
-    int profiling = 0;                     // 0 off, 1 events around ef_classify only, 2 around every kernel
+    int profiling = 0;                     // 0 off, 1 ef_classify events, 2 every kernel, 3 ef_classify on every 8th run
     int ev_mode = 0;                       // mode the pooled events were recorded with
+    uint32_t prof_tick = 0;                // run counter of the sampled mode
     uint32_t dbg = 0;
     unsigned long long *d_stamps = nullptr;
     hipStream_t own_stream = nullptr;

@@ -103,8 +103,9 @@ const char *duet_last_error(const duet_ctx *ctx);
 
 /* HIP events attached to the kernels' own dispatches (hipExtLaunchKernelGGL start/stop events on the run's
  * stream), resolved by duet_ef_profile_collect: 0 = none, 1 = the dominant kernel (ef_classify) only -- two
- * events per run, what bench.py uses inside its timed region --, 2 = every kernel (kernel_ms[] complete,
- * total_ms = first start to last end; serialises the stream a little more). */
+ * events per run --, 2 = every kernel (kernel_ms[] complete, total_ms = first start to last end; serialises
+ * the stream a little more), 3 = like 1 but only on every 8th run (what bench.py uses inside its timed
+ * region: event pairs cost ~6 us of stream time each, a quarter of a config-2 step). */
 int duet_ctx_set_profiling(duet_ctx *ctx, int mode);
 
 /*
