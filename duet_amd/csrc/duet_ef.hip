@@ -152,42 +152,41 @@ struct Params {
 
 // Per-candidate running state over its marks in list order.
 struct CandState {
-    uint32_t n_ps = 0, first_ps = 0;          // distinct PS among tagged marks: 0, 1, 2(=many)   (:191-194)
-    uint32_t seed = kEmpty;                   // PS of first voter (:199-203)
-    uint32_t last_ps = 0;                     // PS of last voter (:77)
-    // voters grouped by PS, first two groups in first-seen order (A, B); a third group sets `more`.
-    // With one PS (class 1) group A is the whole vote (:74-84); with several it feeds :85-105.
-    uint32_t ps_a = 0, ps_b = 0, n_a = 0, n_b = 0, nv = 0;
+    // distinct PS among ALL tagged marks (no PC filter, Q7): first one seen, and whether another was seen (:191-194)
+    uint32_t first_ps = kEmpty;
+    bool multi = false;
+    // voters (tagged, pc <= 8100) grouped by PS: first two groups in first-seen order (A, B); a third group sets
+    // `more`.  Group A's PS is the PS of the FIRST voter = the seed (:199-203); with a single PS (class 1) group A
+    // is the whole vote (:74-84) and its PS is also the last voter's PS (:77); with several PS it feeds :85-105.
+    uint32_t ps_a = kEmpty, ps_b = kEmpty, n_a = 0, n_b = 0, nv = 0;
     uint32_t a1 = 0, a2 = 0, b1 = 0, b2 = 0;  // hap-1 / hap-2 counts per group
     uint32_t ta1 = 0, ta2 = 0, tb1 = 0, tb2 = 0;   // PC sums; A's are per-chunk partials folded into TA1/TA2
     uint64_t TA1 = 0, TA2 = 0;
     bool more = false;
+
+    __device__ __forceinline__ uint32_t n_ps() const { return first_ps == kEmpty ? 0u : (multi ? 2u : 1u); }
+    __device__ __forceinline__ uint32_t seed() const { return ps_a; }        // kEmpty when nobody voted
 };
 
-// thread walks marks [lo, hi) of its candidate; tags of mark m sit at s_tag[m - cs]   (branch-light)
+// thread walks marks [lo, hi) of its candidate; tags of mark m sit at s_tag[m - cs].
+// An absent mark is the all-ones word: its "ps" is kEmpty and its "pc" 2^30-1, so it is neither a new PS nor a voter
+// without a separate test.
 __device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs)
 {
-    // the LDS read of mark m+1 is issued before mark m is processed, so its latency hides under the ~45 VALU
-    // instructions of the body even when the SIMD has no other wave to switch to (small problems)
-    uint64_t next = lo < hi ? s_tag[lo - cs] : 0ull;
     for (uint32_t m = lo; m < hi; ++m) {
-        const uint64_t tag = next;
-        next = s_tag[min(m + 1, hi - 1) - cs];
+        const uint64_t tag = s_tag[m - cs];
         const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
-        const bool tagged = w != 0xFFFFFFFFu;           // an absent mark is all ones
         const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
-        const bool voter = pc <= kPcMax;                // absent marks have pc = 2^30-1: never voters
-        const bool fresh = tagged && st.n_ps == 0;
-        st.first_ps = fresh ? ps : st.first_ps;
-        st.n_ps = tagged ? (ps != st.first_ps ? 2u : max(st.n_ps, 1u)) : st.n_ps;
-        st.seed = (voter && st.seed == kEmpty) ? ps : st.seed;
-        st.last_ps = voter ? ps : st.last_ps;
+        const bool voter = pc <= kPcMax;
+        st.first_ps = st.first_ps == kEmpty ? ps : st.first_ps;
+        st.multi = st.multi || (ps != st.first_ps && ps != kEmpty);
         st.nv += voter;
-        st.ps_a = (voter && st.n_a == 0) ? ps : st.ps_a;
+        st.ps_a = (voter && st.ps_a == kEmpty) ? ps : st.ps_a;
         const bool in_a = voter && ps == st.ps_a;
-        st.ps_b = (voter && !in_a && st.n_b == 0) ? ps : st.ps_b;
-        const bool in_b = voter && !in_a && ps == st.ps_b;
-        st.more = st.more || (voter && !in_a && !in_b);
+        const bool rest = voter && !in_a;
+        st.ps_b = (rest && st.ps_b == kEmpty) ? ps : st.ps_b;
+        const bool in_b = rest && ps == st.ps_b;
+        st.more = st.more || (rest && !in_b);
         const bool is1 = hap == 1, is2 = hap == 2;
         st.n_a += in_a; st.n_b += in_b;
         st.a1 += in_a && is1; st.a2 += in_a && is2;
@@ -214,20 +213,22 @@ __device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uin
     bool want_seed = false;
     // multi-PS candidates get a summary slot (first two voter groups) unless a third group exists or
     // the PC sums could leave 32 bits; those few are re-gathered by ef_finalize
-    const bool c2 = active && st.n_ps == 2;
+    const uint32_t n_ps = st.n_ps();
+    const bool c2 = active && n_ps == 2;
     const bool c2_fast = c2 && !st.more && deg < 500000u;
     const uint32_t rank = c2_fast ? atomicAdd(&sh.c2n, 1u) : kC2Quota;
     if (live) {
         if (divzero) {
             code = kDivZero;
         } else if (active) {
-            want_seed = (st.n_ps == 1) && st.seed != kEmpty;                                       // :198-203
+            want_seed = (n_ps == 1) && st.seed() != kEmpty;                                        // :198-203
             if (c2) {
                 if (rank < kC2Quota) {
                     const uint32_t slot = tile * kC2Quota + rank;
                     uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
                     const uint32_t ng = (st.n_a != 0) + (st.n_b != 0);
                     rec[0] = st.nv; rec[1] = ng;
+                    // ps_a / ps_b are only meaningful when n_a / n_b > 0 (ng says how many groups exist)
                     rec[2] = st.ps_a; rec[3] = st.n_a; rec[4] = st.a1; rec[5] = st.a2;
                     rec[6] = (uint32_t)st.TA1; rec[7] = (uint32_t)st.TA2;
                     rec[8] = st.ps_b; rec[9] = st.n_b; rec[10] = st.b1; rec[11] = st.b2; rec[12] = st.tb1; rec[13] = st.tb2;
@@ -241,9 +242,9 @@ __device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uin
                 v.hap1 = st.a1; v.hap2 = st.a2; v.hap0 = 0;
                 v.allhap = st.a1 + st.a2;
                 v.t1 = st.TA1; v.t2 = st.TA2;
-                code = (p.dbg & 2) ? 0 : (uint8_t)decide((int)st.n_ps, v, deg, svread, refread);
-                ps_out = st.last_ps;
-                if (st.n_ps == 0 || (st.a1 == 0 && st.a2 == 0)) code |= kNeedNearest;              // :106
+                code = (p.dbg & 2) ? 0 : (uint8_t)decide((int)n_ps, v, deg, svread, refread);
+                ps_out = st.ps_a == kEmpty ? 0u : st.ps_a;                // class 1: the single PS = last voter's PS (:77)
+                if (n_ps == 0 || (st.a1 == 0 && st.a2 == 0)) code |= kNeedNearest;                 // :106
             }
         }
         p.out_pred[c] = code;
@@ -254,7 +255,7 @@ __device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uin
     // candidate is dropped, unless a contig starts in between (seed sets are per contig).  Only the
     // set matters downstream, so dropping duplicates early just shortens ef_seed_sort's input.
     if (p.dbg & 1) want_seed = false;
-    const uint32_t seed = st.seed;
+    const uint32_t seed = st.seed();
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const unsigned long long wmask = __ballot(want_seed);
     const unsigned long long smask = __ballot(is_start != 0);
