@@ -1,37 +1,11 @@
-# INTEGRATION — wiring `libduet_ef.so` into upstream Duet
+# coding=utf-8
+"""The ctypes stub a maintainer would drop into upstream as src/duet/ef_gpu.py.
 
-Upstream (yekaizhou/duet v0.6) is pure Python; its step E/F lives in
-`src/duet/sv_phasing_fn.py`.  The library replaces the arithmetic between "callset built"
-(`generate_callinfo`, :36-68) and "rows sorted" (:229).  Everything else — CLI, VCF/BAM reading,
-row formatting — can stay exactly as upstream has it.
-
-## 1. Build
-
-```
-make -C duet_amd/csrc            # hipcc --offload-arch=gfx950 … -> duet_amd/lib/libduet_ef.so
-```
-(or `python -c "import __graft_entry__ as g; g.build()"`).  The only dependency is the HIP runtime.
-If the process also imports PyTorch-ROCm, import torch **before** loading the library so that both
-share torch's bundled `libamdhip64.so` (two HIP runtimes in one process cannot both own the GPU);
-`duet_amd/_lib.py` does this.
-
-## 2. Entry points a binding needs (include/duet_ef.h)
-
-| C symbol | replaces (reference file:line) |
-|---|---|
-| `duet_ctx_create / duet_ctx_destroy / duet_last_error` | — (device context; upstream has no state) |
-| `duet_ef_run_host(ctx, problem, out_pred, out_ps, stats)` | `sv_phasing_fn.py:189-212`: filter (:189-190), PS-class (:191-194), seed sets (:195-203), `predict_hp`/`get_phase_info` (:70-183), contig drop (:209-210) |
-| `duet_ef_run_device(ctx, problem, out_pred, out_ps, stream)` + `duet_ef_check` | same, on device-resident arrays, asynchronous |
-| `duet_ctx_set_profiling`, `duet_ef_profile_collect`, `duet_ef_get_seed_ps` | — (measurement / inspection) |
-
-## 3. The stub a maintainer would add to upstream (ctypes, ~60 lines)
-
-Drop this next to `sv_phasing_fn.py` and replace lines 189-228 of `generate_phased_callset` by
-`phased_callset = phase_on_gpu(callstat, chrom_list, svlen_thres, suppread_thres)`; the final
-`sort` (:229) stays.
-
-```python
-# src/duet/ef_gpu.py  -- kept as a real, tested file: integration/ef_gpu.py
+It consumes exactly what upstream's generate_callinfo returns (sv_phasing_fn.py:49-68: a list of dicts with
+chrom, pos, svlen, svtype, svread, refread, callgt, ref, alt and svreadinfo = [name] or [name, hap, ps, pc] per
+mark) and replaces lines 189-228 of generate_phased_callset.  tests/test_integration_stub.py runs it on such
+lists (with the C oracle in place of `_run`, no GPU needed) and compares with the product path.
+"""
 import ctypes, numpy as np
 
 class _Problem(ctypes.Structure):
@@ -104,42 +78,3 @@ def phase_on_gpu(callstat, chrom_list, svlen_thres, suppread_thres):
     return [dict(ps=int(ps[i]), hp=hp[int(pred[i])], chrom=callstat[i]['chrom'], pos=callstat[i]['pos'],
                  svlen=callstat[i]['svlen'] if callstat[i]['svtype'] in ['INS', 'DUP'] else -callstat[i]['svlen'],
                  svtype=callstat[i]['svtype'], ref=callstat[i]['ref'], alt=callstat[i]['alt']) for i in order]
-```
-
-`duet_amd/sv_phasing_fn.py` is the same idea without the intermediate Python dicts: `parse_vcf`
-and `read_hap_bam` fill the arrays directly, so the flattening is not a second pass.
-
-## 4. Using this repository as the drop-in
-
-`bin/duet BAM REFERENCE OUTPUT [-t -m -c -s -r -a -b]` has upstream's command line (utils.py:19-44;
-one additive flag, `--device`).  Steps B–D shell out to the same external tools; step E/F reads
-`OUTPUT/sv_calling/variants.vcf` and `OUTPUT/snp_phasing/{chrN|N}.bam` and writes
-`OUTPUT/phased_sv.vcf` byte-identically to upstream (tests/test_gpu_parity.py).  To run only the
-accelerated stage on an existing Duet output directory:
-
-```python
-from duet_amd.sv_phasing import sv_phasing
-sv_phasing('OUTPUT', 50, 2, 4, False)       # home, -s, -r, -t, -a   (sv_phasing.py:8)
-```
-
-By default the host side runs natively (`libduet_ingest.so`, `include/duet_ingest.h`: BGZF/BAM reader, VCF
-tokeniser for the three caller dialects, row formatter — 0.2 s per million marks end to end).  It only
-accepts input it reproduces exactly; anything else (non-ASCII bytes, blank lines, malformed numbers, missing
-fields) makes it decline and the Python host path (`duet_amd/read_file.py`, `sv_phasing_fn.py`,
-`write_file.py`, built-in `bamio.py` reader) runs instead and raises what upstream would raise.
-`DUET_NATIVE_INGEST=0` forces the Python path; `DUET_USE_SAMTOOLS=1` reads tags through `samtools view`
-exactly as upstream does (sv_phasing_fn.py:25).
-
-Other entry points:
-
-* `duet_cluster_run_host / duet_cluster_run_device` (include/duet_ef.h) — stage A0, span-position clustering of
-  raw SV marks (what `svim alignment … --cluster_max_distance` does for upstream, sv_calling.py:13-15);
-  Python: `duet_amd._lib.Context.cluster_host(contig, type, pos, span, max_dist=0.9)`.
-* `python -m duet_amd.evaluation CALLSET TRUTHSET [-r -p -b --skip_phasing]` — upstream's
-  `src/scripts/evaluation.py` with the same options and the same ten numbers.
-
-## 5. Multi-GPU
-
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N …`); `duet_amd/dist.py`
-assigns whole contigs to ranks, each rank calls `duet_ef_run_device` on its shard, and one
-`torch.distributed.all_gather_into_tensor` (RCCL) reassembles the `(ps, pred)` records.
