@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -66,29 +67,16 @@ const char *find_sub(const char *hay, size_t hn, const char *needle, size_t nn)
 
 inline bool contains(Span s, const char *needle) { return find_sub(s.p, s.n, needle, strlen(needle)) != nullptr; }
 
-// first ';'-separated item of `info` containing any of the needles
-bool first_item_with(Span info, const char *const *needles, int nn, Span &item)
-{
-    size_t i = 0;
-    while (i <= info.n) {
-        size_t j = i;
-        while (j < info.n && info.p[j] != ';') ++j;
-        Span it{info.p + i, j - i};
-        for (int k = 0; k < nn; ++k)
-            if (contains(it, needles[k])) { item = it; return true; }
-        i = j + 1;
-    }
-    return false;
-}
-
 // ---------------------------------------------------------------------------------------------
 // read-name -> index table (open addressing over an arena of names)
 // ---------------------------------------------------------------------------------------------
+// Layout chosen for the join of ~10^6 mark names against ~10^5..10^7 read names, which is bound by cache
+// misses: a probe touches one slot (hash tag + arena offset) and, on a tag match, one arena entry
+// {index, length, bytes}; lookups are issued in batches with software prefetch (see NameBatch).
 struct NameTable {
-    std::vector<char> arena;
-    std::vector<uint32_t> off, len;
-    std::vector<uint32_t> slots;      // index + 1, 0 = empty
-    uint32_t mask = 0;
+    std::vector<char> arena;          // entries: u32 index, u32 length, bytes
+    std::vector<uint64_t> slots;      // (hash32 << 32) | (arena offset + 1), 0 = empty
+    uint32_t count = 0, mask = 0;
 
     static uint64_t hash(const char *s, size_t n)
     {
@@ -99,43 +87,82 @@ struct NameTable {
     void grow()
     {
         const uint32_t cap = slots.empty() ? 1024u : (uint32_t)slots.size() * 2u;
-        std::vector<uint32_t> ns(cap, 0);
+        std::vector<uint64_t> ns(cap, 0);
         mask = cap - 1;
-        for (uint32_t i = 0; i < off.size(); ++i) {
-            uint32_t s = (uint32_t)hash(arena.data() + off[i], len[i]) & mask;
+        size_t o = 0;
+        while (o < arena.size()) {
+            uint32_t len;
+            memcpy(&len, arena.data() + o + 4, 4);
+            const uint64_t h = hash(arena.data() + o + 8, len);
+            uint32_t s = (uint32_t)h & mask;
             while (ns[s]) s = (s + 1) & mask;
-            ns[s] = i + 1;
+            ns[s] = ((h >> 32) << 32) | (uint64_t)(o + 1);
+            o += 8 + len;
         }
         slots.swap(ns);
     }
-    int find(const char *s, size_t n) const
+    // probe with a precomputed hash; -1 when absent
+    int find_hashed(const char *s, size_t n, uint64_t hh) const
     {
         if (slots.empty()) return -1;
-        uint32_t h = (uint32_t)hash(s, n) & mask;
+        const uint32_t tag = (uint32_t)(hh >> 32);
+        uint32_t h = (uint32_t)hh & mask;
         for (;;) {
-            const uint32_t v = slots[h];
+            const uint64_t v = slots[h];
             if (!v) return -1;
-            const uint32_t i = v - 1;
-            if (len[i] == n && memcmp(arena.data() + off[i], s, n) == 0) return (int)i;
+            if ((uint32_t)(v >> 32) == tag) {
+                const char *e = arena.data() + ((uint32_t)v - 1);
+                uint32_t idx, len;
+                memcpy(&idx, e, 4);
+                memcpy(&len, e + 4, 4);
+                if (len == n && memcmp(e + 8, s, n) == 0) return (int)idx;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+    int find(const char *s, size_t n) const { return find_hashed(s, n, hash(s, n)); }
+    void prefetch_slot(uint64_t hh) const
+    {
+        if (!slots.empty()) __builtin_prefetch(&slots[(uint32_t)hh & mask]);
+    }
+    void prefetch_entry(uint64_t hh) const
+    {   // first slot whose tag matches (if any): bring its arena entry in
+        if (slots.empty()) return;
+        const uint32_t tag = (uint32_t)(hh >> 32);
+        uint32_t h = (uint32_t)hh & mask;
+        for (int step = 0; step < 4; ++step) {
+            const uint64_t v = slots[h];
+            if (!v) return;
+            if ((uint32_t)(v >> 32) == tag) { __builtin_prefetch(arena.data() + ((uint32_t)v - 1)); return; }
             h = (h + 1) & mask;
         }
     }
     uint32_t find_or_add(const char *s, size_t n, bool &added)
     {
-        if ((off.size() + 1) * 2 > slots.size()) grow();
-        uint32_t h = (uint32_t)hash(s, n) & mask;
+        if (((size_t)count + 1) * 2 > slots.size()) grow();
+        const uint64_t hh = hash(s, n);
+        const uint32_t tag = (uint32_t)(hh >> 32);
+        uint32_t h = (uint32_t)hh & mask;
         for (;;) {
-            const uint32_t v = slots[h];
+            const uint64_t v = slots[h];
             if (!v) break;
-            const uint32_t i = v - 1;
-            if (len[i] == n && memcmp(arena.data() + off[i], s, n) == 0) { added = false; return i; }
+            if ((uint32_t)(v >> 32) == tag) {
+                const char *e = arena.data() + ((uint32_t)v - 1);
+                uint32_t idx, len;
+                memcpy(&idx, e, 4);
+                memcpy(&len, e + 4, 4);
+                if (len == n && memcmp(e + 8, s, n) == 0) { added = false; return idx; }
+            }
             h = (h + 1) & mask;
         }
-        const uint32_t idx = (uint32_t)off.size();
-        off.push_back((uint32_t)arena.size());
-        len.push_back((uint32_t)n);
-        arena.insert(arena.end(), s, s + n);
-        slots[h] = idx + 1;
+        const uint32_t idx = count++;
+        const size_t o = arena.size();
+        const uint32_t len = (uint32_t)n;
+        arena.resize(o + 8 + n);
+        memcpy(arena.data() + o, &idx, 4);
+        memcpy(arena.data() + o + 4, &len, 4);
+        memcpy(arena.data() + o + 8, s, n);
+        slots[h] = ((uint64_t)tag << 32) | (uint64_t)(o + 1);
         added = true;
         return idx;
     }
@@ -426,170 +453,315 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     return DUET_INGEST_OK;
 }
 
-int duet_ingest_parse_vcf(duet_ingest *g, const char *path)
+namespace {
+
+struct Rec { Span tok[10]; };
+
+// One pass over an INFO column: the first ';'-separated item CONTAINING each key (read_file.py:34,38,40,48 use
+// `in`).  Every key ends with '=', so an item contains a key iff some '=' in it is preceded by the key's letters.
+struct InfoHits { Span svlen{nullptr, 0}, svtype{nullptr, 0}, supp{nullptr, 0}, names{nullptr, 0}; };
+
+inline bool ends_with(const char *item, size_t eq, const char *key, size_t kn)
+{   // bytes item[eq-kn+1 .. eq] == key (key includes its trailing '=')
+    return eq + 1 >= kn && memcmp(item + eq + 1 - kn, key, kn) == 0;
+}
+
+void scan_info(Span info, InfoHits &h)
+{
+    size_t i = 0;
+    while (i <= info.n) {
+        size_t j = i;
+        bool len_ = false, type_ = false, supp_ = false, names_ = false;
+        for (; j < info.n && info.p[j] != ';'; ++j) {
+            if (info.p[j] != '=') continue;
+            const char *it = info.p + i;
+            const size_t e = j - i;
+            if (ends_with(it, e, "SVLEN=", 6)) len_ = true;
+            if (ends_with(it, e, "SVTYPE=", 7)) type_ = true;
+            if (ends_with(it, e, "SUPPORT=", 8) || ends_with(it, e, "SR=", 3) || ends_with(it, e, "RE=", 3)) supp_ = true;
+            if (ends_with(it, e, "RNAMES=", 7) || ends_with(it, e, "READS=", 6)) names_ = true;
+        }
+        const Span item{info.p + i, j - i};
+        if (len_ && !h.svlen.p) h.svlen = item;
+        if (type_ && !h.svtype.p) h.svtype = item;
+        if (supp_ && !h.supp.p) h.supp = item;
+        if (names_ && !h.names.p) h.names = item;
+        i = j + 1;
+    }
+}
+
+struct Layout { size_t supp_cut, rn_cut; int fmt_kind; };
+
+}  // namespace
+
+int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
 {
     if (!g || !path) return DUET_INGEST_INVALID;
+    const bool timing = getenv("DUET_INGEST_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[duet_ingest] %-14s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (g->alias) return unsupported(g, "contig list names a contig twice");
     if (!read_file(path, g->vcf)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
     const char *d = g->vcf.data();
     const size_t n = g->vcf.size();
-    for (size_t i = 0; i < n; ++i)
-        if ((unsigned char)d[i] >= 0x80 || d[i] == 0) return unsupported(g, "non-ASCII byte in the VCF");
+    if (n && memchr(d, 0, n)) return unsupported(g, "NUL byte in the VCF");
+    lap("read+ascii");
     const int K = (int)g->contigs.size();
+    int T = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+    if (n < (1u << 20)) T = 1;
 
-    struct Rec { Span tok[10]; };
-    std::vector<std::vector<Rec>> per(K);
-    g->contig_lines.clear();
-    size_t p = 0;
-    std::string key;
-    while (p < n) {
-        size_t e = p;
-        while (e < n && d[e] != '\n' && d[e] != '\r') ++e;          // universal newlines
-        // tokens of the line
-        Rec r;
-        int nt = 0;
-        size_t i = p;
-        while (i < e) {
-            while (i < e && is_py_space((unsigned char)d[i])) ++i;
-            if (i >= e) break;
-            size_t j = i;
-            while (j < e && !is_py_space((unsigned char)d[j])) ++j;
-            if (nt < 10) r.tok[nt] = Span{d + i, j - i};
-            ++nt;
-            i = j;
+    // ---- lines (universal newlines: \n, \r, \r\n) ------------------------------------------------
+    std::vector<size_t> line_lo, line_hi;
+    {
+        const bool has_cr = n && memchr(d, '\r', n);
+        size_t p = 0;
+        while (p < n) {
+            size_t e;
+            if (!has_cr) {
+                const char *q = (const char *)memchr(d + p, '\n', n - p);
+                e = q ? (size_t)(q - d) : n;
+            } else {
+                e = p;
+                while (e < n && d[e] != '\n' && d[e] != '\r') ++e;
+            }
+            line_lo.push_back(p);
+            line_hi.push_back(e);
+            p = e + 1;
+            if (has_cr && e < n && d[e] == '\r' && p < n && d[p] == '\n') ++p;
         }
-        if (nt == 0) {
-            // a blank line raises IndexError upstream (read_file.py:30) -- except the empty string after a final
-            // line break, which readlines() does not produce
-            const bool at_end = e >= n;
-            if (!(at_end && p == e)) return unsupported(g, "blank line in the VCF");
-        } else {
-            if (contains(r.tok[0], "##contig=<ID=")) g->contig_lines.push_back(r.tok[0]);
+    }
+    const size_t L = line_lo.size();
+    lap("lines");
+
+    // ---- phase A (parallel over lines): tokenise, pick the records of listed contigs ------------------
+    struct PartA { std::vector<std::vector<Rec>> per; std::vector<Span> contig_lines; std::string why; };
+    std::vector<PartA> pa(T);
+    auto work_a = [&](int t) {
+        PartA &o = pa[t];
+        o.per.resize(K);
+        const size_t lo = L * t / T, hi = L * (t + 1) / T;
+        if (lo < hi) {      // non-ASCII bytes anywhere in this thread's stretch of the file
+            unsigned char acc = 0;
+            for (size_t i = line_lo[lo]; i < line_hi[hi - 1]; ++i) acc |= (unsigned char)d[i];
+            if (acc & 0x80) { o.why = "non-ASCII byte in the VCF"; return; }
+        }
+        std::string key;
+        for (size_t li = lo; li < hi; ++li) {
+            const size_t p = line_lo[li], e = line_hi[li];
+            Rec r;
+            int nt = 0;
+            size_t i = p;
+            while (i < e) {
+                while (i < e && is_py_space((unsigned char)d[i])) ++i;
+                if (i >= e) break;
+                size_t j = i;
+                while (j < e && !is_py_space((unsigned char)d[j])) ++j;
+                if (nt < 10) r.tok[nt] = Span{d + i, j - i};
+                ++nt;
+                i = j;
+            }
+            if (nt == 0) {   // a blank line raises IndexError upstream (read_file.py:30)
+                o.why = "blank line in the VCF";
+                return;
+            }
+            if (contains(r.tok[0], "##contig=<ID=")) o.contig_lines.push_back(r.tok[0]);
             key.assign(r.tok[0].p, r.tok[0].n);
             auto it = g->owner.find(key);
             if (it != g->owner.end()) {
-                if (nt < 10) return unsupported(g, "record with fewer than 10 columns");
-                per[it->second].push_back(r);
+                if (nt < 10) { o.why = "record with fewer than 10 columns"; return; }
+                o.per[it->second].push_back(r);
             }
         }
-        p = e + 1;
-        if (e < n && d[e] == '\r' && p < n && d[p] == '\n') ++p;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(work_a, t);
+        work_a(0);
+        for (auto &th : pool) th.join();
     }
+    lap("phase A");
+    for (int t = 0; t < T; ++t)
+        if (!pa[t].why.empty()) return unsupported(g, pa[t].why);
+    g->contig_lines.clear();
+    for (int t = 0; t < T; ++t) g->contig_lines.insert(g->contig_lines.end(), pa[t].contig_lines.begin(), pa[t].contig_lines.end());
 
-    size_t C = 0;
-    for (auto &v : per) C += v.size();
+    // callset order: contig-major, file order inside a contig
+    std::vector<const Rec *> recs;
     g->cand_ctg_off.assign(K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        for (int t = 0; t < T; ++t)
+            for (const Rec &r : pa[t].per[k]) recs.push_back(&r);
+        g->cand_ctg_off[k + 1] = (uint32_t)recs.size();
+    }
+    const size_t C = recs.size();
+
     g->read_off.assign(K + 1, 0);
-    for (auto *v : {&g->cand_pos, &g->cand_svlen, &g->cand_svread, &g->cand_refread}) { v->clear(); v->reserve(C); }
-    g->cand_gt_ok.clear(); g->cand_plus.clear(); g->cand_off.assign(1, 0); g->mark_read.clear();
-    g->c_chrom.clear(); g->c_ref.clear(); g->c_alt.clear(); g->c_type.clear();
     g->read_tag.clear();
     for (int k = 0; k < K; ++k) {
         g->read_off[k + 1] = g->read_off[k] + (uint32_t)g->tags[k].size();
         g->read_tag.insert(g->read_tag.end(), g->tags[k].begin(), g->tags[k].end());
     }
 
-    static const char *const kSupp[] = {"SUPPORT=", "SR=", "RE="};
-    static const char *const kNames[] = {"RNAMES=", "READS="};
-    static const char *const kLen[] = {"SVLEN="};
-    static const char *const kType[] = {"SVTYPE="};
+    lap("merge");
+    // ---- layout switches from each contig's FIRST record (read_file.py:41,49,57,63,65) ---------------
+    std::vector<Layout> layout(K, Layout{0, 0, 0});
     for (int k = 0; k < K; ++k) {
-        const std::vector<Rec> &recs = per[k];
-        if (!recs.empty()) {
-            // layout switches from the contig's FIRST record (read_file.py:41,49,57,63,65)
-            Span it;
-            if (!first_item_with(recs[0].tok[7], kSupp, 3, it)) return unsupported(g, "first record without a support count");
-            const size_t supp_cut = contains(it, "SUPPORT=") ? 8 : 3;
-            if (!first_item_with(recs[0].tok[7], kNames, 2, it)) return unsupported(g, "first record without read names");
-            const size_t rn_cut = contains(it, "RNAMES=") ? 7 : 6;
-            int fmt_kind;
-            {
-                const Span s = recs[0].tok[9];
-                int nsub = 1;
-                size_t last = 0;
-                for (size_t i = 0; i < s.n; ++i)
-                    if (s.p[i] == ':') { ++nsub; last = i + 1; }
-                if (nsub < 3) return unsupported(g, "sample column with fewer than three fields");
-                if (nsub > 4) fmt_kind = 0;
-                else fmt_kind = memchr(s.p + last, ',', s.n - last) ? 2 : 1;
-            }
+        if (g->cand_ctg_off[k] == g->cand_ctg_off[k + 1]) continue;
+        const Rec &r0 = *recs[g->cand_ctg_off[k]];
+        InfoHits h;
+        scan_info(r0.tok[7], h);
+        if (!h.supp.p) return unsupported(g, "first record without a support count");
+        if (!h.names.p) return unsupported(g, "first record without read names");
+        layout[k].supp_cut = contains(h.supp, "SUPPORT=") ? 8 : 3;
+        layout[k].rn_cut = contains(h.names, "RNAMES=") ? 7 : 6;
+        const Span s = r0.tok[9];
+        int nsub = 1;
+        size_t last = 0;
+        for (size_t i = 0; i < s.n; ++i)
+            if (s.p[i] == ':') { ++nsub; last = i + 1; }
+        if (nsub < 3) return unsupported(g, "sample column with fewer than three fields");
+        layout[k].fmt_kind = nsub > 4 ? 0 : (memchr(s.p + last, ',', s.n - last) ? 2 : 1);
+    }
+
+    // ---- phase B (parallel over candidates): numbers + join of the mark names ------------------------
+    g->cand_pos.assign(C, 0); g->cand_svlen.assign(C, 0); g->cand_svread.assign(C, 0); g->cand_refread.assign(C, 0);
+    g->cand_gt_ok.assign(C, 0); g->cand_plus.assign(C, 0);
+    g->c_chrom.assign(C, Span{nullptr, 0}); g->c_ref.assign(C, Span{nullptr, 0}); g->c_alt.assign(C, Span{nullptr, 0});
+    g->c_type.assign(C, Span{nullptr, 0});
+    std::vector<uint32_t> deg(C, 0);
+    struct PartB { std::vector<uint32_t> marks; std::string why; };
+    int TB = C < 4096 ? 1 : T;
+    std::vector<PartB> pb(TB);
+    auto work_b = [&](int t) {
+        PartB &o = pb[t];
+        const size_t lo = C * t / TB, hi = C * (t + 1) / TB;
+        int k = 0;
+        for (size_t c = lo; c < hi; ++c) {
+            while (c >= g->cand_ctg_off[k + 1]) ++k;
+            const Layout &ly = layout[k];
             const NameTable &tab = g->tables[k];
             const uint32_t rbase = g->read_off[k];
-            for (const Rec &r : recs) {
-                long long v;
-                if (!py_int(r.tok[1].p, r.tok[1].n, v) || v < 0 || v > 0xFFFFFFFFLL) return unsupported(g, "POS");
-                g->cand_pos.push_back((uint32_t)v);
-                // SVLEN: first item containing 'SVLEN='; missing or exactly 'SVLEN=.' -> 0; '>' anywhere -> skip 7
-                long long svlen = 0;
-                if (first_item_with(r.tok[7], kLen, 1, it) && !(it.n == 7 && memcmp(it.p, "SVLEN=.", 7) == 0)) {
-                    const size_t cut = memchr(it.p, '>', it.n) ? 7 : 6;
-                    if (it.n < cut || !py_int(it.p + cut, it.n - cut, svlen)) return unsupported(g, "SVLEN");
-                }
-                if (svlen < 0) svlen = -svlen;
-                if (svlen > 0xFFFFFFFFLL) return unsupported(g, "SVLEN range");
-                g->cand_svlen.push_back((uint32_t)svlen);
-                if (!first_item_with(r.tok[7], kType, 1, it) || it.n < 7) return unsupported(g, "SVTYPE");
-                const Span ty{it.p + 7, it.n - 7};
-                g->c_type.push_back(ty);
-                g->cand_plus.push_back((ty.n == 3 && (memcmp(ty.p, "INS", 3) == 0 || memcmp(ty.p, "DUP", 3) == 0)) ? 1 : 0);
-                if (!first_item_with(r.tok[7], kSupp, 3, it) || it.n < supp_cut ||
-                    !py_int(it.p + supp_cut, it.n - supp_cut, v) || v < 0 || v > 0xFFFFFFFFLL)
-                    return unsupported(g, "support count");
-                g->cand_svread.push_back((uint32_t)v);
-                if (!first_item_with(r.tok[7], kNames, 2, it) || it.n < rn_cut) return unsupported(g, "read names");
-                {   // ','.split keeps empty names
-                    const char *s = it.p + rn_cut;
-                    const size_t sn = it.n - rn_cut;
-                    size_t i = 0;
-                    for (;;) {
+            const Rec &r = *recs[c];
+            long long v;
+            if (!py_int(r.tok[1].p, r.tok[1].n, v) || v < 0 || v > 0xFFFFFFFFLL) { o.why = "POS"; return; }
+            g->cand_pos[c] = (uint32_t)v;
+            InfoHits h;
+            scan_info(r.tok[7], h);
+            // SVLEN: missing or exactly 'SVLEN=.' -> 0; '>' anywhere in the item -> skip 7 characters (Q20)
+            long long svlen = 0;
+            if (h.svlen.p && !(h.svlen.n == 7 && memcmp(h.svlen.p, "SVLEN=.", 7) == 0)) {
+                const size_t cut = memchr(h.svlen.p, '>', h.svlen.n) ? 7 : 6;
+                if (h.svlen.n < cut || !py_int(h.svlen.p + cut, h.svlen.n - cut, svlen)) { o.why = "SVLEN"; return; }
+            }
+            if (svlen < 0) svlen = -svlen;
+            if (svlen > 0xFFFFFFFFLL) { o.why = "SVLEN range"; return; }
+            g->cand_svlen[c] = (uint32_t)svlen;
+            if (!h.svtype.p || h.svtype.n < 7) { o.why = "SVTYPE"; return; }
+            const Span ty{h.svtype.p + 7, h.svtype.n - 7};
+            g->c_type[c] = ty;
+            g->cand_plus[c] = (ty.n == 3 && (memcmp(ty.p, "INS", 3) == 0 || memcmp(ty.p, "DUP", 3) == 0)) ? 1 : 0;
+            if (!h.supp.p || h.supp.n < ly.supp_cut || !py_int(h.supp.p + ly.supp_cut, h.supp.n - ly.supp_cut, v) ||
+                v < 0 || v > 0xFFFFFFFFLL) { o.why = "support count"; return; }
+            g->cand_svread[c] = (uint32_t)v;
+            if (!h.names.p || h.names.n < ly.rn_cut) { o.why = "read names"; return; }
+            {   // ','.split keeps empty names.  Lookups go in batches of 32: hash + prefetch the slots, prefetch the
+                // matching arena entries, then compare -- the join is cache-miss bound, not compute bound.
+                const char *s = h.names.p + ly.rn_cut;
+                const size_t sn = h.names.n - ly.rn_cut;
+                size_t i = 0;
+                uint32_t cnt = 0;
+                bool more = true;
+                while (more) {
+                    Span nm[32];
+                    uint64_t hh[32];
+                    int nb = 0;
+                    while (nb < 32) {
                         size_t j = i;
                         while (j < sn && s[j] != ',') ++j;
-                        const int idx = tab.find(s + i, j - i);
-                        g->mark_read.push_back(idx < 0 ? kAbsent : rbase + (uint32_t)idx);
-                        if (j >= sn) break;
+                        nm[nb] = Span{s + i, j - i};
+                        hh[nb] = NameTable::hash(s + i, j - i);
+                        tab.prefetch_slot(hh[nb]);
+                        ++nb;
+                        if (j >= sn) { more = false; break; }
                         i = j + 1;
                     }
-                }
-                if (g->mark_read.size() > 0xFFFFFFF0ull) return unsupported(g, "too many marks");
-                g->cand_off.push_back((uint32_t)g->mark_read.size());
-                // sample column
-                const Span s = r.tok[9];
-                std::vector<Span> sub;
-                {
-                    size_t i = 0;
-                    for (;;) {
-                        size_t j = i;
-                        while (j < s.n && s.p[j] != ':') ++j;
-                        sub.push_back(Span{s.p + i, j - i});
-                        if (j >= s.n) break;
-                        i = j + 1;
+                    for (int q = 0; q < nb; ++q) tab.prefetch_entry(hh[q]);
+                    for (int q = 0; q < nb; ++q) {
+                        const int idx = tab.find_hashed(nm[q].p, nm[q].n, hh[q]);
+                        o.marks.push_back(idx < 0 ? kAbsent : rbase + (uint32_t)idx);
                     }
+                    cnt += (uint32_t)nb;
                 }
-                g->cand_gt_ok.push_back((sub[0].n == 3 && memcmp(sub[0].p, "./.", 3) == 0) ? 0 : 1);
-                auto opt_int = [&](Span x, long long &o) {
-                    if (x.n == 1 && x.p[0] == '.') { o = 0; return true; }
-                    return py_int(x.p, x.n, o);
+                deg[c] = cnt;
+            }
+            // sample column: up to the first three ':' fields and the last one
+            const Span s = r.tok[9];
+            Span sub[3] = {{nullptr, 0}, {nullptr, 0}, {nullptr, 0}}, lastf{nullptr, 0};
+            {
+                size_t i = 0;
+                int f = 0;
+                for (;;) {
+                    size_t j = i;
+                    while (j < s.n && s.p[j] != ':') ++j;
+                    if (f < 3) sub[f] = Span{s.p + i, j - i};
+                    lastf = Span{s.p + i, j - i};
+                    ++f;
+                    if (j >= s.n) break;
+                    i = j + 1;
+                }
+                g->cand_gt_ok[c] = (sub[0].n == 3 && memcmp(sub[0].p, "./.", 3) == 0) ? 0 : 1;
+                auto opt_int = [&](Span x, long long &out) {
+                    if (x.n == 1 && x.p[0] == '.') { out = 0; return true; }
+                    return py_int(x.p, x.n, out);
                 };
                 long long ref = 0, other = 0;
-                if (fmt_kind == 2) {
-                    const Span l = sub.back();
-                    const char *c = (const char *)memchr(l.p, ',', l.n);
-                    // upstream: k = find(','); with k == -1 it slices [: -1] / [0:] -- leave that to the Python path
-                    if (!c) return unsupported(g, "AD without a comma");
-                    if (!opt_int(Span{l.p, (size_t)(c - l.p)}, ref) || !opt_int(Span{c + 1, l.n - (size_t)(c - l.p) - 1}, other))
-                        return unsupported(g, "AD");
+                if (ly.fmt_kind == 2) {
+                    const char *cm = (const char *)memchr(lastf.p, ',', lastf.n);
+                    // upstream: k = find(','); with k == -1 it slices [:-1] / [0:] -- left to the Python path
+                    if (!cm) { o.why = "AD without a comma"; return; }
+                    if (!opt_int(Span{lastf.p, (size_t)(cm - lastf.p)}, ref) ||
+                        !opt_int(Span{cm + 1, lastf.n - (size_t)(cm - lastf.p) - 1}, other)) { o.why = "AD"; return; }
                 } else {
-                    if (sub.size() < 3 || !opt_int(sub[1], ref) || !opt_int(sub[2], other)) return unsupported(g, "sample counts");
+                    if (f < 3 || !opt_int(sub[1], ref) || !opt_int(sub[2], other)) { o.why = "sample counts"; return; }
                 }
-                if (ref < 0 || ref > 0xFFFFFFFFLL) return unsupported(g, "reference-read count range");
-                g->cand_refread.push_back((uint32_t)ref);
-                g->c_chrom.push_back(r.tok[0]);
-                g->c_ref.push_back(r.tok[3]);
-                g->c_alt.push_back(r.tok[4]);
+                if (ref < 0 || ref > 0xFFFFFFFFLL) { o.why = "reference-read count range"; return; }
+                g->cand_refread[c] = (uint32_t)ref;
             }
+            g->c_chrom[c] = r.tok[0];
+            g->c_ref[c] = r.tok[3];
+            g->c_alt[c] = r.tok[4];
         }
-        g->cand_ctg_off[k + 1] = (uint32_t)g->cand_pos.size();
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < TB; ++t) pool.emplace_back(work_b, t);
+        work_b(0);
+        for (auto &th : pool) th.join();
     }
+    lap("phase B");
+    for (int t = 0; t < TB; ++t)
+        if (!pb[t].why.empty()) return unsupported(g, pb[t].why);
+    g->cand_off.assign(C + 1, 0);
+    uint64_t total = 0;
+    for (size_t c = 0; c < C; ++c) {
+        total += deg[c];
+        if (total > 0xFFFFFFF0ull) return unsupported(g, "too many marks");
+        g->cand_off[c + 1] = (uint32_t)total;
+    }
+    g->mark_read.resize(total);
+    {
+        size_t at = 0;
+        for (int t = 0; t < TB; ++t) {
+            if (!pb[t].marks.empty()) memcpy(g->mark_read.data() + at, pb[t].marks.data(), pb[t].marks.size() * 4);
+            at += pb[t].marks.size();
+        }
+    }
+    lap("finish");
     g->parsed = true;
     return DUET_INGEST_OK;
 }

@@ -43,7 +43,7 @@ def load():
         lib.duet_ingest_error.restype = ctypes.c_char_p
         lib.duet_ingest_error.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
-        lib.duet_ingest_parse_vcf.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        lib.duet_ingest_parse_vcf.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         lib.duet_ingest_get_arrays.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestArrays)]
         lib.duet_ingest_emit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
@@ -89,7 +89,7 @@ class NativeIngest(object):
                     if lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) != OK:
                         return decline()
                     break
-        if lib.duet_ingest_parse_vcf(h, vcf_path.encode()) != OK:
+        if lib.duet_ingest_parse_vcf(h, vcf_path.encode(), int(thread)) != OK:
             return decline()
         a = IngestArrays()
         if lib.duet_ingest_get_arrays(h, ctypes.byref(a)) != OK:

@@ -48,8 +48,8 @@ const char *duet_ingest_error(const duet_ingest *ing);
 /* Tag dict of contig k from a BAM file (built-in BGZF/BAM reader, `threads` inflate workers). */
 int duet_ingest_add_bam(duet_ingest *ing, int contig, const char *bam_path, int threads);
 
-/* Parse the caller VCF and join its mark names against the tag dicts added so far. */
-int duet_ingest_parse_vcf(duet_ingest *ing, const char *vcf_path);
+/* Parse the caller VCF (`threads` workers) and join its mark names against the tag dicts added so far. */
+int duet_ingest_parse_vcf(duet_ingest *ing, const char *vcf_path, int threads);
 int duet_ingest_get_arrays(const duet_ingest *ing, duet_ingest_arrays *out);
 
 /* Text of phased_sv.vcf: header (write_file.py:19-45; include_all_ctgs selects which ##contig lines are
