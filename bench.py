@@ -258,6 +258,7 @@ def main():
         if world == 1 and not args.no_extra:
             out['extra'] = extra_points(ctx, torch, engine, synth, DeviceProblem, args.large)
             out['extra']['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
+            out['extra']['three_timed_regions_config2'] = abi_and_e2e(ctx, soa, contig, float(iso.total_ms))
         print(json.dumps(out))
         sys.stdout.flush()
 
@@ -265,6 +266,38 @@ def main():
         dist_mod.barrier()
         dist_mod.destroy_process_group()
     ctx.close()
+
+
+def abi_and_e2e(ctx, soa, contig, kernels_ms):
+    """SURVEY 8d asks for three timed regions: kernels only, the C-ABI call on host arrays (H2D + kernels + D2H),
+    and end to end (caller VCF + haplotagged BAM on disk -> phased_sv.vcf on disk, native host path, -t 4)."""
+    import shutil
+    import tempfile
+    from duet_amd import synth
+    from duet_amd.sv_phasing import sv_phasing
+    ctx.run_host(soa, 50, 2)
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        ctx.run_host(soa, 50, 2)
+    t_abi = (time.perf_counter() - t0) / reps
+    home = tempfile.mkdtemp(prefix='duet_e2e_')
+    try:
+        synth.write_workdir(home, [contig], dialect='cutesv', seed=1, write_sam=False)
+        sv_phasing(home, 50, 2, 4, False)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sv_phasing(home, 50, 2, 4, False)
+        t_e2e = (time.perf_counter() - t0) / 3
+        size = os.path.getsize(os.path.join(home, 'phased_sv.vcf'))
+    finally:
+        shutil.rmtree(home, ignore_errors=True)
+    M = soa.n_marks
+    return {'t_kernels_ms': kernels_ms, 'marks_per_s_kernels': M / (kernels_ms * 1e-3) if kernels_ms else None,
+            't_abi_ms': t_abi * 1e3, 'marks_per_s_abi': M / t_abi,
+            't_e2e_ms': t_e2e * 1e3, 'marks_per_s_e2e': M / t_e2e, 'phased_sv_vcf_bytes': size,
+            'note': 't_abi = duet_ef_run_host on pageable host arrays (PCIe both ways); t_e2e = duet_amd.sv_phasing.sv_phasing '
+                    'with the native ingest (libduet_ingest.so), 4 host threads, files in the page cache'}
 
 
 def cluster_point(ctx, torch, synth, contigs):
