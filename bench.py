@@ -60,7 +60,7 @@ def cpu_baseline(soa, budget_s=10.0):
     t0 = time.perf_counter()
     c_oracle.ef(soa, 50, 2)
     one = time.perf_counter() - t0
-    reps = max(1, min(200, int(budget_s / max(one, 1e-4))))
+    reps = max(1, min(2000, int(budget_s / max(one, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(reps):
         c_oracle.ef(soa, 50, 2)

@@ -1,0 +1,42 @@
+# coding=utf-8
+"""The `duet` command: BAM REFERENCE OUTPUT [-t -m -c -s -r -a -b] as upstream (src/duet/duet:14-28), one additive
+flag (--device).  The pipeline is a table of stages; B, C, D shell out to external tools (duet_amd/stages.py),
+the last one -- SV phasing, steps E/F -- runs on the MI355X."""
+
+import logging
+import os
+import time
+
+from duet_amd import engine, stages
+from duet_amd.sv_phasing import sv_phasing
+from duet_amd.utils import check_envs, parse_args, set_logging
+
+_BAR = '*' * 25
+
+
+def pipeline(a):
+    """(callable, arguments) per stage, in upstream's fixed order: SNP call, SV call, SNP phase, SV phase."""
+    return (
+        (stages.snp_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.min_allele_frequency, a.thread, a.include_all_ctgs)),
+        (stages.sv_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.cluster_max_distance, a.sv_min_size, a.thread, a.sv_caller,
+                             a.min_support_read)),
+        (stages.snp_phasing, (a.OUTPUT, a.REFERENCE, a.BAM, a.thread)),
+        (sv_phasing, (a.OUTPUT, a.sv_min_size, a.min_support_read, a.thread, a.include_all_ctgs)),
+    )
+
+
+def main(argv):
+    a = parse_args(argv)
+    check_envs(a.REFERENCE, a.BAM)
+    os.makedirs(a.OUTPUT, exist_ok=True)
+    set_logging(a.OUTPUT)
+    began = time.time()
+    logging.info(_BAR + ' DUET STARTED ' + _BAR)
+    todo = pipeline(a)
+    for fn, args in todo[:-1]:
+        fn(*args)
+    engine.default_context(a.device)          # fail before the last stage if there is no MI355X / no library
+    fn, args = todo[-1]
+    fn(*args)
+    logging.info('%s DUET FINISHED IN %ss %s' % (_BAR, round(time.time() - began, 3), _BAR))
+    logging.info('OUTPUT .VCF FILE AT ' + a.OUTPUT + '/phased_sv.vcf')

@@ -148,31 +148,31 @@ def evaluation(baseinfo, callinfo, threshold_tp_range, ratio):
 
 
 def parse_args(argv):
-    ap = argparse.ArgumentParser(description='evaluate SV calling, genotyping and phasing performance')
-    ap.add_argument('callset', type=str, help='phased SV callset in .vcf format')
-    ap.add_argument('truthset', type=str, help='phased SV truthset in .vcf format')
+    ap = argparse.ArgumentParser(description='precision / recall / F1 of SV calling, genotyping and phasing against a truth set')
+    ap.add_argument('callset', type=str, help='VCF of phased SV calls to score')
+    ap.add_argument('truthset', type=str, help='VCF of the phased truth set')
     ap.add_argument('-r', '--refdist', type=int, default=1000,
-                    help='maximum distance comparison calls must be within from base call')
+                    help='a call matches a truth call at most this many bp away [%(default)s]')
     ap.add_argument('-p', '--pctsim', type=float, default=0,
-                    help='edit distance ratio between the REF/ALT haplotype sequences of base and comparison call')
-    ap.add_argument('-b', '--bed_file', type=str, help='optional .bed file to confine benchmark regions')
+                    help='minimum shorter/longer SV length ratio for a match [%(default)s]')
+    ap.add_argument('-b', '--bed_file', type=str, help='BED file; only calls inside its regions are scored')
     ap.add_argument('--skip_phasing', action='store_true',
-                    help='only benchmark on SV calling and genotyping [%(default)s]')
+                    help='score calling and genotyping only')
     return ap.parse_args(argv)
 
 
 def main(argv):
     args = parse_args(argv)
-    bed = args.bed_file if args.bed_file else ''
-    res = evaluation(parse_vcf(args.truthset, args.skip_phasing, bed), parse_vcf(args.callset, args.skip_phasing, bed),
-                     args.refdist, args.pctsim)
-    avg, p, r, f1, p_gt, r_gt, f1_gt, p_hp, r_hp, f1_hp = res
+    bed = args.bed_file or ''
+    truth, calls = (parse_vcf(path, args.skip_phasing, bed) for path in (args.truthset, args.callset))
+    res = evaluation(truth, calls, args.refdist, args.pctsim)
+    # upstream's report lines, verbatim (evaluation.py:184-189)
     if not args.skip_phasing:
-        print('Average SV number per phase set is', avg)
-    print('The precision, recall and F1 score of SV calling are', p, r, f1)
-    print('The precision, recall and F1 score of SV genotyping are', p_gt, r_gt, f1_gt)
-    if not args.skip_phasing:
-        print('The precision, recall and F1 score of SV phasing are', p_hp, r_hp, f1_hp)
+        print('Average SV number per phase set is', res[0])
+    for what, at in (('calling', 1), ('genotyping', 4), ('phasing', 7)):
+        if what == 'phasing' and args.skip_phasing:
+            continue
+        print('The precision, recall and F1 score of SV %s are' % what, res[at], res[at + 1], res[at + 2])
 
 
 if __name__ == '__main__':

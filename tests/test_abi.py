@@ -11,8 +11,8 @@ from duet_amd import _lib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    with open(os.path.join(REPO, 'include', 'duet_ef.h')) as f:
+def declared_functions(header='duet_ef.h'):
+    with open(os.path.join(REPO, 'include', header)) as f:
         text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
     return sorted(set(re.findall(r'\b(duet_[a-z_0-9]+)\s*\(', text)))
 
@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.duet_abi_version.restype = ctypes.c_int
     assert lib.duet_abi_version() == 1
+
+
+def test_ingest_library_exports_every_declared_symbol():
+    from duet_amd import native
+    import __graft_entry__
+    __graft_entry__.build()
+    assert declared_functions('duet_ingest.h') == sorted(native.EXPORTS)
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in declared_functions('duet_ingest.h'):
+        assert hasattr(lib, name), name
 
 
 def test_struct_layout_matches_header():
