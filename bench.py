@@ -354,9 +354,13 @@ def extra_points(ctx, torch, engine, synth, DeviceProblem, large):
         dt = (time.perf_counter() - t0) / n
         prof = ctx.profile_collect()
         ctx.set_profiling(0)
+        from oracle import c_oracle
+        pred, ps = dp.results()
+        rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
+        ok = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
         ab = classify_bytes(soa)
         kms = float(prof.kernel_ms[0])
-        pts[name] = {'marks': soa.n_marks, 'candidates': soa.n_cands, 'reads': soa.n_reads,
+        pts[name] = {'parity_vs_oracle': ok, 'marks': soa.n_marks, 'candidates': soa.n_cands, 'reads': soa.n_reads,
                      'contigs': soa.n_contigs, 'ms_per_step': dt * 1e3, 'marks_per_s': soa.n_marks / dt,
                      'kernels_ms': {k: float(prof.kernel_ms[i]) for i, k in enumerate(('ef_classify', 'ef_seed_sort', 'ef_finalize'))},
                      'classify_GBs': ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
