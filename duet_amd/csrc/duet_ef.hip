@@ -53,7 +53,8 @@ constexpr uint8_t kClass2Slow = 16;               // multi-PS candidate without 
 constexpr uint8_t kDivZero = 32;                  // kept candidate with svread + refread == 0
 
 constexpr int kCandPerBlock = 256;
-constexpr int kChunk = 4096;                      // marks staged in LDS per pass (32 KiB of tags)
+constexpr int kChunk = 4096;                      // marks staged in LDS per pass (32 KiB of tags; 2048 was measured: -7 % at 2e7 marks, +38 % at 1e6)
+constexpr int kStageIt = kChunk / (kCandPerBlock * 4);   // 16-byte index loads per thread and pass
 constexpr int kSmallK = 64;
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB)
@@ -203,10 +204,10 @@ struct TileShared {
     uint32_t c2n;                             // summary slots handed out in this tile (reset by the caller)
 };
 
-// decision + outputs + seed entries of one 256-candidate tile.  All 256 threads call it (it synchronises).
-__device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uint32_t tile, uint32_t tid, bool live, uint32_t c,
-                                            bool active, bool divzero, const CandState &st, uint32_t deg,
-                                            uint32_t svread, uint32_t refread, uint32_t is_start)
+// decision + outputs of ONE candidate (the one this thread walked); returns its seed entry or kEmpty
+__device__ __forceinline__ uint32_t decide_store(const Params &p, TileShared &sh, uint32_t tile, bool live, uint32_t c,
+                                                 bool active, bool divzero, const CandState &st, uint32_t deg,
+                                                 uint32_t svread, uint32_t refread)
 {
     uint8_t code = 0;
     uint32_t ps_out = 0;
@@ -250,18 +251,23 @@ __device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uin
         p.out_pred[c] = code;
         p.out_ps[c] = ps_out;
     }
-
-    // ---- seeds of this tile, compacted.  A seed equal to the seed of the previous seed-bearing
-    // candidate is dropped, unless a contig starts in between (seed sets are per contig).  Only the
-    // set matters downstream, so dropping duplicates early just shortens ef_seed_sort's input.
     if (p.dbg & 1) want_seed = false;
-    const uint32_t seed = st.seed();
+    return want_seed ? st.seed() : kEmpty;
+}
+
+// Seed entries of one tile, in candidate order (thread t speaks for candidate c0 + t; sh.seed[] must hold every
+// candidate's seed or kEmpty and be visible).  A seed equal to the seed of the previous seed-bearing candidate is
+// dropped, unless a contig starts in between (seed sets are per contig).  Only the set matters downstream, so
+// dropping duplicates early just shortens ef_seed_sort's input.  All 256 threads call it (it synchronises).
+__device__ __forceinline__ void seeds_tile(const Params &p, TileShared &sh, uint32_t tile, uint32_t tid, uint32_t c,
+                                           uint32_t is_start)
+{
+    const uint32_t seed = sh.seed[tid];
+    const bool want_seed = seed != kEmpty;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const unsigned long long wmask = __ballot(want_seed);
     const unsigned long long smask = __ballot(is_start != 0);
     const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);    // lanes 0..lane
-    sh.seed[tid] = want_seed ? seed : kEmpty;
-    __syncthreads();
     if (lane == 0) {
         if (wmask) {
             const uint32_t li = 63u - (uint32_t)__clzll(wmask);
@@ -304,16 +310,16 @@ __device__ __forceinline__ void finish_tile(const Params &p, TileShared &sh, uin
     if (tid == 0) p.blk_rec[(size_t)tile * 4] = total;
 }
 
-// ---- staging pieces: 16 marks per thread and pass, 4 x (16-byte index load -> 4 tag gathers) ----------
+// ---- staging pieces: 4 * kStageIt marks per thread and pass, kStageIt x (16-byte index load -> 4 tag gathers) ----
 // Index loads are branch-free and their values are not touched here: a conditional load, or any use of the
 // loaded registers, makes the compiler wait on the spot, which would serialise the four loads and break the
 // software pipeline.  The mark array is 16-byte aligned on this path, so an aligned 16-byte load that starts
 // inside it stays inside its last 16-byte granule even when M is not a multiple of 4; lanes past m_end read
 // a harmless in-range address.  stage_gather masks both cases when it finally consumes the indices.
-__device__ __forceinline__ void stage_load_marks(const Params &p, uint4 (&r)[4], uint32_t cs, uint32_t m_end, uint32_t tid)
+__device__ __forceinline__ void stage_load_marks(const Params &p, uint4 (&r)[kStageIt], uint32_t cs, uint32_t m_end, uint32_t tid)
 {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < kStageIt; ++it) {
         const uint32_t m = cs + 4u * (tid + it * kCandPerBlock);
         r[it] = *reinterpret_cast<const uint4 *>(p.mark_read + (m < m_end ? m : cs));
     }
@@ -322,12 +328,12 @@ __device__ __forceinline__ void stage_load_marks(const Params &p, uint4 (&r)[4],
 // Tag gathers, branch-free for the same reason: absent / out-of-range marks read entry 0 (the host makes sure
 // read_tag always points at >= 1 readable word) and `valid` remembers which of the 16 are real; stage_store
 // substitutes the "untagged" word when the values are finally consumed.
-__device__ __forceinline__ void stage_gather(const Params &p, uint64_t (&t)[16], uint32_t &valid, const uint4 (&r)[4],
+__device__ __forceinline__ void stage_gather(const Params &p, uint64_t (&t)[4 * kStageIt], uint32_t &valid, const uint4 (&r)[kStageIt],
                                              uint32_t cs, uint32_t m_end, uint32_t tid)
 {
     valid = 0;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < kStageIt; ++it) {
         const uint32_t m = cs + 4u * (tid + it * kCandPerBlock);
         const bool in = m < m_end;
         const uint32_t idx[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
@@ -340,11 +346,11 @@ __device__ __forceinline__ void stage_gather(const Params &p, uint64_t (&t)[16],
     }
 }
 
-__device__ __forceinline__ void stage_store(uint64_t *s_tag, const uint64_t (&t)[16], uint32_t valid, uint32_t cs,
+__device__ __forceinline__ void stage_store(uint64_t *s_tag, const uint64_t (&t)[4 * kStageIt], uint32_t valid, uint32_t cs,
                                             uint32_t m_end, uint32_t tid)
 {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < kStageIt; ++it) {
         const uint32_t i = 4u * (tid + it * kCandPerBlock);
         if (cs + i < m_end) {
 #pragma unroll
@@ -371,32 +377,36 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
     for (uint32_t i = tid; i <= nc; i += kCandPerBlock) s_off[i] = p.cand_off[c0 + i];
     if (tid == 0) sh.c2n = 0;
 
-    // candidate scalars, coalesced
-    const bool live = tid < nc;
-    const uint32_t c = c0 + tid;
+    // candidate scalars, coalesced (candidate c0 + tid)
     uint32_t svlen = 0, svread = 0, refread = 0, gt_ok = 0, is_start = 0;
-    if (live) {
-        svlen = p.cand_svlen[c];
-        svread = p.cand_svread[c];
-        refread = p.cand_refread[c];
-        gt_ok = p.cand_gt_ok[c];
-        is_start = p.ctg_start[c];
+    if (tid < nc) {
+        svlen = p.cand_svlen[c0 + tid];
+        svread = p.cand_svread[c0 + tid];
+        refread = p.cand_refread[c0 + tid];
+        gt_ok = p.cand_gt_ok[c0 + tid];
+        is_start = p.ctg_start[c0 + tid];
     }
-    const bool kept = live && svlen >= p.svlen_thres && svread >= p.suppread_thres && gt_ok != 0;   // :189-190
+    const bool kept = tid < nc && svlen >= p.svlen_thres && svread >= p.suppread_thres && gt_ok != 0;     // :189-190
     const bool divzero = kept && ((uint64_t)svread + (uint64_t)refread == 0);
-    const bool active = kept && !divzero;
     __syncthreads();
     STAMP(0, 1);
     const uint32_t m_begin = s_off[0], m_end = s_off[nc];
-    const uint32_t my_b = live ? s_off[tid] : 0, my_e = live ? s_off[tid + 1] : 0;
+
+    // thread t walks candidate c0 + t.  (Dealing a tile's candidates to lanes in descending order of their mark
+    // count -- so that the four waves loop 18/14/10/6 times instead of 4 x 18 -- was measured and is NOT faster: a
+    // workgroup holds its LDS until its slowest wave is done, and that wave still loops 18 times.)
+    const uint32_t j = tid;
+    const bool live = j < nc;
+    const bool active = kept && !divzero;
+    const uint32_t my_b = live ? s_off[j] : 0, my_e = live ? s_off[j + 1] : 0;
     CandState st;
 
     const uint32_t base = VEC ? (m_begin & ~3u) : m_begin;
     for (uint32_t cs = base; cs < m_end; cs += kChunk) {
         // ---- stage: LDS[i] = tag of mark cs+i -----------------------------------------------
         if (VEC) {
-            uint4 r[4];
-            uint64_t t[16];
+            uint4 r[kStageIt];
+            uint64_t t[4 * kStageIt];
             uint32_t valid;
             stage_load_marks(p, r, cs, m_end, tid);
             stage_gather(p, t, valid, r, cs, m_end, tid);
@@ -418,7 +428,10 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         __syncthreads();
     }
     STAMP(0, 4);
-    finish_tile(p, sh, blockIdx.x, tid, live, c, active, divzero, st, my_e - my_b, svread, refread, is_start);
+    const uint32_t seed = decide_store(p, sh, blockIdx.x, live, c0 + j, active, divzero, st, my_e - my_b, svread, refread);
+    sh.seed[j] = seed;
+    __syncthreads();
+    seeds_tile(p, sh, blockIdx.x, tid, c0 + tid, is_start);
     STAMP(0, 6);
 }
 
