@@ -11,8 +11,8 @@
 //                  on the data path, so the order is deterministic)
 //   cl_heads1/2    partition starts: contig/type change, centre gap > part_gap, or part_max marks reached
 //   cl_parts       partition start list (from an exclusive scan of the head flags)
-//   cl_cluster     one wavefront per partition: span-position distances into an LDS triangle (fp64),
-//                  average-linkage agglomeration by repeated wave-wide argmin + Lance-Williams update
+//   cl_cluster     16 / 32 / 64 lanes per partition (one lane for <= 8 marks): span-position distances into an LDS
+//                  triangle (fp64), average linkage by repeated group-wide argmin + Lance-Williams update
 //   cl_emit        per partition: clusters by smallest member, members in sorted order -> order[], cand_*[]
 //
 // Bit-exactness vs the oracle: distances and updates are the same binary64 expressions in the same order
@@ -274,8 +274,8 @@ __global__ void cl_parts(const ClParams p, const uint32_t *flag, const uint32_t 
 
 // work lists by partition size (which agglomeration kernel variant takes it); list order is irrelevant --
 // every partition writes to its own fixed output range -- so a (wave-aggregated) atomic append is fine
-constexpr int kClasses = 4;
-__device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <= 48 ? 2 : 3); }   // class 1 unused
+constexpr int kClasses = 5;
+__device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : 4))); }
 
 __global__ void cl_classes(const ClParams p, uint32_t *lists /* [kClasses][M] */, uint32_t *counts /* [kClasses] */)
 {
@@ -320,102 +320,117 @@ __device__ __forceinline__ void tri_decode(uint32_t q, uint32_t n, uint32_t pair
     j = i + 1 + (q - tri_row_start(i, n));
 }
 
-template <int NMAX>
+// GROUP lanes of a wavefront work on one partition (GROUP = 16 / 32 / 64 for up to 16 / 32 / 128 marks), so a
+// wave carries 4 / 2 / 1 partitions at once and the fixed cost of a merge step (argmin butterfly, decode, two
+// barriers) is shared.  Control flow is wave-uniform; groups that are done (or idle) are predicated off.
+template <int GROUP, int NMAX>
 __global__ __launch_bounds__(64) void cl_cluster(const ClParams p, const uint32_t *list, const uint32_t *count)
 {
+    constexpr int SUBS = 64 / GROUP;
     constexpr int TRI = NMAX * (NMAX - 1) / 2;
-    __shared__ double s_d[TRI];
-    __shared__ uint32_t s_pos[NMAX], s_span[NMAX], s_lab[NMAX], s_size[NMAX];
-    const uint32_t lane = threadIdx.x;
+    __shared__ double s_d[SUBS][TRI];
+    __shared__ uint32_t s_pos[SUBS][NMAX], s_span[SUBS][NMAX], s_lab[SUBS][NMAX], s_size[SUBS][NMAX];
+    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
+    const unsigned long long gmask = GROUP == 64 ? ~0ull : (((1ull << (GROUP & 63)) - 1ull) << (sub * GROUP));
     const uint32_t L = *count;
     const double inf = __builtin_inf();
-    for (uint32_t li = blockIdx.x; li < L; li += gridDim.x) {
-        const uint32_t part = list[li];
-        const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
-        if (n == 1) {
-            if (lane == 0) { p.label[s] = 0; p.pc[part] = 1; }
-            continue;
-        }
+    for (uint32_t base = blockIdx.x * SUBS; base < L; base += gridDim.x * SUBS) {
+        const uint32_t li = base + sub;
+        const bool has = li < L;
+        const uint32_t part = has ? list[li] : 0u;
+        const uint32_t s = has ? p.part_start[part] : 0u;
+        const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
         __syncthreads();
-        for (uint32_t i = lane; i < n; i += 64) {
+        for (uint32_t i = sl; i < n; i += GROUP) {
             const uint32_t a = p.sorted[s + i];
-            s_pos[i] = p.pos[a];
-            s_span[i] = p.span[a];
-            s_lab[i] = i;
-            s_size[i] = 1;
+            s_pos[sub][i] = p.pos[a];
+            s_span[sub][i] = p.span[a];
+            s_lab[sub][i] = i;
+            s_size[sub][i] = 1;
         }
         __syncthreads();
-        const uint32_t pairs = n * (n - 1) / 2;
+        const uint32_t pairs = n ? n * (n - 1) / 2 : 0u;
         // span-position distance of every pair, one pass over the triangle
-        for (uint32_t q = lane; q < pairs; q += 64) {
+        for (uint32_t q = sl; q < pairs; q += GROUP) {
             uint32_t i, j;
             tri_decode(q, n, pairs, i, j);
-            const uint64_t si = s_pos[i], ei = (uint64_t)s_pos[i] + s_span[i], ci = centre_of(s_pos[i], s_span[i]);
-            const uint64_t sj = s_pos[j], ej = (uint64_t)s_pos[j] + s_span[j], cj = centre_of(s_pos[j], s_span[j]);
+            const uint32_t pi = s_pos[sub][i], spi = s_span[sub][i], pj = s_pos[sub][j], spj = s_span[sub][j];
+            const uint64_t si = pi, ei = (uint64_t)pi + spi, ci = centre_of(pi, spi);
+            const uint64_t sj = pj, ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
             uint64_t m = si > sj ? si - sj : sj - si;
             const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
             m = m2 < m ? m2 : m;
             m = m3 < m ? m3 : m;
-            const uint32_t sa = s_span[i], sb = s_span[j];
-            const uint32_t smax = sa > sb ? sa : sb, sdif = sa > sb ? sa - sb : sb - sa;
+            const uint32_t smax = spi > spj ? spi : spj, sdif = spi > spj ? spi - spj : spj - spi;
             const double dp = (double)m / p.normalizer;
             const double ds = smax ? (double)sdif / (double)smax : 0.0;
-            s_d[q] = dp + ds;
+            s_d[sub][q] = dp + ds;
         }
         __syncthreads();
-        // each lane owns a contiguous run of pairs, so lane order is pair order
-        const uint32_t per = (pairs + 63) / 64;
-        const uint32_t q_lo = min(pairs, lane * per), q_hi = min(pairs, q_lo + per);
-        for (uint32_t merges = 0; merges + 1 < n; ++merges) {
-            // wave-wide argmin over the triangle; inactive pairs hold +inf; ties -> smallest pair index
+        // each lane of the group owns a contiguous run of pairs, so lane order is pair order
+        const uint32_t per = (pairs + GROUP - 1) / GROUP;
+        const uint32_t q_lo = min(pairs, sl * per), q_hi = min(pairs, q_lo + per);
+        bool active = n >= 2;
+        uint32_t merges = 0;
+        while (__ballot(active)) {
+            // group-wide argmin over the triangle; inactive pairs hold +inf; ties -> smallest pair index
             double bd = inf;
             uint32_t bq = 0xFFFFFFFFu;
-            for (uint32_t q = q_lo; q < q_hi; ++q) {
-                const double v = s_d[q];
-                if (v < bd) { bd = v; bq = q; }
+            if (active) {
+                for (uint32_t q = q_lo; q < q_hi; ++q) {
+                    const double v = s_d[sub][q];
+                    if (v < bd) { bd = v; bq = q; }
+                }
             }
             double md = bd;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
+            for (int off = GROUP / 2; off > 0; off >>= 1) {
                 const double od = __shfl_xor(md, off, 64);
                 md = od < md ? od : md;
             }
-            if (!(md <= p.max_dist)) break;
-            const unsigned long long tie = __ballot(bd == md);
-            bq = __shfl(bq, __ffsll((long long)tie) - 1, 64);
-            // row a of pair bq
-            uint32_t a, b;
-            tri_decode(bq, n, pairs, a, b);
-            const double na = (double)s_size[a], nb = (double)s_size[b];
-            __syncthreads();
-            for (uint32_t k = lane; k < n; k += 64) {
-                if (k == a || k == b) continue;
-                const uint32_t lo_a = k < a ? k : a, hi_a = k < a ? a : k;
-                const uint32_t lo_b = k < b ? k : b, hi_b = k < b ? b : k;
-                const uint32_t qa = tri_row_start(lo_a, n) + (hi_a - lo_a - 1);
-                const uint32_t qb = tri_row_start(lo_b, n) + (hi_b - lo_b - 1);
-                const double da = s_d[qa], db = s_d[qb];
-                if (da == inf) continue;                       // k already merged away
-                s_d[qa] = (na * da + nb * db) / (na + nb);
-                s_d[qb] = inf;
+            const bool go = active && md <= p.max_dist;
+            const unsigned long long tie = __ballot(go && bd == md) & gmask;
+            bq = __shfl(bq, tie ? __ffsll((long long)tie) - 1 : (int)lane, 64);
+            uint32_t a = 0, b = 0;
+            double na = 0, nb = 0;
+            if (go) {
+                tri_decode(bq, n, pairs, a, b);
+                na = (double)s_size[sub][a];
+                nb = (double)s_size[sub][b];
             }
-            if (lane == 0) {
-                s_d[bq] = inf;
-                s_size[a] += s_size[b];
-            }
-            for (uint32_t k = lane; k < n; k += 64)
-                if (s_lab[k] == b) s_lab[k] = a;
             __syncthreads();
+            if (go) {
+                for (uint32_t k = sl; k < n; k += GROUP) {
+                    if (k == a || k == b) continue;
+                    const uint32_t lo_a = k < a ? k : a, hi_a = k < a ? a : k;
+                    const uint32_t lo_b = k < b ? k : b, hi_b = k < b ? b : k;
+                    const uint32_t qa = tri_row_start(lo_a, n) + (hi_a - lo_a - 1);
+                    const uint32_t qb = tri_row_start(lo_b, n) + (hi_b - lo_b - 1);
+                    const double da = s_d[sub][qa], db = s_d[sub][qb];
+                    if (da == inf) continue;                   // k already merged away
+                    s_d[sub][qa] = (na * da + nb * db) / (na + nb);
+                    s_d[sub][qb] = inf;
+                }
+                if (sl == 0) {
+                    s_d[sub][bq] = inf;
+                    s_size[sub][a] += s_size[sub][b];
+                }
+                for (uint32_t k = sl; k < n; k += GROUP)
+                    if (s_lab[sub][k] == b) s_lab[sub][k] = a;
+            }
+            __syncthreads();
+            ++merges;
+            active = go && merges + 1 < n;
         }
         __syncthreads();
         uint32_t roots = 0;
-        for (uint32_t k = lane; k < n; k += 64) {
-            p.label[s + k] = (uint8_t)s_lab[k];
-            roots += s_lab[k] == k;
+        for (uint32_t k = sl; k < n; k += GROUP) {
+            p.label[s + k] = (uint8_t)s_lab[sub][k];
+            roots += s_lab[sub][k] == k;
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
-        if (lane == 0) p.pc[part] = roots;
+        for (int off = GROUP / 2; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
+        if (has && sl == 0) p.pc[part] = roots;
     }
 }
 
@@ -643,14 +658,18 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     // beside the bulk
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side, ctx->cl_fork, 0));
-    hipLaunchKernelGGL((cl_cluster<128>), dim3(grid < 1024u ? grid : 1024u), dim3(64), 0, ctx->cl_side, p,
-                       (const uint32_t *)(lists + 3 * (size_t)M), (const uint32_t *)(cnts + 3));
+    hipLaunchKernelGGL((cl_cluster<64, 128>), dim3(grid < 1024u ? grid : 1024u), dim3(64), 0, ctx->cl_side, p,
+                       (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
     HIP_TRY(ctx, hipEventRecord(ctx->cl_join, ctx->cl_side));
     const uint32_t g_lane = (M + 63) / 64 < 4096u ? (M + 63) / 64 : 4096u;
     hipLaunchKernelGGL((cl_cluster_small<8>), dim3(g_lane), dim3(64), 0, st, p, (const uint32_t *)lists,
                        (const uint32_t *)(cnts + 0));
-    hipLaunchKernelGGL((cl_cluster<48>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
+    hipLaunchKernelGGL((cl_cluster<16, 16>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
+                       (const uint32_t *)(cnts + 1));
+    hipLaunchKernelGGL((cl_cluster<32, 32>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
                        (const uint32_t *)(cnts + 2));
+    hipLaunchKernelGGL((cl_cluster<64, 48>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
+                       (const uint32_t *)(cnts + 3));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join, 0));
     // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
