@@ -23,7 +23,7 @@ KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
 # every symbol include/duet_ef.h declares (checked by tests/test_abi.py)
 EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
            'duet_ctx_set_profiling', 'duet_ctx_set_debug', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
-           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host')
+           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device')
 
 
 class EfProblem(ctypes.Structure):
@@ -54,6 +54,13 @@ class ClusterResult(ctypes.Structure):
     _fields_ = [('order', ctypes.c_void_p), ('cand_off', ctypes.c_void_p), ('cand_contig', ctypes.c_void_p),
                 ('cand_type', ctypes.c_void_p), ('cand_pos', ctypes.c_void_p), ('cand_span', ctypes.c_void_p),
                 ('n_cands', ctypes.c_void_p)]
+
+
+class SvimProblem(ctypes.Structure):
+    _fields_ = [('marks', ClusterProblem), ('mark_read', ctypes.c_void_p), ('read_tag', ctypes.c_void_p),
+                ('n_reads', ctypes.c_uint32), ('n_contigs', ctypes.c_uint32), ('depth', ctypes.c_void_p),
+                ('depth_off', ctypes.c_void_p), ('depth_bin', ctypes.c_uint32), ('svlen_thres', ctypes.c_uint32),
+                ('suppread_thres', ctypes.c_uint32), ('reserved', ctypes.c_uint32)]
 
 
 class DuetLibraryError(RuntimeError):
@@ -99,6 +106,8 @@ def load():
     lib.duet_cluster_run_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ClusterProblem),
                                             ctypes.POINTER(ClusterResult), ctypes.c_void_p]
     lib.duet_cluster_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ClusterProblem), ctypes.POINTER(ClusterResult)]
+    lib.duet_svim_phase_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(SvimProblem), ctypes.POINTER(ClusterResult),
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
     _lib = lib
     return lib
 

@@ -558,6 +558,50 @@ __global__ __launch_bounds__(64) void cl_emit(const ClParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused SVIM-mode pipeline: clusters -> the arrays ef_classify reads
+// ---------------------------------------------------------------------------------------------
+
+// ctg_off[k] = first candidate whose contig is >= k (candidates are sorted by contig); ctg_off[K] = N
+__global__ void sv_contig_offsets(const uint16_t *cand_contig, const uint32_t *n_cands, uint32_t K, uint32_t *ctg_off)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > K) return;
+    const uint32_t N = *n_cands;
+    uint32_t lo = 0, hi = N;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (cand_contig[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    ctg_off[k] = k == K ? N : lo;
+}
+
+__global__ void sv_adapt_cands(uint32_t N, const uint32_t *cand_off, const uint16_t *cand_contig, const uint32_t *cand_pos,
+                               const uint32_t *depth, const uint32_t *depth_off_dev, uint32_t depth_bin,
+                               uint32_t *svread, uint32_t *refread, uint8_t *gt_ok)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const uint32_t support = cand_off[c + 1] - cand_off[c];
+    const uint32_t k = cand_contig[c];
+    const uint32_t nb = depth_off_dev[k + 1] - depth_off_dev[k];
+    uint32_t d = 0;
+    if (nb) {
+        uint32_t bin = cand_pos[c] / depth_bin;
+        bin = bin < nb ? bin : nb - 1;
+        d = depth[depth_off_dev[k] + bin];
+    }
+    svread[c] = support;
+    refread[c] = d > support ? d - support : 0u;
+    gt_ok[c] = 1;
+}
+
+__global__ void sv_adapt_marks(uint32_t M, const uint32_t *order, const uint32_t *raw_mark_read, uint32_t *mark_read)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) mark_read[m] = raw_mark_read[order[m]];
+}
+
 uint32_t bits_for(uint64_t max_value)
 {
     uint32_t b = 0;
@@ -730,6 +774,54 @@ int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *pr, const d
     HIP_TRY(ctx, hipMemcpy(res->cand_pos, r.cand_pos, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(res->cand_span, r.cand_span, (size_t)n * 4, hipMemcpyDeviceToHost));
     return DUET_OK;
+}
+
+int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const duet_cluster_result *res, uint8_t *out_pred,
+                           uint32_t *out_ps, uint32_t *n_cands_host, void *stream_)
+{
+    if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
+    if (!pr || !res || !out_pred || !out_ps || !n_cands_host) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
+    if (!pr->depth_off || pr->depth_bin == 0 || pr->n_contigs == 0 || pr->n_contigs > 65535)
+        return duet_fail(ctx, DUET_ERR_INVALID, "bad depth / contig description");
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t M = pr->marks.n_marks, K = pr->n_contigs;
+    *n_cands_host = 0;
+    if (M == 0) return DUET_OK;
+    int rc = duet_cluster_run_device(ctx, &pr->marks, res, st);
+    if (rc) return rc;
+    // workspace: ctg_off (device + host), adapted candidate columns, gathered marks, device depth_off
+    const size_t sz[6] = {((size_t)K + 1) * 4 * 2, (size_t)M * 4, (size_t)M * 4, (size_t)M, (size_t)M * 4, 0};
+    for (int i = 0; i < 5; ++i)
+        if ((rc = duet_reserve(ctx, ctx->sv_ws[i], sz[i]))) return rc;
+    uint32_t *d_ctg_off = (uint32_t *)ctx->sv_ws[0].ptr, *d_depth_off = d_ctg_off + (K + 1);
+    uint32_t *d_svread = (uint32_t *)ctx->sv_ws[1].ptr, *d_refread = (uint32_t *)ctx->sv_ws[2].ptr;
+    uint8_t *d_gt = (uint8_t *)ctx->sv_ws[3].ptr;
+    uint32_t *d_mark = (uint32_t *)ctx->sv_ws[4].ptr;
+    HIP_TRY(ctx, hipMemcpyAsync(d_depth_off, pr->depth_off, ((size_t)K + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(sv_contig_offsets, dim3((K + 1 + 255) / 256), dim3(256), 0, st, (const uint16_t *)res->cand_contig,
+                       (const uint32_t *)res->n_cands, K, d_ctg_off);
+    std::vector<uint32_t> ctg_off(K + 1);
+    HIP_TRY(ctx, hipMemcpyAsync(ctg_off.data(), d_ctg_off, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));             // the one host round trip: candidates per contig
+    const uint32_t N = ctg_off[K];
+    *n_cands_host = N;
+    if (N == 0) return DUET_OK;
+    hipLaunchKernelGGL(sv_adapt_cands, dim3((N + 255) / 256), dim3(256), 0, st, N, (const uint32_t *)res->cand_off,
+                       (const uint16_t *)res->cand_contig, (const uint32_t *)res->cand_pos, pr->depth,
+                       (const uint32_t *)d_depth_off, pr->depth_bin, d_svread, d_refread, d_gt);
+    hipLaunchKernelGGL(sv_adapt_marks, dim3((M + 255) / 256), dim3(256), 0, st, M, (const uint32_t *)res->order,
+                       pr->mark_read, d_mark);
+    HIP_TRY(ctx, hipGetLastError());
+    duet_ef_problem ef;
+    memset(&ef, 0, sizeof(ef));
+    ef.n_contigs = K; ef.n_cands = N; ef.n_marks = M; ef.n_reads = pr->n_reads;
+    ef.cand_ctg_off = ctg_off.data();
+    ef.read_tag = pr->read_tag;
+    ef.cand_pos = res->cand_pos; ef.cand_svlen = res->cand_span; ef.cand_svread = d_svread; ef.cand_refread = d_refread;
+    ef.cand_gt_ok = d_gt; ef.cand_off = res->cand_off; ef.mark_read = d_mark;
+    ef.svlen_thres = pr->svlen_thres; ef.suppread_thres = pr->suppread_thres;
+    return duet_ef_run_device(ctx, &ef, out_pred, out_ps, st);
 }
 
 }  // extern "C"

@@ -947,6 +947,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf &b : ctx->cl_ws) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->cl_in) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->cl_out) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->sv_ws) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->cl_side) (void)hipStreamDestroy(ctx->cl_side);
     if (ctx->cl_fork) (void)hipEventDestroy(ctx->cl_fork);

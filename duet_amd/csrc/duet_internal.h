@@ -34,6 +34,7 @@ struct duet_ctx {
     DevBuf h_in[9], h_out[2];
     // clustering (A0) workspace and host-run staging
     DevBuf cl_ws[14], cl_in[4], cl_out[6];
+    DevBuf sv_ws[5];                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side = nullptr;         // side stream + fork/join events for the large-partition kernel
     hipEvent_t cl_fork = nullptr, cl_join = nullptr;
     // profiling events: 6 per run

@@ -104,3 +104,59 @@ class DeviceCluster(object):
 
     def n_cands(self):
         return int(self.keep['out_n_cands'][:4].cpu().numpy().view(np.uint32)[0])
+
+
+class DeviceSvim(DeviceCluster):
+    """Fused SVIM-mode pipeline on resident inputs: raw marks (+ their read indices), read tags, binned depth."""
+
+    def __init__(self, marks, read_tag, depth, depth_off, depth_bin=1000, svlen_thres=50, suppread_thres=2,
+                 max_dist=0.9, device='cuda:0'):
+        DeviceCluster.__init__(self, marks, max_dist=max_dist, device=device)
+        torch = self.torch
+
+        def up(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            t = torch.zeros(a.nbytes + 64, dtype=torch.uint8, device=self.device)
+            if a.nbytes:
+                t[:a.nbytes] = torch.from_numpy(np.frombuffer(a.tobytes(), dtype=np.uint8).copy()).to(self.device)
+            return t
+
+        self.keep['sv_read'] = up(marks['read'], np.uint32)
+        self.keep['sv_tag'] = up(read_tag, np.uint64)
+        self.keep['sv_depth'] = up(depth, np.uint32)
+        self.depth_off = np.ascontiguousarray(depth_off, dtype=np.uint32)
+        p = _lib.SvimProblem()
+        p.marks = self.problem
+        p.mark_read = self.keep['sv_read'].data_ptr()
+        p.read_tag = self.keep['sv_tag'].data_ptr()
+        p.n_reads = len(read_tag)
+        p.n_contigs = len(self.depth_off) - 1
+        p.depth = self.keep['sv_depth'].data_ptr()
+        p.depth_off = self.depth_off.ctypes.data
+        p.depth_bin, p.svlen_thres, p.suppread_thres = int(depth_bin), int(svlen_thres), int(suppread_thres)
+        self.sv_problem = p
+        self.out_pred = torch.zeros(self.M + 64, dtype=torch.uint8, device=self.device)
+        self.out_ps = torch.zeros(self.M + 16, dtype=torch.int32, device=self.device)
+        self.n_found = 0
+
+    def run_fused(self, ctx, stream=None):
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        ct = self._ct
+        n = ct.c_uint32(0)
+        rc = ctx.lib.duet_svim_phase_device(ctx.handle, ct.byref(self.sv_problem), ct.byref(self.result),
+                                            ct.c_void_p(self.out_pred.data_ptr()), ct.c_void_p(self.out_ps.data_ptr()),
+                                            ct.byref(n), ct.c_void_p(stream))
+        if rc:
+            ctx._raise(rc)
+        self.n_found = n.value
+        return stream
+
+    def fetch(self):
+        """-> dict of the cluster arrays + pred/ps, trimmed to the candidate count (synchronises)."""
+        N, M = self.n_found, self.M
+        g = lambda key, dt, n: self.keep['out_' + key][:n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
+        return dict(order=g('order', np.uint32, M), cand_off=g('cand_off', np.uint32, N + 1),
+                    cand_contig=g('cand_contig', np.uint16, N), cand_type=g('cand_type', np.uint8, N),
+                    cand_pos=g('cand_pos', np.uint32, N), cand_span=g('cand_span', np.uint32, N),
+                    pred=self.out_pred[:N].cpu().numpy(), ps=self.out_ps[:N].cpu().numpy().view(np.uint32))

@@ -236,11 +236,13 @@ def bench_genome(n_marks_target, seed, labels=None, reads_per_mark=0.2, mean_deg
 MARK_TYPES = {'DEL': 0, 'INS': 1, 'INV': 2, 'DUP': 3}
 
 
-def raw_marks(contigs, seed, pos_jitter=40, span_jitter_pct=6, shuffle=True):
+def raw_marks(contigs, seed, pos_jitter=40, span_jitter_pct=6, shuffle=True, reads_of=None):
     """Raw SV marks (signatures) for the A0 clustering stage: every support-read mark of every candidate
     becomes one (contig, type, pos, span) record near its candidate -- pos +- pos_jitter, span within
     +- span_jitter_pct % of the candidate's |SVLEN| -- in shuffled order (a BAM scan emits them read by read).
-    -> dict(contig u16[M], type u8[M], pos u32[M], span u32[M], truth int64[M] (global candidate index))"""
+    -> dict(contig u16[M], type u8[M], pos u32[M], span u32[M], truth int64[M] (global candidate index)
+            [, read u32[M] = the mark's index into reads_of.read_tag or 0xFFFFFFFF, when reads_of (an EfSoA built
+            from the same contigs) is given])"""
     rng = SplitMix(0xC1050000 + seed)
     parts = {k: [] for k in ('contig', 'type', 'pos', 'span', 'truth')}
     base = 0
@@ -262,11 +264,28 @@ def raw_marks(contigs, seed, pos_jitter=40, span_jitter_pct=6, shuffle=True):
         parts['truth'].append(cand + base)
         base += len(deg)
     out = {k: np.concatenate(v) if v else np.zeros(0, dtype=np.int64) for k, v in parts.items()}
+    if reads_of is not None:
+        out['read'] = reads_of.mark_read.astype(np.int64)          # same (candidate-major) order as the marks above
     if shuffle and len(out['pos']):
         perm = np.argsort(rng.u64(len(out['pos'])), kind='stable')
         out = {k: v[perm] for k, v in out.items()}
-    return dict(contig=out['contig'].astype(np.uint16), type=out['type'].astype(np.uint8),
-                pos=out['pos'].astype(np.uint32), span=out['span'].astype(np.uint32), truth=out['truth'])
+    res = dict(contig=out['contig'].astype(np.uint16), type=out['type'].astype(np.uint8),
+               pos=out['pos'].astype(np.uint32), span=out['span'].astype(np.uint32), truth=out['truth'])
+    if 'read' in out:
+        res['read'] = out['read'].astype(np.uint32)
+    return res
+
+
+def depth_bins(contigs, bin_width=1000, seed=1):
+    """Synthetic binned coverage for the fused SVIM-mode pipeline: -> (depth u32[total], depth_off int64[K+1])."""
+    rng = SplitMix(0xDE970000 + seed)
+    off = [0]
+    parts = []
+    for c in contigs:
+        nb = c.length // bin_width + 1
+        parts.append(8 + rng.below(nb, 30))
+        off.append(off[-1] + nb)
+    return np.concatenate(parts).astype(np.uint32), np.array(off, dtype=np.int64)
 
 
 # ------------------------------------------------------------------------------------------

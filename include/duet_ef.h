@@ -183,6 +183,38 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *prob, con
                             void *stream);
 int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Fused SVIM-mode pipeline: raw SV marks -> A0 clustering -> E/F phasing, everything resident in HBM, no VCF
+ * round trip.  What upstream obtains from the SVIM VCF per candidate is derived
+ * on the device from the clusters:
+ *     POS      = floor mean of the members' pos          SVLEN   = floor mean of the members' span
+ *     support  = number of member marks (svread)          GT      = called ("not ./.")
+ *     marks    = the members' read indices in cluster order
+ *     refread  = max(depth(contig, POS) - support, 0), depth read from a binned coverage array -- this
+ *                repository's stand-in for SVIM's AD[0] (reads at the locus that do not support the SV);
+ *                like A0 itself it has no pinned reference (svim is external).
+ * Candidates come out grouped by contig, then by (type, centre); out_pred / out_ps are indexed like the
+ * cluster result's candidate arrays.  The call synchronises `stream` once (candidate counts per contig come
+ * back to the host to lay out the E/F workspace).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct duet_svim_problem {
+    duet_cluster_problem marks;     /* device arrays */
+    const uint32_t *mark_read;      /* [M] device: read index of each raw mark (into read_tag) or DUET_MARK_ABSENT */
+    const uint64_t *read_tag;       /* [R] device */
+    uint32_t n_reads;
+    uint32_t n_contigs;             /* K: mark_contig values are < K */
+    const uint32_t *depth;          /* device: coverage bins, contig k at depth_off[k] .. depth_off[k+1] */
+    const uint32_t *depth_off;      /* [K+1] HOST */
+    uint32_t depth_bin;             /* bin width in bp (>= 1) */
+    uint32_t svlen_thres, suppread_thres;
+    uint32_t reserved;
+} duet_svim_problem;
+
+/* res: device arrays as for duet_cluster_run_device (n_cands a device word); out_pred[M], out_ps[M] device;
+ * *n_cands_host receives the candidate count. */
+int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *prob, const duet_cluster_result *res,
+                           uint8_t *out_pred, uint32_t *out_ps, uint32_t *n_cands_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

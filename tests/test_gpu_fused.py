@@ -1,0 +1,51 @@
+# coding=utf-8
+"""-m gpu: the fused SVIM-mode pipeline (raw marks -> A0 clustering -> E/F phasing on the device) against the
+composition of the two C oracles with the adapter rules of include/duet_ef.h restated in numpy."""
+import numpy as np
+import pytest
+
+from duet_amd import _lib, engine, synth
+from duet_amd.devmem import DeviceSvim
+from oracle import c_oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_fused(marks, read_tag, depth, depth_off, depth_bin, svlen_thres, suppread_thres, n_contigs, max_dist=0.9):
+    cl = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], max_dist=max_dist)
+    N = len(cl['cand_pos'])
+    off = cl['cand_off'].astype(np.int64)
+    support = np.diff(off)
+    k = cl['cand_contig'].astype(np.int64)
+    nb = np.diff(depth_off.astype(np.int64))[k]
+    bins = np.minimum(cl['cand_pos'].astype(np.int64) // depth_bin, np.maximum(nb - 1, 0))
+    d = np.where(nb > 0, depth[np.minimum(depth_off[k].astype(np.int64) + bins, len(depth) - 1)], 0).astype(np.int64)
+    soa = engine.EfSoA(cand_ctg_off=np.searchsorted(k, np.arange(n_contigs + 1)), read_tag=read_tag,
+                       cand_pos=cl['cand_pos'], cand_svlen=cl['cand_span'], cand_svread=support,
+                       cand_refread=np.maximum(d - support, 0), cand_gt_ok=np.ones(N, dtype=np.uint8),
+                       cand_off=off, mark_read=marks['read'][cl['order']])
+    rc, pred, ps = c_oracle.ef(soa, svlen_thres, suppread_thres)
+    assert rc == 0
+    return cl, pred, ps
+
+
+@pytest.mark.parametrize('kind,seed', [('chr21', 21), ('genome_small', 3), ('config2', 1)])
+def test_fused_pipeline_matches_oracle_composition(kind, seed):
+    contigs = H.case_contigs(kind, seed)
+    soa = engine.soa_from_synth(contigs)
+    marks = synth.raw_marks(contigs, seed, reads_of=soa)
+    depth, depth_off = synth.depth_bins(contigs, 1000, seed)
+    want_cl, want_pred, want_ps = oracle_fused(marks, soa.read_tag, depth, depth_off, 1000, 50, 2, len(contigs))
+    ctx = _lib.Context(0)
+    ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
+    for _ in range(2):                                   # twice: the second run reuses every workspace
+        ds.run_fused(ctx)
+        got = ds.fetch()
+        assert ds.n_found == len(want_cl['cand_pos'])
+        for f in ('order', 'cand_off', 'cand_contig', 'cand_type', 'cand_pos', 'cand_span'):
+            assert np.array_equal(got[f], want_cl[f]), f
+        assert np.array_equal(got['pred'], want_pred)
+        assert np.array_equal(got['ps'], want_ps)
+    assert int((want_pred != 0).sum()) > 0
+    ctx.close()
