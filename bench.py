@@ -258,6 +258,7 @@ def main():
         if world == 1 and not args.no_extra:
             out['extra'] = extra_points(ctx, torch, engine, synth, DeviceProblem, args.large)
             out['extra']['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
+            out['extra']['fused_clustered_and_phased_config2'] = fused_point(ctx, torch, engine, synth, [contig])
             out['extra']['three_timed_regions_config2'] = abi_and_e2e(ctx, soa, contig, float(iso.total_ms))
             out['extra']['concurrent_jobs_config2'] = concurrent_jobs(torch, _lib, DeviceProblem, soa, args.steps)
         print(json.dumps(out))
@@ -356,6 +357,45 @@ def cluster_point(ctx, torch, synth, contigs):
             'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'algorithmic_bytes_18_per_mark': 18 * M,
             'GBs_vs_B_A0': 18 * M / dt / 1e9, 'cpu_oracle_ms_1core': cpu * 1e3,
             'note': 'launch-bound at this size: ~30 small launches (5 radix passes x 5 kernels + scans)'}
+
+
+def fused_point(ctx, torch, engine, synth, contigs):
+    """The metric read literally -- marks clustered AND phased: duet_svim_phase_device on raw shuffled marks
+    (A0 sort + linkage + emit, adapter, E/F) resident in HBM, checked against the two C oracles composed."""
+    from duet_amd.devmem import DeviceSvim
+    from oracle import c_oracle
+    soa = engine.soa_from_synth(contigs)
+    marks = synth.raw_marks(contigs, 1, reads_of=soa)
+    depth, depth_off = synth.depth_bins(contigs, 1000, 1)
+    ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
+    for _ in range(3):
+        ds.run_fused(ctx)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ds.run_fused(ctx)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    got = ds.fetch()
+    cl = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'])
+    N = len(cl['cand_pos'])
+    support = np.diff(cl['cand_off'].astype(np.int64))
+    k = cl['cand_contig'].astype(np.int64)
+    nb = np.diff(depth_off)[k]
+    bins = np.minimum(cl['cand_pos'].astype(np.int64) // 1000, np.maximum(nb - 1, 0))
+    d = depth[depth_off[k] + bins].astype(np.int64)
+    ref = engine.EfSoA(cand_ctg_off=np.searchsorted(k, np.arange(len(contigs) + 1)), read_tag=soa.read_tag,
+                       cand_pos=cl['cand_pos'], cand_svlen=cl['cand_span'], cand_svread=support,
+                       cand_refread=np.maximum(d - support, 0), cand_gt_ok=np.ones(N, dtype=np.uint8),
+                       cand_off=cl['cand_off'], mark_read=marks['read'][cl['order']])
+    rc, wp, ws = c_oracle.ef(ref, 50, 2)
+    ok = bool(rc == 0 and ds.n_found == N and np.array_equal(got['pred'], wp) and np.array_equal(got['ps'], ws)
+              and np.array_equal(got['cand_off'], cl['cand_off']) and np.array_equal(got['order'], cl['order']))
+    M = len(marks['pos'])
+    return {'marks': M, 'candidates_found': int(ds.n_found), 'phased': int((got['pred'] != 0).sum()),
+            'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'parity_vs_composed_oracles': ok,
+            'note': 'one host sync inside (contig offsets of the found candidates) + E/F plan rebuild per call'}
 
 
 def extra_points(ctx, torch, engine, synth, DeviceProblem, large):

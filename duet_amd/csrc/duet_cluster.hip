@@ -20,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -49,7 +51,9 @@ struct ClParams {
     const uint32_t *sorted;                           // mark index at each sorted position
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
-    uint8_t *label;                                   // [M] root (index inside its partition) of each sorted position
+    float inv_norm, t_lo[3], t_hi[3];                 // cl_fast: 1/normalizer; max_dist / {1, 2, 4} * (1 -/+ 1e-5) in binary32
+    uint32_t fast;                                    // 0: parameters outside cl_fast's vetted range, everything goes to cl_agglom
+    uint32_t *e_info, *e_pos, *e_span;                // [M] per sorted position: rank | end << 8 | cluster << 16 | head << 24; head means
     uint32_t *pc;                                     // [P] clusters per partition
     const uint32_t *cbase;                            // [M] at a partition's start position: its first candidate
     // outputs
@@ -275,23 +279,31 @@ __global__ void cl_parts(const ClParams p, const uint32_t *flag, const uint32_t 
 // work lists by partition size (which agglomeration kernel variant takes it); list order is irrelevant --
 // every partition writes to its own fixed output range -- so a (wave-aggregated) atomic append is fine
 constexpr int kClasses = 5;
-__device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : 4))); }
+__device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 3 : 4))); }
 
-__global__ void cl_classes(const ClParams p, uint32_t *lists /* [kClasses][M] */, uint32_t *counts /* [kClasses] */)
+__global__ __launch_bounds__(1024) void cl_classes(const ClParams p, uint32_t *lists /* [kClasses][M] */, uint32_t *counts /* [kClasses] */)
 {
+    __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
+    if (threadIdx.x < kClasses) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = part < *p.n_parts;
     const int cls = live ? size_class(p.part_start[part + 1] - p.part_start[part]) : -1;
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t at = 0;
 #pragma unroll
     for (int c = 0; c < kClasses; ++c) {
         const unsigned long long m = __ballot(cls == c);
         if (!m) continue;
         uint32_t base = 0;
-        if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
+        if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&s_cnt[c], (uint32_t)__popcll(m));
         base = __shfl(base, __ffsll((long long)m) - 1, 64);
-        if (cls == c) lists[(size_t)c * p.M + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = part;
+        if (cls == c) at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
+    __syncthreads();
+    if (threadIdx.x < kClasses && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (cls >= 0) lists[(size_t)cls * p.M + s_base[cls] + at] = part;
 }
 
 // pcat[i] = clusters of the partition that starts at sorted position i, 0 elsewhere (may alias flag)
@@ -303,35 +315,92 @@ __global__ void cl_pcat(const ClParams p, const uint32_t *flag, const uint32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
-// agglomeration: one wavefront (64-thread workgroup) per partition
+// agglomeration
 // ---------------------------------------------------------------------------------------------
+//
+// GROUP lanes of a wavefront work on one partition of up to GROUP * R marks; lane sl owns the rows
+// sl, sl + GROUP, ... of the partition's full symmetric distance matrix in LDS (odd row stride: a lane reading
+// its own row at a group-uniform column is conflict-free).  A wave carries 64 / GROUP partitions in lockstep;
+// control flow is wave-uniform and groups that have nothing to do in a phase are predicated off.
+//
+// The oracle's merge step is "global argmin over the active upper triangle, ties to the smallest (row, col)".
+// Here every row caches (rmin, rarg) = its minimum over the active columns to its right and the smallest
+// column that attains it, so the global argmin is a butterfly over one value per row.  Invariant:
+//     rmin <= the row's true minimum;  if the row is not marked stale, (rmin, rarg) is exact.
+// A merge (a, b) changes column a and removes column b.  A row k < a folds the new d(k, a) into its cache when
+// that keeps it exact, and is marked stale when its cached column went away; row a's new minimum is a butterfly
+// over the values the other rows just computed.  A stale row is rescanned (cooperatively: one LDS read per
+// lane + a butterfly) only when the argmin picks it -- its rmin is still a lower bound, so rows whose bound
+// never becomes the smallest are never rescanned.  The picked pair is the oracle's: the smallest row index
+// among the rows with the smallest bound, exact once clean, and any row before it has a larger bound.
 
-// pair index q of the upper triangle (row i: j = i+1..n-1, rows in order) -> (i, j)
-__device__ __forceinline__ uint32_t tri_row_start(uint32_t i, uint32_t n) { return i * n - i * (i + 1) / 2; }
+constexpr uint32_t kNoCol = 0xFFFFu;
 
-__device__ __forceinline__ void tri_decode(uint32_t q, uint32_t n, uint32_t pairs, uint32_t &i, uint32_t &j)
+// Minimum of a 32-bit value over each group of GROUP consecutive lanes, delivered to every lane of the group.
+// Inside a 16-lane row the steps are DPP lane permutes fused into v_min_u32 (pairs, quads, halves, row: each step
+// combines two sets that are already uniform); across rows the four row minima go through SGPRs.
+#define DUET_DPP_MIN(v, ctrl) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, 0xF, 0xF, false))
+template <int GROUP>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
 {
-    // rows counted from the end have lengths 1, 2, 3, ...: the pair's distance from the end picks the row
-    const uint32_t r = pairs - 1 - q;
-    uint32_t t = (uint32_t)((__fsqrt_rn(8.0f * (float)r + 1.0f) - 1.0f) * 0.5f);
-    while ((t + 1) * (t + 2) / 2 <= r) ++t;
-    while (t * (t + 1) / 2 > r) --t;
-    i = n - 2 - t;
-    j = i + 1 + (q - tri_row_start(i, n));
+    if (GROUP >= 2) DUET_DPP_MIN(v, 0xB1);        // quad_perm [1,0,3,2]
+    if (GROUP >= 4) DUET_DPP_MIN(v, 0x4E);        // quad_perm [2,3,0,1]
+    if (GROUP >= 8) DUET_DPP_MIN(v, 0x141);       // row_half_mirror
+    if (GROUP >= 16) DUET_DPP_MIN(v, 0x140);      // row_mirror
+    if (GROUP >= 32) {
+        const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+        const uint32_t lo = min(r0, r1), hi = min(r2, r3);
+        v = GROUP == 64 ? min(lo, hi) : (threadIdx.x < 32 ? lo : hi);
+    }
+    return v;
 }
 
-// GROUP lanes of a wavefront work on one partition (GROUP = 16 / 32 / 64 for up to 16 / 32 / 128 marks), so a
-// wave carries 4 / 2 / 1 partitions at once and the fixed cost of a merge step (argmin butterfly, decode, two
-// barriers) is shared.  Control flow is wave-uniform; groups that are done (or idle) are predicated off.
-template <int GROUP, int NMAX>
-__global__ __launch_bounds__(64) void cl_cluster(const ClParams p, const uint32_t *list, const uint32_t *count)
+// minimum of the candidates val[r] (column r * GROUP + sl; non-negative binary64, whose bit patterns order like
+// unsigned integers) over the group, and the smallest column attaining it
+template <int GROUP, int R>
+__device__ __forceinline__ void group_argmin(const double (&val)[R], uint32_t sub, double &gval, uint32_t &gcol)
 {
-    constexpr int SUBS = 64 / GROUP;
-    constexpr int TRI = NMAX * (NMAX - 1) / 2;
-    __shared__ double s_d[SUBS][TRI];
-    __shared__ uint32_t s_pos[SUBS][NMAX], s_span[SUBS][NMAX], s_lab[SUBS][NMAX], s_size[SUBS][NMAX];
+    double m = val[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) m = val[r] < m ? val[r] : m;
+    const uint32_t hi = (uint32_t)__double2hiint(m), lo = (uint32_t)__double2loint(m);
+    const uint32_t mh = group_min_u32<GROUP>(hi);
+    const uint32_t ml = group_min_u32<GROUP>(hi == mh ? lo : 0xFFFFFFFFu);
+    m = __hiloint2double((int)mh, (int)ml);
+    gval = m;
+    gcol = kNoCol;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+        const unsigned long long bal = (__ballot(val[r] == m) >> (sub * GROUP)) & gm;
+        if (bal) gcol = (uint32_t)r * GROUP + (uint32_t)__ffsll((long long)bal) - 1u;
+    }
+}
+
+__device__ __forceinline__ double sp_distance(uint32_t pi, uint32_t spi, uint32_t pj, uint32_t spj, double normalizer)
+{
+    const uint64_t si = pi, ei = (uint64_t)pi + spi, ci = centre_of(pi, spi);
+    const uint64_t sj = pj, ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
+    uint64_t m = si > sj ? si - sj : sj - si;
+    const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
+    m = m2 < m ? m2 : m;
+    m = m3 < m ? m3 : m;
+    const uint32_t smax = spi > spj ? spi : spj, sdif = spi > spj ? spi - spj : spj - spi;
+    const double dp = (double)m / normalizer;
+    const double ds = smax ? (double)sdif / (double)smax : 0.0;
+    return dp + ds;
+}
+
+template <int GROUP, int R>
+__global__ __launch_bounds__(64) void cl_agglom(const ClParams p, const uint32_t *list, const uint32_t *count)
+{
+    constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, S = NMAX | 1;
+    __shared__ double s_d[SUBS][NMAX * S];
+    __shared__ uint32_t s_pos[SUBS][NMAX], s_span[SUBS][NMAX], s_size[SUBS][NMAX];
+    __shared__ uint8_t s_lab[SUBS][NMAX];
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
-    const unsigned long long gmask = GROUP == 64 ? ~0ull : (((1ull << (GROUP & 63)) - 1ull) << (sub * GROUP));
+    double *D = s_d[sub];
     const uint32_t L = *count;
     const double inf = __builtin_inf();
     for (uint32_t base = blockIdx.x * SUBS; base < L; base += gridDim.x * SUBS) {
@@ -341,221 +410,544 @@ __global__ __launch_bounds__(64) void cl_cluster(const ClParams p, const uint32_
         const uint32_t s = has ? p.part_start[part] : 0u;
         const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
         __syncthreads();
-        for (uint32_t i = sl; i < n; i += GROUP) {
-            const uint32_t a = p.sorted[s + i];
-            s_pos[sub][i] = p.pos[a];
-            s_span[sub][i] = p.span[a];
-            s_lab[sub][i] = i;
-            s_size[sub][i] = 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            if (k < n) {
+                const uint32_t a = p.sorted[s + k];
+                s_pos[sub][k] = p.pos[a];
+                s_span[sub][k] = p.span[a];
+                s_size[sub][k] = 1;
+            }
         }
         __syncthreads();
-        const uint32_t pairs = n ? n * (n - 1) / 2 : 0u;
-        // span-position distance of every pair, one pass over the triangle
-        for (uint32_t q = sl; q < pairs; q += GROUP) {
-            uint32_t i, j;
-            tri_decode(q, n, pairs, i, j);
-            const uint32_t pi = s_pos[sub][i], spi = s_span[sub][i], pj = s_pos[sub][j], spj = s_span[sub][j];
-            const uint64_t si = pi, ei = (uint64_t)pi + spi, ci = centre_of(pi, spi);
-            const uint64_t sj = pj, ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
-            uint64_t m = si > sj ? si - sj : sj - si;
-            const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
-            m = m2 < m ? m2 : m;
-            m = m3 < m ? m3 : m;
-            const uint32_t smax = spi > spj ? spi : spj, sdif = spi > spj ? spi - spj : spj - spi;
-            const double dp = (double)m / p.normalizer;
-            const double ds = smax ? (double)sdif / (double)smax : 0.0;
-            s_d[sub][q] = dp + ds;
-        }
-        __syncthreads();
-        // each lane of the group owns a contiguous run of pairs, so lane order is pair order
-        const uint32_t per = (pairs + GROUP - 1) / GROUP;
-        const uint32_t q_lo = min(pairs, sl * per), q_hi = min(pairs, q_lo + per);
-        bool active = n >= 2;
-        uint32_t merges = 0;
-        while (__ballot(active)) {
-            // group-wide argmin over the triangle; inactive pairs hold +inf; ties -> smallest pair index
-            double bd = inf;
-            uint32_t bq = 0xFFFFFFFFu;
-            if (active) {
-                for (uint32_t q = q_lo; q < q_hi; ++q) {
-                    const double v = s_d[sub][q];
-                    if (v < bd) { bd = v; bq = q; }
+        // every unordered pair once: row k takes the columns k+1 .. k+n/2 (mod n); for even n the distance-n/2
+        // pairs only from the lower half of the rows
+        const uint32_t half = n >> 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            if (k < n) {
+                const uint32_t pk = s_pos[sub][k], spk = s_span[sub][k];
+                const uint32_t tmax = (!(n & 1u) && k >= half) ? half - 1 : half;
+                for (uint32_t t = 1; t <= tmax; ++t) {
+                    uint32_t j = k + t;
+                    j = j >= n ? j - n : j;
+                    const double v = sp_distance(pk, spk, s_pos[sub][j], s_span[sub][j], p.normalizer);
+                    D[k * S + j] = v;
+                    D[j * S + k] = v;
                 }
             }
-            double md = bd;
+        }
+        __syncthreads();
+        double rmin[R];
+        uint32_t rarg[R], lab[R];
+        bool alive[R], stale[R];
 #pragma unroll
-            for (int off = GROUP / 2; off > 0; off >>= 1) {
-                const double od = __shfl_xor(md, off, 64);
-                md = od < md ? od : md;
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            rmin[r] = inf;
+            rarg[r] = kNoCol;
+            lab[r] = k;
+            alive[r] = k < n;
+            stale[r] = false;
+            for (uint32_t j = k + 1; j < n; ++j) {
+                const double v = D[k * S + j];
+                if (v < rmin[r]) { rmin[r] = v; rarg[r] = j; }
             }
-            const bool go = active && md <= p.max_dist;
-            const unsigned long long tie = __ballot(go && bd == md) & gmask;
-            bq = __shfl(bq, tie ? __ffsll((long long)tie) - 1 : (int)lane, 64);
-            uint32_t a = 0, b = 0;
-            double na = 0, nb = 0;
-            if (go) {
-                tri_decode(bq, n, pairs, a, b);
-                na = (double)s_size[sub][a];
-                nb = (double)s_size[sub][b];
+        }
+        bool done = n < 2;
+        // every iteration merges or cleans a stale row, so the loop ends by itself; the bound is a safety net
+        for (uint32_t iter = 0; iter < (uint32_t)NMAX * NMAX; ++iter) {
+            double cand[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) cand[r] = alive[r] ? rmin[r] : inf;
+            double gval;
+            uint32_t g;
+            group_argmin<GROUP, R>(cand, sub, gval, g);
+            const bool act = !done && gval <= p.max_dist && g != kNoCol;      // distances are finite: inf = no pair left
+            done = done || !act;
+            if (!__ballot(act)) break;
+            // the picked row's cache, from its owner lane
+            uint32_t mine = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((uint32_t)r == g / GROUP) mine = rarg[r] | (stale[r] ? 0x80000000u : 0u);
+            const uint32_t info = __shfl(mine, act ? (int)(sub * GROUP + g % GROUP) : (int)lane, 64);
+            const bool do_rescan = act && (info >> 31);
+            const bool do_merge = act && !(info >> 31);
+            if (__ballot(do_rescan)) {
+                double cv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t k = sl + r * GROUP;
+                    cv[r] = (do_rescan && alive[r] && k > g) ? D[k * S + g] : inf;
+                }
+                double nv;
+                uint32_t nc;
+                group_argmin<GROUP, R>(cv, sub, nv, nc);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (do_rescan && sl + r * GROUP == g) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; }
+            }
+            if (__ballot(do_merge)) {
+                const uint32_t a = g, b = info & 0xFFFFu;
+                uint32_t za = 0, zb = 0;
+                if (do_merge) { za = s_size[sub][a]; zb = s_size[sub][b]; }
+                const double na = (double)za, nb = (double)zb;
+                double cv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t k = sl + r * GROUP;
+                    cv[r] = inf;
+                    if (do_merge && alive[r] && k != a && k != b) {
+                        const double da = D[k * S + a], db = D[k * S + b];
+                        const double v = (na * da + nb * db) / (na + nb);
+                        D[k * S + a] = v;
+                        D[a * S + k] = v;
+                        if (k < a) {
+                            const bool hit = rarg[r] == a || rarg[r] == b;
+                            if (v < rmin[r]) { rmin[r] = v; rarg[r] = a; stale[r] = false; }
+                            else if (v == rmin[r]) { if (!stale[r] && (hit || a < rarg[r])) rarg[r] = a; }
+                            else if (hit) stale[r] = true;
+                        } else {
+                            if (k < b && rarg[r] == b) stale[r] = true;
+                            cv[r] = v;
+                        }
+                    }
+                    if (do_merge && lab[r] == b) lab[r] = a;
+                }
+                double nv;
+                uint32_t nc;
+                group_argmin<GROUP, R>(cv, sub, nv, nc);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t k = sl + r * GROUP;
+                    if (do_merge && k == a) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; }
+                    if (do_merge && k == b) alive[r] = false;
+                }
+                if (do_merge && sl == 0) s_size[sub][a] = za + zb;
             }
             __syncthreads();
-            if (go) {
-                for (uint32_t k = sl; k < n; k += GROUP) {
-                    if (k == a || k == b) continue;
-                    const uint32_t lo_a = k < a ? k : a, hi_a = k < a ? a : k;
-                    const uint32_t lo_b = k < b ? k : b, hi_b = k < b ? b : k;
-                    const uint32_t qa = tri_row_start(lo_a, n) + (hi_a - lo_a - 1);
-                    const uint32_t qb = tri_row_start(lo_b, n) + (hi_b - lo_b - 1);
-                    const double da = s_d[sub][qa], db = s_d[sub][qb];
-                    if (da == inf) continue;                   // k already merged away
-                    s_d[sub][qa] = (na * da + nb * db) / (na + nb);
-                    s_d[sub][qb] = inf;
-                }
-                if (sl == 0) {
-                    s_d[sub][bq] = inf;
-                    s_size[sub][a] += s_size[sub][b];
-                }
-                for (uint32_t k = sl; k < n; k += GROUP)
-                    if (s_lab[sub][k] == b) s_lab[sub][k] = a;
-            }
-            __syncthreads();
-            ++merges;
-            active = go && merges + 1 < n;
         }
+        // what cl_emit needs, while the partition is still in LDS: each mark's place in the partition's output
+        // and, at each cluster's smallest member, the cluster's rank, end and floor means
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (sl + r * GROUP < n) s_lab[sub][sl + r * GROUP] = (uint8_t)lab[r];
         __syncthreads();
-        uint32_t roots = 0;
-        for (uint32_t k = sl; k < n; k += GROUP) {
-            p.label[s + k] = (uint8_t)s_lab[sub][k];
-            roots += s_lab[sub][k] == k;
+        uint32_t roots = 0, cr[R], before[R], sameb[R], size[R];
+        uint64_t sp[R], ss[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { cr[r] = before[r] = sameb[r] = size[r] = 0; sp[r] = ss[r] = 0; }
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t lj = s_lab[sub][j], pj = s_pos[sub][j], spj = s_span[sub][j];
+            const bool isroot = lj == j;
+            roots += isroot;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP, my = lab[r];
+                cr[r] += isroot && j < my;
+                before[r] += lj < my;
+                const bool same = lj == my;
+                sameb[r] += same && j < k;
+                size[r] += same;
+                sp[r] += same ? pj : 0u;
+                ss[r] += same ? spj : 0u;
+            }
         }
 #pragma unroll
-        for (int off = GROUP / 2; off > 0; off >>= 1) roots += __shfl_xor(roots, off, 64);
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            if (k < n) {
+                const bool root = lab[r] == k;
+                p.e_info[s + k] = (before[r] + sameb[r]) | ((before[r] + size[r]) << 8) | (cr[r] << 16) | (root ? 1u << 24 : 0u);
+                if (root) {
+                    p.e_pos[s + k] = (uint32_t)(sp[r] / size[r]);
+                    p.e_span[s + k] = (uint32_t)(ss[r] / size[r]);
+                }
+            }
+        }
         if (has && sl == 0) p.pc[part] = roots;
     }
 }
 
-// Small partitions (n <= NS): one LANE per partition.  Each lane runs the whole agglomeration on its own
-// triangle, stored transposed in LDS ([entry][lane]) so that the 64 lanes of a wave hit 64 different banks.
-// Same arithmetic, same pair order, same tie-break as the wave-per-partition kernel.
-template <int NS>
-__global__ __launch_bounds__(64) void cl_cluster_small(const ClParams p, const uint32_t *list, const uint32_t *count)
+// ---------------------------------------------------------------------------------------------
+// agglomeration, fast path: partitions whose clusters can be read off the threshold graph
+// ---------------------------------------------------------------------------------------------
+//
+// What stage A0 emits depends only on the FINAL clusters of a partition (clusters by smallest member, members
+// in sorted order, floor means), not on the order of the merges.  Two facts about average linkage pin them down
+// without running it (u = 2^-53; a Lance-Williams step rounds 3 times, a merge tree is at most 127 deep, so a
+// computed cluster distance lies within (1 +/- 4.3e-14) of the range of the pair distances it averages):
+//   * marks in different connected components of the graph {d(i,j) <= max_dist * (1 + 9e-6)} are never merged:
+//     every cross distance the oracle ever computes stays above max_dist;
+//   * a component in which EVERY pair has d <= max_dist * (1 - 9e-6) ends as exactly one cluster: while two of
+//     its clusters remain, their computed distance is below max_dist, so the oracle keeps merging.
+// cl_fast evaluates d in binary32 (relative error < 4e-7, hence the 1e-5 guard band around max_dist), builds each
+// mark's closed neighbourhood as a bit mask, and accepts the partition when no pair falls inside the guard
+// band and every neighbourhood equals the neighbourhood of its smallest member (<=> every component is a
+// clique).  Everything else -- about one partition in a few hundred on SV-like data, nearly all on random data
+// -- is appended to a "hard" list and gets the exact binary64 agglomeration (cl_agglom).  Both paths produce
+// the oracle's clusters; tests/test_gpu_cluster.py and tools/stress.py cover both.
+
+template <int NW>
+struct BitSet {
+    uint64_t w[NW];
+    __device__ __forceinline__ void clear() { for (int i = 0; i < NW; ++i) w[i] = 0; }
+    __device__ __forceinline__ uint32_t count() const { uint32_t c = 0; for (int i = 0; i < NW; ++i) c += __popcll(w[i]); return c; }
+    __device__ __forceinline__ uint32_t count_below(uint32_t k) const      // set bits at positions < k
+    {
+        uint32_t c = 0;
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t lo = 64u * i;
+            const uint64_t m = k >= lo + 64u ? ~0ull : (k > lo ? (1ull << (k - lo)) - 1ull : 0ull);
+            c += __popcll(w[i] & m);
+        }
+        return c;
+    }
+    __device__ __forceinline__ uint32_t first() const                      // lowest set bit (undefined if empty)
+    {
+        for (int i = 0; i < NW - 1; ++i)
+            if (w[i]) return 64u * i + (uint32_t)__ffsll((long long)w[i]) - 1u;
+        return 64u * (NW - 1) + (uint32_t)__ffsll((long long)w[NW - 1]) - 1u;
+    }
+    __device__ __forceinline__ bool test(uint32_t j) const { return (w[NW == 1 ? 0 : j >> 6] >> (j & 63u)) & 1ull; }
+    __device__ __forceinline__ bool equals(const BitSet &o) const { bool e = true; for (int i = 0; i < NW; ++i) e = e && w[i] == o.w[i]; return e; }
+};
+
+__device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+
+constexpr int kLevels = 3;              // thresholds max_dist, max_dist / 2, max_dist / 4
+constexpr int kMaxAtoms = 4;
+
+// Average linkage over at most kMaxAtoms "atoms" (clusters already known to form first), every lane of the group
+// running the same steps on the group's LDS scratch: D[a][b] the atoms' average distances (a < b used), sz their
+// sizes, lab[a] the atom that a's cluster is named after (its smallest atom).  Returns false when a decision --
+// which pair is closest, whether it is within max_dist -- is not safe against a 1e-4 relative error of D.
+__device__ __forceinline__ bool atoms_linkage(uint32_t m, double (*D)[kMaxAtoms], double *sz, uint32_t *lab, double max_dist)
 {
-    constexpr int TRI = NS * (NS - 1) / 2;
-    __shared__ double s_d[TRI][64];
-    __shared__ uint32_t s_pos[NS][64], s_span[NS][64];
-    __shared__ uint8_t s_lab[NS][64], s_size[NS][64];
-    const uint32_t lane = threadIdx.x;
+    bool alive[kMaxAtoms];
+#pragma unroll
+    for (int a = 0; a < kMaxAtoms; ++a) alive[a] = (uint32_t)a < m;
+    for (uint32_t step = 0; step + 1 < m; ++step) {
+        double d1 = __builtin_inf(), d2 = __builtin_inf();
+        int a1 = 0, b1 = 1;
+#pragma unroll
+        for (int a = 0; a < kMaxAtoms; ++a)
+#pragma unroll
+            for (int b = a + 1; b < kMaxAtoms; ++b) {
+                if (!alive[a] || !alive[b]) continue;
+                const double v = D[a][b];
+                if (v < d1) { d2 = d1; d1 = v; a1 = a; b1 = b; }
+                else if (v < d2) d2 = v;
+            }
+        if (!(d2 > d1 * (1.0 + 1e-4))) return false;                       // a near-tie for the closest pair
+        if (!(fabs(d1 - max_dist) > 1e-4 * max_dist)) return false;         // too close to the threshold to call
+        if (d1 > max_dist) break;
+        const double na = sz[a1], nb = sz[b1];
+#pragma unroll
+        for (int c = 0; c < kMaxAtoms; ++c) {
+            if (!alive[c] || c == a1 || c == b1) continue;
+            const double da = c < a1 ? D[c][a1] : D[a1][c], db = c < b1 ? D[c][b1] : D[b1][c];
+            const double v = (na * da + nb * db) / (na + nb);
+            if (c < a1) D[c][a1] = v; else D[a1][c] = v;
+        }
+        sz[a1] = na + nb;
+#pragma unroll
+        for (int c = 0; c < kMaxAtoms; ++c) {
+            if (c == b1) alive[c] = false;
+            if (lab[c] == (uint32_t)b1) lab[c] = (uint32_t)a1;
+        }
+    }
+    return true;
+}
+
+template <int GROUP, int R>
+__global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *list, const uint32_t *count, uint32_t *hard_list,
+                                              uint32_t *hard_count)
+{
+    constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
+    static_assert(NMAX <= 128 && (R == 1 || (GROUP * R) % 64 == 0 || GROUP * R <= 64), "unsupported shape");
+    __shared__ uint2 s_ps[SUBS][NMAX];                       // (pos, span)
+    __shared__ uint64_t s_mask[SUBS][NMAX][NW];
+    __shared__ uint8_t s_atom[SUBS][NMAX];
+    __shared__ double s_D[SUBS][kMaxAtoms][kMaxAtoms], s_sz[SUBS][kMaxAtoms];
+    __shared__ uint32_t s_lab[SUBS][kMaxAtoms], s_aroot[SUBS][kMaxAtoms];
+    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     const uint32_t L = *count;
-    const double inf = __builtin_inf();
-    for (uint32_t base = blockIdx.x * 64u; base < L; base += gridDim.x * 64u) {
-        const uint32_t li = base + lane;
-        if (li >= L) continue;
-        const uint32_t part = list[li];
-        const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t a = p.sorted[s + i];
-            s_pos[i][lane] = p.pos[a];
-            s_span[i][lane] = p.span[a];
-            s_lab[i][lane] = (uint8_t)i;
-            s_size[i][lane] = 1;
-        }
-        uint32_t q = 0;
-        for (uint32_t i = 0; i + 1 < n; ++i) {
-            const uint32_t pi = s_pos[i][lane], spi = s_span[i][lane];
-            const uint64_t si = pi, ei = (uint64_t)pi + spi, ci = centre_of(pi, spi);
-            for (uint32_t j = i + 1; j < n; ++j, ++q) {
-                const uint32_t pj = s_pos[j][lane], spj = s_span[j][lane];
-                const uint64_t sj = pj, ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
-                uint64_t m = si > sj ? si - sj : sj - si;
-                const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
-                m = m2 < m ? m2 : m;
-                m = m3 < m ? m3 : m;
-                const uint32_t smax = spi > spj ? spi : spj, sdif = spi > spj ? spi - spj : spj - spi;
-                const double dp = (double)m / p.normalizer;
-                const double ds = smax ? (double)sdif / (double)smax : 0.0;
-                s_d[q][lane] = dp + ds;
+    auto group_any = [&](bool x) -> bool { return ((__ballot(x) >> (sub * GROUP)) & gm) != 0ull; };
+    for (uint32_t base = blockIdx.x * SUBS; base < L; base += gridDim.x * SUBS) {
+        const uint32_t li = base + sub;
+        const bool has = li < L;
+        const uint32_t part = has ? list[li] : 0u;
+        const uint32_t s = has ? p.part_start[part] : 0u;
+        const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+        __syncthreads();
+        uint32_t pk[R], spk[R], ek[R], ck[R];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            pk[r] = spk[r] = 0;
+            if (k < n) {
+                const uint32_t a = p.sorted[s + k];
+                pk[r] = p.pos[a];
+                spk[r] = p.span[a];
+                s_ps[sub][k] = make_uint2(pk[r], spk[r]);
             }
+            ek[r] = pk[r] + spk[r];
+            ck[r] = pk[r] + (spk[r] >> 1);
+            bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits: leave it to the exact path
         }
-        const uint32_t pairs = q;
-        for (uint32_t merges = 0; merges + 1 < n; ++merges) {
-            double bd = inf;
-            uint32_t ba = 0, bb = 0, bq = 0;
-            q = 0;
-            for (uint32_t i = 0; i + 1 < n; ++i)
-                for (uint32_t j = i + 1; j < n; ++j, ++q) {
-                    const double v = s_d[q][lane];
-                    if (v < bd) { bd = v; ba = i; bb = j; bq = q; }
+        __syncthreads();
+        // closed neighbourhoods at the three thresholds; amb: some pair sits inside a threshold's guard band
+        BitSet<NW> N[kLevels][R];
+        bool amb[kLevels];
+#pragma unroll
+        for (int l = 0; l < kLevels; ++l) {
+            amb[l] = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) N[l][r].clear();
+        }
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint2 q = s_ps[sub][j];
+            const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
+                const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
+                const float dp = (float)m * p.inv_norm;
+#pragma unroll
+                for (int l = 0; l < kLevels; ++l) {
+                    const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
+                    amb[l] = amb[l] || e_hi != e_lo;
+                    if (e_hi) N[l][r].w[NW == 1 ? 0 : j >> 6] |= 1ull << (j & 63u);
                 }
-            if (!(bd <= p.max_dist)) break;
-            const double na = (double)s_size[ba][lane], nb = (double)s_size[bb][lane];
-            for (uint32_t k = 0; k < n; ++k) {
-                if (k == ba || k == bb) continue;
-                const uint32_t lo_a = k < ba ? k : ba, hi_a = k < ba ? ba : k;
-                const uint32_t lo_b = k < bb ? k : bb, hi_b = k < bb ? bb : k;
-                const uint32_t qa = tri_row_start(lo_a, n) + (hi_a - lo_a - 1);
-                const uint32_t qb = tri_row_start(lo_b, n) + (hi_b - lo_b - 1);
-                const double da = s_d[qa][lane], db = s_d[qb][lane];
-                if (da == inf) continue;
-                s_d[qa][lane] = (na * da + nb * db) / (na + nb);
-                s_d[qb][lane] = inf;
             }
-            s_d[bq][lane] = inf;
-            s_size[ba][lane] = (uint8_t)(s_size[ba][lane] + s_size[bb][lane]);
-            for (uint32_t k = 0; k < n; ++k)
-                if (s_lab[k][lane] == bb) s_lab[k][lane] = (uint8_t)ba;
         }
-        (void)pairs;
-        uint32_t roots = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t l = s_lab[k][lane];
-            p.label[s + k] = (uint8_t)l;
-            roots += l == k;
+#pragma unroll
+        for (int l = 0; l < kLevels; ++l)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                if (k < n) N[l][r].w[NW == 1 ? 0 : k >> 6] |= 1ull << (k & 63u);
+            }
+        // every component of a level's graph is a clique <=> each mark's neighbourhood equals that of its
+        // smallest member; leaves the level's masks in s_mask
+        auto cliques = [&](const BitSet<NW> (&Nl)[R]) -> bool {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                if (k < n)
+                    for (int i = 0; i < NW; ++i) s_mask[sub][k][i] = Nl[r].w[i];
+            }
+            __syncthreads();
+            bool differs = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                if (k < n) {
+                    const uint32_t f = Nl[r].first();
+                    BitSet<NW> o;
+                    for (int i = 0; i < NW; ++i) o.w[i] = s_mask[sub][f][i];
+                    differs = differs || !o.equals(Nl[r]);
+                }
+            }
+            return !group_any(differs);
+        };
+        const bool unfit = group_any(bad) || !p.fast;
+        BitSet<NW> F[R];                                     // the final cluster of each of this lane's marks
+#pragma unroll
+        for (int r = 0; r < R; ++r) F[r] = N[0][r];
+        const bool amb0 = group_any(amb[0]), cl0 = cliques(N[0]);       // collective: every lane takes part
+        bool solved = n < 2 || (!unfit && !amb0 && cl0);
+        const bool want2 = has && !solved && !unfit;
+        if (__ballot(want2)) {
+            // atoms: the cliques of the finest usable level -- they are complete clusters before anything else
+            // happens (every pair inside is closer than every pair across), so what remains is average linkage over
+            // the atoms, decided from binary32 estimates of their average distances when that is safe
+            const bool amb2 = group_any(amb[2]), cl2 = cliques(N[2]);
+            const bool amb1 = group_any(amb[1]), cl1 = cliques(N[1]);
+            const bool ok2 = !amb2 && cl2, ok1 = !amb1 && cl1;
+            bool two = want2 && (ok1 || ok2);
+            BitSet<NW> A[R];
+            uint32_t ra[R], ai[R];
+            BitSet<NW> heads;
+            heads.clear();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                A[r] = ok1 ? N[1][r] : N[2][r];
+                ra[r] = A[r].first();
+                const unsigned long long b = (__ballot(two && sl + r * GROUP < n && ra[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
+                heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+            }
+            const uint32_t m = heads.count();
+            two = two && m <= (uint32_t)kMaxAtoms;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                ai[r] = two ? heads.count_below(ra[r]) : 0u;
+                if (two && k < n) {
+                    for (int i = 0; i < NW; ++i) s_mask[sub][k][i] = A[r].w[i];      // the chosen level's atoms
+                    s_atom[sub][k] = (uint8_t)ai[r];
+                    if (ra[r] == k) {
+                        s_aroot[sub][ai[r]] = k;
+                        s_sz[sub][ai[r]] = (double)A[r].count();
+                        s_lab[sub][ai[r]] = ai[r];
+                    }
+                }
+            }
+            if (two && sl < kMaxAtoms * kMaxAtoms) s_D[sub][sl / kMaxAtoms][sl % kMaxAtoms] = 0.0;
+            if (GROUP < kMaxAtoms * kMaxAtoms && two && sl + GROUP < kMaxAtoms * kMaxAtoms)
+                s_D[sub][(sl + GROUP) / kMaxAtoms][(sl + GROUP) % kMaxAtoms] = 0.0;
+            __syncthreads();
+            if (__ballot(two)) {
+                float acc[R][kMaxAtoms];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int b = 0; b < kMaxAtoms; ++b) acc[r][b] = 0.f;
+                const uint32_t n2 = two ? n : 0u;
+                for (uint32_t j = 0; j < n2; ++j) {
+                    const uint2 q = s_ps[sub][j];
+                    const uint32_t aj = s_atom[sub][j];
+                    const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t mm = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
+                        const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
+                        const float d = (float)mm * p.inv_norm + fs * __builtin_amdgcn_rcpf(fm);
+#pragma unroll
+                        for (int b = 0; b < kMaxAtoms; ++b) acc[r][b] += aj == (uint32_t)b ? d : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (two && sl + r * GROUP < n)
+#pragma unroll
+                        for (int b = 0; b < kMaxAtoms; ++b)
+                            if ((uint32_t)b != ai[r] && (uint32_t)b < m) atomicAdd(&s_D[sub][ai[r]][b], (double)acc[r][b]);
+                __syncthreads();
+                if (two) {
+                    // every lane of the group: averages into the upper triangle, then the linkage (same values
+                    // written by all lanes)
+#pragma unroll
+                    for (int a = 0; a < kMaxAtoms; ++a)
+#pragma unroll
+                        for (int b = a + 1; b < kMaxAtoms; ++b)
+                            if ((uint32_t)b < m) {
+                                const double v = (s_D[sub][a][b] + s_D[sub][b][a]) / (2.0 * s_sz[sub][a] * s_sz[sub][b]);
+                                __builtin_amdgcn_wave_barrier();
+                                s_D[sub][a][b] = v;
+                            }
+                }
+                __syncthreads();
+                bool okl = false;
+                if (two) okl = atoms_linkage(m, s_D[sub], s_sz[sub], s_lab[sub], p.max_dist);
+                __syncthreads();
+                if (two && okl) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t mine = s_lab[sub][ai[r]];
+                        F[r].clear();
+                        for (uint32_t b = 0; b < m; ++b)
+                            if (s_lab[sub][b] == mine)
+                                for (int i = 0; i < NW; ++i) F[r].w[i] |= s_mask[sub][s_aroot[sub][b]][i];
+                    }
+                    solved = true;
+                }
+            }
         }
-        p.pc[part] = roots;
+        if (!solved) {
+            if (has && sl == 0) {
+                const uint32_t hc = n <= 16 ? 0u : (n <= 32 ? 1u : (n <= 64 ? 2u : 3u));
+                hard_list[(size_t)hc * p.M + atomicAdd(&hard_count[hc], 1u)] = part;
+            }
+        }
+        // cluster heads of the group, as a bit set every lane of the group holds
+        __syncthreads();
+        uint32_t rt[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            rt[r] = k < n ? F[r].first() : k;
+            if (k < n)
+                for (int i = 0; i < NW; ++i) s_mask[sub][k][i] = F[r].w[i];
+        }
+        __syncthreads();
+        BitSet<NW> heads;
+        heads.clear();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned long long b = (__ballot(solved && sl + r * GROUP < n && rt[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
+            heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+        }
+        if (!solved) continue;
+        uint32_t before[R];
+        uint64_t sp[R], ss[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { before[r] = 0; sp[r] = ss[r] = 0; }
+        for (int i = 0; i < NW; ++i) {
+            uint64_t hm = heads.w[i];
+            while (hm) {
+                const uint32_t h = 64u * i + (uint32_t)__ffsll((long long)hm) - 1u;
+                hm &= hm - 1ull;
+                uint32_t sz = 0;
+                for (int c = 0; c < NW; ++c) sz += __popcll(s_mask[sub][h][c]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) before[r] += h < rt[r] ? sz : 0u;
+            }
+        }
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint2 q = s_ps[sub][j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool in = F[r].test(j);
+                sp[r] += in ? q.x : 0u;
+                ss[r] += in ? q.y : 0u;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            if (k < n) {
+                const bool head = rt[r] == k;
+                const uint32_t size = F[r].count();
+                p.e_info[s + k] = (before[r] + F[r].count_below(k)) | ((before[r] + size) << 8) |
+                                  (heads.count_below(rt[r]) << 16) | (head ? 1u << 24 : 0u);
+                if (head) {
+                    p.e_pos[s + k] = (uint32_t)(sp[r] / size);
+                    p.e_span[s + k] = (uint32_t)(ss[r] / size);
+                }
+            }
+        }
+        if (has && sl == 0) p.pc[part] = heads.count();
     }
 }
 
-// one wavefront per partition: clusters by smallest member, members in sorted order
-__global__ __launch_bounds__(64) void cl_emit(const ClParams p)
+// one thread per sorted position: members to their place in order[], cluster heads write the candidate
+__global__ void cl_emit(const ClParams p, const uint32_t *flag, const uint32_t *pid)
 {
-    __shared__ uint32_t s_lab[128], s_pos[128], s_span[128];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t P = *p.n_parts;
-    for (uint32_t part = blockIdx.x; part < P; part += gridDim.x) {
-        const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
-        const uint32_t cb = p.cbase[s];
-        __syncthreads();
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t a = p.sorted[s + i];
-            s_lab[i] = p.label[s + i];
-            s_pos[i] = p.pos[a];
-            s_span[i] = p.span[a];
-        }
-        __syncthreads();
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t my = s_lab[i];
-            uint32_t cr = 0, before = 0, same_before = 0, size = 0;
-            uint64_t sp = 0, ss = 0;
-            for (uint32_t j = 0; j < n; ++j) {
-                const uint32_t lj = s_lab[j];
-                cr += (lj == j && j < my);
-                before += lj < my;
-                same_before += (lj == my && j < i);
-                if (lj == my) { ++size; sp += s_pos[j]; ss += s_span[j]; }
-            }
-            const uint32_t a = p.sorted[s + i];
-            p.order[s + before + same_before] = a;
-            if (my == i) {
-                const uint32_t cand = cb + cr;
-                p.cand_off[cand + 1] = s + before + size;
-                p.cand_contig[cand] = p.contig[a];
-                p.cand_type[cand] = p.type[a];
-                p.cand_pos[cand] = (uint32_t)(sp / size);
-                p.cand_span[cand] = (uint32_t)(ss / size);
-            }
-        }
-        if (part == 0 && lane == 0) p.cand_off[0] = 0;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.M) return;
+    const uint32_t info = p.e_info[i];
+    const uint32_t part = pid[i] - (flag[i] ? 0u : 1u);
+    const uint32_t s = p.part_start[part];
+    const uint32_t a = p.sorted[i];
+    p.order[s + (info & 0xFFu)] = a;
+    if (info >> 24) {
+        const uint32_t cand = p.cbase[s] + ((info >> 16) & 0xFFu);
+        p.cand_off[cand + 1] = s + ((info >> 8) & 0xFFu);
+        p.cand_contig[cand] = p.contig[a];
+        p.cand_type[cand] = p.type[a];
+        p.cand_pos[cand] = p.e_pos[i];
+        p.cand_span[cand] = p.e_span[i];
     }
+    if (i == 0) p.cand_off[0] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -627,7 +1019,8 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
     if (!pr || !res) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
     if (pr->part_max < 1 || pr->part_max > 128) return duet_fail(ctx, DUET_ERR_INVALID, "part_max must be in 1..128");
-    if (!(pr->normalizer > 0)) return duet_fail(ctx, DUET_ERR_INVALID, "normalizer must be positive");
+    if (!(pr->normalizer >= 1e-280 && pr->normalizer <= 1e300))
+        return duet_fail(ctx, DUET_ERR_INVALID, "normalizer must be in [1e-280, 1e300]");     // keeps every distance finite
     if (!res->n_cands) return duet_fail(ctx, DUET_ERR_INVALID, "null n_cands");
     hipStream_t st = (hipStream_t)stream_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -645,7 +1038,7 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M, (size_t)M * 4, 64, (size_t)M * 4 * kClasses, 16};
+                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 64, (size_t)M * 4 * (kClasses + 4), ((size_t)M + 1) * 4 * 2};
     int rc;
     for (int i = 0; i < 14; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
@@ -655,7 +1048,8 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr, *tmpB = (uint32_t *)ctx->cl_ws[6].ptr;
     uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
     uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
-    uint8_t *label = (uint8_t *)ctx->cl_ws[9].ptr;
+    uint32_t *e_info = (uint32_t *)ctx->cl_ws[9].ptr;
+    uint32_t *pcat = (uint32_t *)ctx->cl_ws[13].ptr, *cbase = pcat + (M + 1);
     uint32_t *pc = (uint32_t *)ctx->cl_ws[10].ptr;
     uint32_t *scal = (uint32_t *)ctx->cl_ws[11].ptr;      // [0] = n_parts
 
@@ -692,38 +1086,68 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     launch_scan<0>(tmpA, M, spart, tmpB, scal, st);               // tmpB = partition id, scal[0] = #partitions
     hipLaunchKernelGGL(cl_parts, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, part_start,
                        (const uint32_t *)scal);
-    p.part_start = part_start; p.n_parts = scal; p.label = label; p.pc = pc;
+    p.part_start = part_start; p.n_parts = scal; p.pc = pc;
+    p.e_info = e_info;
+    p.e_pos = (uint32_t *)kout;                                   // the spare key buffer: 2 x M words
+    p.e_span = p.e_pos + M;
     const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
-    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M]
-    uint32_t *cnts = scal + 2;
-    HIP_TRY(ctx, hipMemsetAsync(cnts, 0, 4 * kClasses, st));
-    hipLaunchKernelGGL(cl_classes, g256, b256, 0, st, p, lists, cnts);
-    // the few large partitions (49..128 marks) take long, serial agglomerations: run them on a side stream
-    // beside the bulk
+    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses + 4][M]: by size class, then the hard lists
+    uint32_t *hard = lists + (size_t)kClasses * M;
+    uint32_t *cnts = scal + 2, *hcnt = scal + 8;
+    p.inv_norm = (float)(1.0 / pr->normalizer);
+    for (int l = 0; l < 3; ++l) {
+        p.t_lo[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 - 1e-5));
+        p.t_hi[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 + 1e-5));
+    }
+    p.fast = (pr->max_dist >= 0 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
+    if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
+    HIP_TRY(ctx, hipMemsetAsync(cnts, 0, 4 * 12, st));
+    hipLaunchKernelGGL(cl_classes, dim3((M + 1023) / 1024), dim3(1024), 0, st, p, lists, cnts);
+    // Four independent chains (a size class's fast pass, then the exact pass over what it declined); the long
+    // serial merge chains of the few large partitions run on side streams beside the bulk.
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side, ctx->cl_fork, 0));
-    hipLaunchKernelGGL((cl_cluster<64, 128>), dim3(grid < 1024u ? grid : 1024u), dim3(64), 0, ctx->cl_side, p,
-                       (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_join, ctx->cl_side));
-    const uint32_t g_lane = (M + 63) / 64 < 4096u ? (M + 63) / 64 : 4096u;
-    hipLaunchKernelGGL((cl_cluster_small<8>), dim3(g_lane), dim3(64), 0, st, p, (const uint32_t *)lists,
-                       (const uint32_t *)(cnts + 0));
-    hipLaunchKernelGGL((cl_cluster<16, 16>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
-                       (const uint32_t *)(cnts + 1));
-    hipLaunchKernelGGL((cl_cluster<32, 32>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
-                       (const uint32_t *)(cnts + 2));
-    hipLaunchKernelGGL((cl_cluster<64, 48>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
-                       (const uint32_t *)(cnts + 3));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join, 0));
+    for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[i], ctx->cl_fork, 0));
+    {
+        hipStream_t s3 = ctx->cl_side[0];                        // 65..128 marks
+        hipLaunchKernelGGL((cl_fast<64, 2>), dim3(grid), dim3(64), 0, s3, p, (const uint32_t *)(lists + 4 * (size_t)M),
+                           (const uint32_t *)(cnts + 4), hard, hcnt);
+        hipLaunchKernelGGL((cl_agglom<64, 2>), dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, s3, p,
+                           (const uint32_t *)(hard + 3 * (size_t)M), (const uint32_t *)(hcnt + 3));
+        hipStream_t s2 = ctx->cl_side[1];                        // 33..64
+        hipLaunchKernelGGL((cl_fast<64, 1>), dim3(grid), dim3(64), 0, s2, p, (const uint32_t *)(lists + 3 * (size_t)M),
+                           (const uint32_t *)(cnts + 3), hard, hcnt);
+        hipLaunchKernelGGL((cl_agglom<64, 1>), dim3(grid), dim3(64), 0, s2, p, (const uint32_t *)(hard + 2 * (size_t)M),
+                           (const uint32_t *)(hcnt + 2));
+        hipStream_t s1 = ctx->cl_side[2];                        // 17..32
+        hipLaunchKernelGGL((cl_fast<32, 1>), dim3(grid), dim3(64), 0, s1, p, (const uint32_t *)(lists + 2 * (size_t)M),
+                           (const uint32_t *)(cnts + 2), hard, hcnt);
+        hipLaunchKernelGGL((cl_agglom<32, 1>), dim3(grid), dim3(64), 0, s1, p, (const uint32_t *)(hard + (size_t)M),
+                           (const uint32_t *)(hcnt + 1));
+        // <= 16 on the caller's stream
+        hipLaunchKernelGGL((cl_fast<8, 1>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), hard, hcnt);
+        hipLaunchKernelGGL((cl_fast<16, 1>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
+                           (const uint32_t *)(cnts + 1), hard, hcnt);
+        hipLaunchKernelGGL((cl_agglom<16, 1>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)hard, (const uint32_t *)(hcnt + 0));
+    }
+    for (int i = 0; i < 3; ++i) {
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[i], ctx->cl_side[i]));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[i], 0));
+    }
     // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
-    hipLaunchKernelGGL(cl_pcat, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, tmpA);
-    launch_scan<0>(tmpA, M, spart, tmpB, res->n_cands, st);       // tmpB[s] = first candidate of the partition at s
-    p.cbase = tmpB;
+    hipLaunchKernelGGL(cl_pcat, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, pcat);
+    launch_scan<0>(pcat, M, spart, cbase, res->n_cands, st);      // cbase[s] = first candidate of the partition at s
+    p.cbase = cbase;
     p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
     p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
-    hipLaunchKernelGGL(cl_emit, dim3(grid), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB);
     HIP_TRY(ctx, hipGetLastError());
+    if (getenv("DUET_CL_DEBUG")) {
+        uint32_t h[16];
+        HIP_TRY(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u hard %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11]);
+    }
     return DUET_OK;
 }
 

@@ -923,10 +923,12 @@ duet_ctx *duet_ctx_create(int device_id)
     }
     duet_ctx *ctx = new duet_ctx();
     ctx->device = device_id;
-    if ((e = hipStreamCreateWithFlags(&ctx->cl_side, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->cl_fork, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->cl_join, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    e = hipEventCreateWithFlags(&ctx->cl_fork, hipEventDisableTiming);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&ctx->cl_side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cl_join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         duet_g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         delete ctx;
         return nullptr;
@@ -949,9 +951,11 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf &b : ctx->cl_out) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->sv_ws) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-    if (ctx->cl_side) (void)hipStreamDestroy(ctx->cl_side);
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->cl_side[i]) (void)hipStreamDestroy(ctx->cl_side[i]);
+        if (ctx->cl_join[i]) (void)hipEventDestroy(ctx->cl_join[i]);
+    }
     if (ctx->cl_fork) (void)hipEventDestroy(ctx->cl_fork);
-    if (ctx->cl_join) (void)hipEventDestroy(ctx->cl_join);
     delete ctx;
 }
 

@@ -35,8 +35,8 @@ struct duet_ctx {
     // clustering (A0) workspace and host-run staging
     DevBuf cl_ws[14], cl_in[4], cl_out[6];
     DevBuf sv_ws[5];                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
-    hipStream_t cl_side = nullptr;         // side stream + fork/join events for the large-partition kernel
-    hipEvent_t cl_fork = nullptr, cl_join = nullptr;
+    hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
+    hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};
     // profiling events: 6 per run
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;

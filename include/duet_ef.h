@@ -130,7 +130,10 @@ int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pr
  * collect into *stats, and reset. */
 int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 
-/* Diagnostics: low bits ablate kernel phases (tools/ablate.py).  0 in production. */
+/* Diagnostics: low bits ablate E/F kernel phases (tools/ablate.py); DUET_DBG_CLUSTER_EXACT sends every A0
+ * partition through the exact binary64 agglomeration instead of the threshold-graph fast path (the outputs are
+ * identical; tests use it to exercise both).  0 in production. */
+#define DUET_DBG_CLUSTER_EXACT 0x100u
 int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags);
 
 /* Debug/inspection: copy contig k's sorted seed-PS array of the LAST run to `out` (capacity `cap`),

@@ -22,12 +22,17 @@ def ctx():
 
 def check(ctx, marks, **kw):
     want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
-    for hints in (True, False):
-        got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
+    # hints on/off (sort key width), threshold-graph fast path on/off (DUET_DBG_CLUSTER_EXACT = 0x100)
+    for hints, dbg in ((True, 0), (False, 0), (True, 0x100)):
+        ctx.set_debug(dbg)
+        try:
+            got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
+        finally:
+            ctx.set_debug(0)
         for f in FIELDS:
             assert got[f].shape == want[f].shape, (f, got[f].shape, want[f].shape)
             bad = np.nonzero(got[f] != want[f])[0]
-            assert bad.size == 0, (f, bad[:5], got[f][bad[:5]], want[f][bad[:5]])
+            assert bad.size == 0, (f, dbg, bad[:5], got[f][bad[:5]], want[f][bad[:5]])
     return want
 
 
@@ -38,6 +43,36 @@ def random_marks(seed, M, clumps=40, contigs=3, types=3, spread=60, span_lo=50, 
     span = np.where(rng.chance(M, 1, 2), (span // 100) * 100 + rng.between(M, 0, 8), span)
     return dict(contig=rng.below(M, contigs).astype(np.uint16), type=rng.below(M, types).astype(np.uint8),
                 pos=pos.astype(np.uint32), span=span.astype(np.uint32))
+
+
+def sv_like_marks(seed, n_sv):
+    """SV-like input: tight groups of jittered marks, neighbours at distances spread around the thresholds --
+    what the threshold-graph fast path (atoms, then linkage over atoms) is made for, including its refusals."""
+    rng = synth.SplitMix(31000 + seed)
+    near = rng.between(n_sv, 0, 1300)
+    gap = np.where(rng.chance(n_sv, 2, 3), near, 2500 + near)
+    centre = 10000 + np.cumsum(gap)
+    span = rng.between(n_sv, 60, 3000)
+    same = rng.chance(n_sv, 1, 2)
+    for i in range(1, n_sv):                       # every other SV inherits (roughly) its neighbour's span
+        if same[i]:
+            span[i] = max(1, int(span[i - 1] * (0.6 + 0.01 * (near[i] % 80))))
+    per = 1 + rng.below(n_sv, 25)
+    pj = np.array([0, 5, 40, 150])[rng.below(n_sv, 4)]
+    sj = np.array([0, 2, 6, 15])[rng.below(n_sv, 4)]
+    sv = np.repeat(np.arange(n_sv), per)
+    M = len(sv)
+    p = centre[sv] + rng.between(M, 0, 301) * pj[sv] // 300
+    sp = np.maximum(span[sv] * (100 + rng.between(M, 0, 31) * sj[sv] // 30) // 100, 0)
+    perm = rng.permutation(M) if hasattr(rng, 'permutation') else np.argsort(rng.below(M, 1 << 30), kind='stable')
+    return dict(contig=((sv // 400) % 2).astype(np.uint16)[perm], type=((sv // 200) % 2).astype(np.uint8)[perm],
+                pos=p.astype(np.uint32)[perm], span=sp.astype(np.uint32)[perm])
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_sv_like_marks(ctx, seed):
+    marks = sv_like_marks(seed, 1500)
+    check(ctx, marks, max_dist=[0.9, 0.3, 0.5, 0.7, 1.2, 0.9, 0.15, 0.45][seed], part_max=[100, 100, 128, 100, 60, 100, 100, 100][seed])
 
 
 @pytest.mark.parametrize('seed', range(6))
@@ -63,6 +98,31 @@ def test_big_partitions_hit_the_cap(ctx):
     check(ctx, marks, part_max=128, max_dist=0.4)
     check(ctx, marks, part_max=37, part_gap=5)
     assert len(want['cand_off']) - 1 < M
+
+
+def test_threshold_exactly_on_a_pair_distance(ctx):
+    """max_dist equal to pair distances that occur (d = k/900 for equal spans, d = 1/3 + ...): the fast path's
+    guard band must hand these partitions to the exact agglomeration."""
+    M = 4000
+    rng = synth.SplitMix(99)
+    pos = 50000 + rng.between(M, 0, 40) * 2000 + rng.between(M, 0, 5) * 90
+    span = np.where(rng.chance(M, 1, 3), 300, 200)
+    marks = dict(contig=np.zeros(M, dtype=np.uint16), type=np.zeros(M, dtype=np.uint8), pos=pos.astype(np.uint32),
+                 span=span.astype(np.uint32))
+    for md in (0.1, 0.2, 90 / 900, 180 / 900, 1 / 3, 1 / 3 + 0.1, 0.0, 1e-300, -1.0, 1e9, float('inf')):
+        check(ctx, marks, max_dist=md)
+
+
+def test_positions_near_the_32_bit_edge(ctx):
+    M = 900
+    rng = synth.SplitMix(5)
+    pos = 0xFFFFFFFF - rng.between(M, 0, 3000)
+    span = rng.between(M, 0, 6000)
+    marks = dict(contig=np.zeros(M, dtype=np.uint16), type=np.zeros(M, dtype=np.uint8), pos=pos.astype(np.uint32),
+                 span=span.astype(np.uint32))
+    check(ctx, marks)
+    check(ctx, marks, normalizer=1e-4)
+    check(ctx, marks, normalizer=1e12, max_dist=1e-7)
 
 
 def test_zero_spans_and_identical_marks(ctx):

@@ -6,7 +6,7 @@ import numpy as np
 from duet_amd import _lib, synth
 from oracle import c_oracle
 from tests import soa_fuzz
-from tests.test_gpu_cluster import random_marks, FIELDS
+from tests.test_gpu_cluster import random_marks, sv_like_marks, FIELDS
 
 n_ef = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n_cl = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -36,9 +36,13 @@ t0 = time.time()
 badc = 0
 for i in range(n_cl):
     M = 1 + rng.one(20000)
-    marks = random_marks(9000 + i, M, clumps=1 + rng.one(60), contigs=1 + rng.one(4), types=1 + rng.one(4),
-                         spread=1 + rng.one(1500), span_lo=1 + rng.one(100), span_hi=200 + rng.one(5000))
-    kw = dict(max_dist=[0.1, 0.3, 0.9, 1.5][rng.one(4)], part_gap=[10, 1000, 5000][rng.one(3)], part_max=[7, 100, 128][rng.one(3)])
+    if i % 2:
+        marks = sv_like_marks(9000 + i, 1 + rng.one(2500))
+        M = len(marks['pos'])
+    else:
+        marks = random_marks(9000 + i, M, clumps=1 + rng.one(60), contigs=1 + rng.one(4), types=1 + rng.one(4),
+                             spread=1 + rng.one(1500), span_lo=1 + rng.one(100), span_hi=200 + rng.one(5000))
+    kw = dict(max_dist=[0.1, 0.3, 0.9, 1.5, 0.5, 0.7][rng.one(6)], part_gap=[10, 1000, 5000][rng.one(3)], part_max=[7, 100, 128][rng.one(3)])
     want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
     got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
     if any(got[f].shape != want[f].shape or not np.array_equal(got[f], want[f]) for f in FIELDS):
