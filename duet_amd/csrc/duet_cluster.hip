@@ -612,58 +612,62 @@ struct BitSet {
             if (w[i]) return 64u * i + (uint32_t)__ffsll((long long)w[i]) - 1u;
         return 64u * (NW - 1) + (uint32_t)__ffsll((long long)w[NW - 1]) - 1u;
     }
-    __device__ __forceinline__ bool test(uint32_t j) const { return (w[NW == 1 ? 0 : j >> 6] >> (j & 63u)) & 1ull; }
+    // (no dynamically indexed w[]: that would put the set in scratch memory)
+    __device__ __forceinline__ bool test(uint32_t j) const
+    {
+        uint64_t x = w[0];
+        for (int i = 1; i < NW; ++i) x = (j >> 6) == (uint32_t)i ? w[i] : x;
+        return (x >> (j & 63u)) & 1ull;
+    }
+    __device__ __forceinline__ void set_if(bool c, uint32_t j)
+    {
+        for (int i = 0; i < NW; ++i) w[i] |= (c && (NW == 1 || (j >> 6) == (uint32_t)i)) ? 1ull << (j & 63u) : 0ull;
+    }
     __device__ __forceinline__ bool equals(const BitSet &o) const { bool e = true; for (int i = 0; i < NW; ++i) e = e && w[i] == o.w[i]; return e; }
 };
 
 __device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
 
 constexpr int kLevels = 3;              // thresholds max_dist, max_dist / 2, max_dist / 4
-constexpr int kMaxAtoms = 4;
 
-// Average linkage over at most kMaxAtoms "atoms" (clusters already known to form first), every lane of the group
-// running the same steps on the group's LDS scratch: D[a][b] the atoms' average distances (a < b used), sz their
-// sizes, lab[a] the atom that a's cluster is named after (its smallest atom).  Returns false when a decision --
-// which pair is closest, whether it is within max_dist -- is not safe against a 1e-4 relative error of D.
-__device__ __forceinline__ bool atoms_linkage(uint32_t m, double (*D)[kMaxAtoms], double *sz, uint32_t *lab, double max_dist)
+// Average linkage over m <= KA "atoms" (clusters already known to form first), every lane of the group running
+// the same steps on the group's LDS scratch: D[a * KA + b] (a < b) the atoms' average distances, sz their sizes,
+// lab[a] the atom that a's cluster is named after (its smallest atom).  Returns false when a decision -- which
+// pair is closest, whether it is within max_dist -- is not safe against a 1e-4 relative error of D.
+template <int KA>
+__device__ __forceinline__ bool atoms_linkage(uint32_t m, double *D, double *sz, uint32_t *lab, double max_dist)
 {
-    bool alive[kMaxAtoms];
-#pragma unroll
-    for (int a = 0; a < kMaxAtoms; ++a) alive[a] = (uint32_t)a < m;
+    uint32_t alive = m >= 32 ? ~0u : (1u << m) - 1u;
     for (uint32_t step = 0; step + 1 < m; ++step) {
         double d1 = __builtin_inf(), d2 = __builtin_inf();
-        int a1 = 0, b1 = 1;
-#pragma unroll
-        for (int a = 0; a < kMaxAtoms; ++a)
-#pragma unroll
-            for (int b = a + 1; b < kMaxAtoms; ++b) {
-                if (!alive[a] || !alive[b]) continue;
-                const double v = D[a][b];
+        uint32_t a1 = 0, b1 = 1;
+        for (uint32_t a = 0; a + 1 < m; ++a) {
+            if (!((alive >> a) & 1u)) continue;
+            for (uint32_t b = a + 1; b < m; ++b) {
+                if (!((alive >> b) & 1u)) continue;
+                const double v = D[a * KA + b];
                 if (v < d1) { d2 = d1; d1 = v; a1 = a; b1 = b; }
                 else if (v < d2) d2 = v;
             }
+        }
         if (!(d2 > d1 * (1.0 + 1e-4))) return false;                       // a near-tie for the closest pair
         if (!(fabs(d1 - max_dist) > 1e-4 * max_dist)) return false;         // too close to the threshold to call
         if (d1 > max_dist) break;
         const double na = sz[a1], nb = sz[b1];
-#pragma unroll
-        for (int c = 0; c < kMaxAtoms; ++c) {
-            if (!alive[c] || c == a1 || c == b1) continue;
-            const double da = c < a1 ? D[c][a1] : D[a1][c], db = c < b1 ? D[c][b1] : D[b1][c];
-            const double v = (na * da + nb * db) / (na + nb);
-            if (c < a1) D[c][a1] = v; else D[a1][c] = v;
+        for (uint32_t c = 0; c < m; ++c) {
+            if (!((alive >> c) & 1u) || c == a1 || c == b1) continue;
+            const uint32_t ia = c < a1 ? c * KA + a1 : a1 * KA + c, ib = c < b1 ? c * KA + b1 : b1 * KA + c;
+            D[ia] = (na * D[ia] + nb * D[ib]) / (na + nb);
         }
         sz[a1] = na + nb;
-#pragma unroll
-        for (int c = 0; c < kMaxAtoms; ++c) {
-            if (c == b1) alive[c] = false;
-            if (lab[c] == (uint32_t)b1) lab[c] = (uint32_t)a1;
-        }
+        alive &= ~(1u << b1);
+        for (uint32_t c = 0; c < m; ++c)
+            if (lab[c] == b1) lab[c] = a1;
     }
     return true;
 }
 
-template <int GROUP, int R>
+template <int GROUP, int R, int KA>
 __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *list, const uint32_t *count, uint32_t *hard_list,
                                               uint32_t *hard_count)
 {
@@ -672,8 +676,8 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
     __shared__ uint2 s_ps[SUBS][NMAX];                       // (pos, span)
     __shared__ uint64_t s_mask[SUBS][NMAX][NW];
     __shared__ uint8_t s_atom[SUBS][NMAX];
-    __shared__ double s_D[SUBS][kMaxAtoms][kMaxAtoms], s_sz[SUBS][kMaxAtoms];
-    __shared__ uint32_t s_lab[SUBS][kMaxAtoms], s_aroot[SUBS][kMaxAtoms];
+    __shared__ double s_D[SUBS][KA][KA], s_sz[SUBS][KA];
+    __shared__ uint32_t s_lab[SUBS][KA], s_aroot[SUBS][KA];
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     const uint32_t L = *count;
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                 for (int l = 0; l < kLevels; ++l) {
                     const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
                     amb[l] = amb[l] || e_hi != e_lo;
-                    if (e_hi) N[l][r].w[NW == 1 ? 0 : j >> 6] |= 1ull << (j & 63u);
+                    N[l][r].set_if(e_hi, j);
                 }
             }
         }
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t k = sl + r * GROUP;
-                if (k < n) N[l][r].w[NW == 1 ? 0 : k >> 6] |= 1ull << (k & 63u);
+                N[l][r].set_if(k < n, k);
             }
         // every component of a level's graph is a clique <=> each mark's neighbourhood equals that of its
         // smallest member; leaves the level's masks in s_mask
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                 heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
             }
             const uint32_t m = heads.count();
-            two = two && m <= (uint32_t)kMaxAtoms;
+            two = two && m <= (uint32_t)KA;
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -801,16 +805,15 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                     }
                 }
             }
-            if (two && sl < kMaxAtoms * kMaxAtoms) s_D[sub][sl / kMaxAtoms][sl % kMaxAtoms] = 0.0;
-            if (GROUP < kMaxAtoms * kMaxAtoms && two && sl + GROUP < kMaxAtoms * kMaxAtoms)
-                s_D[sub][(sl + GROUP) / kMaxAtoms][(sl + GROUP) % kMaxAtoms] = 0.0;
+            if (two)
+                for (uint32_t e = sl; e < (uint32_t)(KA * KA); e += GROUP) s_D[sub][e / KA][e % KA] = 0.0;
             __syncthreads();
             if (__ballot(two)) {
-                float acc[R][kMaxAtoms];
+                float acc[R][KA];
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int b = 0; b < kMaxAtoms; ++b) acc[r][b] = 0.f;
+                    for (int b = 0; b < KA; ++b) acc[r][b] = 0.f;
                 const uint32_t n2 = two ? n : 0u;
                 for (uint32_t j = 0; j < n2; ++j) {
                     const uint2 q = s_ps[sub][j];
@@ -822,32 +825,27 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                         const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
                         const float d = (float)mm * p.inv_norm + fs * __builtin_amdgcn_rcpf(fm);
 #pragma unroll
-                        for (int b = 0; b < kMaxAtoms; ++b) acc[r][b] += aj == (uint32_t)b ? d : 0.f;
+                        for (int b = 0; b < KA; ++b) acc[r][b] += aj == (uint32_t)b ? d : 0.f;
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (two && sl + r * GROUP < n)
 #pragma unroll
-                        for (int b = 0; b < kMaxAtoms; ++b)
+                        for (int b = 0; b < KA; ++b)
                             if ((uint32_t)b != ai[r] && (uint32_t)b < m) atomicAdd(&s_D[sub][ai[r]][b], (double)acc[r][b]);
                 __syncthreads();
                 if (two) {
-                    // every lane of the group: averages into the upper triangle, then the linkage (same values
-                    // written by all lanes)
-#pragma unroll
-                    for (int a = 0; a < kMaxAtoms; ++a)
-#pragma unroll
-                        for (int b = a + 1; b < kMaxAtoms; ++b)
-                            if ((uint32_t)b < m) {
-                                const double v = (s_D[sub][a][b] + s_D[sub][b][a]) / (2.0 * s_sz[sub][a] * s_sz[sub][b]);
-                                __builtin_amdgcn_wave_barrier();
-                                s_D[sub][a][b] = v;
-                            }
+                    // averages into the upper triangle (lanes share the pairs), then every lane of the group
+                    // runs the linkage on them (all lanes write the same values)
+                    for (uint32_t e = sl; e < m * m; e += GROUP) {
+                        const uint32_t a = e / m, b = e % m;
+                        if (a < b) s_D[sub][a][b] = (s_D[sub][a][b] + s_D[sub][b][a]) / (2.0 * s_sz[sub][a] * s_sz[sub][b]);
+                    }
                 }
                 __syncthreads();
                 bool okl = false;
-                if (two) okl = atoms_linkage(m, s_D[sub], s_sz[sub], s_lab[sub], p.max_dist);
+                if (two) okl = atoms_linkage<KA>(m, &s_D[sub][0][0], s_sz[sub], s_lab[sub], p.max_dist);
                 __syncthreads();
                 if (two && okl) {
 #pragma unroll
@@ -1109,23 +1107,23 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[i], ctx->cl_fork, 0));
     {
         hipStream_t s3 = ctx->cl_side[0];                        // 65..128 marks
-        hipLaunchKernelGGL((cl_fast<64, 2>), dim3(grid), dim3(64), 0, s3, p, (const uint32_t *)(lists + 4 * (size_t)M),
+        hipLaunchKernelGGL((cl_fast<64, 2, 16>), dim3(grid), dim3(64), 0, s3, p, (const uint32_t *)(lists + 4 * (size_t)M),
                            (const uint32_t *)(cnts + 4), hard, hcnt);
         hipLaunchKernelGGL((cl_agglom<64, 2>), dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, s3, p,
                            (const uint32_t *)(hard + 3 * (size_t)M), (const uint32_t *)(hcnt + 3));
         hipStream_t s2 = ctx->cl_side[1];                        // 33..64
-        hipLaunchKernelGGL((cl_fast<64, 1>), dim3(grid), dim3(64), 0, s2, p, (const uint32_t *)(lists + 3 * (size_t)M),
+        hipLaunchKernelGGL((cl_fast<64, 1, 8>), dim3(grid), dim3(64), 0, s2, p, (const uint32_t *)(lists + 3 * (size_t)M),
                            (const uint32_t *)(cnts + 3), hard, hcnt);
         hipLaunchKernelGGL((cl_agglom<64, 1>), dim3(grid), dim3(64), 0, s2, p, (const uint32_t *)(hard + 2 * (size_t)M),
                            (const uint32_t *)(hcnt + 2));
         hipStream_t s1 = ctx->cl_side[2];                        // 17..32
-        hipLaunchKernelGGL((cl_fast<32, 1>), dim3(grid), dim3(64), 0, s1, p, (const uint32_t *)(lists + 2 * (size_t)M),
+        hipLaunchKernelGGL((cl_fast<32, 1, 4>), dim3(grid), dim3(64), 0, s1, p, (const uint32_t *)(lists + 2 * (size_t)M),
                            (const uint32_t *)(cnts + 2), hard, hcnt);
         hipLaunchKernelGGL((cl_agglom<32, 1>), dim3(grid), dim3(64), 0, s1, p, (const uint32_t *)(hard + (size_t)M),
                            (const uint32_t *)(hcnt + 1));
         // <= 16 on the caller's stream
-        hipLaunchKernelGGL((cl_fast<8, 1>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), hard, hcnt);
-        hipLaunchKernelGGL((cl_fast<16, 1>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
+        hipLaunchKernelGGL((cl_fast<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), hard, hcnt);
+        hipLaunchKernelGGL((cl_fast<16, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
                            (const uint32_t *)(cnts + 1), hard, hcnt);
         hipLaunchKernelGGL((cl_agglom<16, 1>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)hard, (const uint32_t *)(hcnt + 0));
     }

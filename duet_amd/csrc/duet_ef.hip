@@ -819,34 +819,40 @@ namespace {
 inline int fail(duet_ctx *ctx, int code, const std::string &msg) { return duet_fail(ctx, code, msg); }
 inline int reserve(duet_ctx *ctx, DevBuf &b, size_t bytes) { return duet_reserve(ctx, b, bytes); }
 
-// (re)build the workspace for this contig layout; a no-op when it matches the cached plan
+// (re)build the workspace for this contig layout; a no-op when it matches the cached plan.  The rebuild is
+// ordered on `stream` (uploads from a pinned staging block, memsets, one small kernel): the device is only
+// synchronised when a buffer has to grow or the context moves to another stream.
 int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
 {
     const uint32_t K = pr->n_contigs, C = pr->n_cands;
-    if (ctx->plan_C == C && ctx->plan_off.size() == (size_t)K + 1 &&
+    if (ctx->plan_C == C && ctx->plan_off.size() == (size_t)K + 1 && ctx->plan_stream == stream &&
         memcmp(ctx->plan_off.data(), pr->cand_ctg_off, sizeof(uint32_t) * (K + 1)) == 0)
         return DUET_OK;
     const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
-    // contig of the first candidate of every 256-candidate block
-    std::vector<uint32_t> blk_ctg(B);
-    {
-        uint32_t k = 0;
-        for (uint32_t b = 0; b < B; ++b) {
-            const uint32_t c = b * kCandPerBlock;
-            while (c >= pr->cand_ctg_off[k + 1]) ++k;
-            blk_ctg[b] = k;
-        }
-    }
     const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
+    const size_t want[6] = {small_words * 4, C, (size_t)B * kCandPerBlock * 8, ((size_t)C + K + 1) * 4, ((size_t)C + K + 1) * 4,
+                            (size_t)B * kC2Quota * kC2Words * 4};
+    DevBuf *bufs[6] = {&ctx->ws_small, &ctx->ws_start, &ctx->ws_ent, &ctx->ws_one, &ctx->ws_tmp, &ctx->ws_c2};
+    bool grow = ctx->plan_stream != stream;
+    for (int i = 0; i < 6; ++i) grow = grow || want[i] > bufs[i]->cap;
+    const size_t stage_bytes = ((size_t)K + 1 + B) * 4;
+    grow = grow || stage_bytes > ctx->plan_stage_cap;
     int rc;
-    // the previous plan's buffers may still be in use by work queued on a stream
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    if ((rc = reserve(ctx, ctx->ws_small, small_words * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_start, C))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_ent, (size_t)B * kCandPerBlock * 8))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_one, ((size_t)C + K + 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_tmp, ((size_t)C + K + 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->ws_c2, (size_t)B * kC2Quota * kC2Words * 4))) return rc;
+    if (grow) {
+        // buffers of the previous plan may still be in use by queued work
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        for (int i = 0; i < 6; ++i)
+            if ((rc = reserve(ctx, *bufs[i], want[i]))) return rc;
+        if (stage_bytes > ctx->plan_stage_cap) {
+            if (ctx->plan_stage) HIP_TRY(ctx, hipHostFree(ctx->plan_stage));
+            ctx->plan_stage = nullptr;
+            ctx->plan_stage_cap = 0;
+            HIP_TRY(ctx, hipHostMalloc((void **)&ctx->plan_stage, stage_bytes + stage_bytes / 4 + 4096, hipHostMallocDefault));
+            ctx->plan_stage_cap = stage_bytes + stage_bytes / 4 + 4096;
+        }
+    } else {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->plan_ev));        // the staging block's previous upload has been read
+    }
     uint32_t *w = (uint32_t *)ctx->ws_small.ptr;
     ctx->d_ctg_off = w;            w += K + 1;
     ctx->d_n_one = w;              w += K;
@@ -854,17 +860,28 @@ int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
     ctx->d_blk_ctg = w;            w += B;
     w += ((uintptr_t)w & 31) ? (32 - ((uintptr_t)w & 31)) / 4 : 0;        // 32-byte aligned tile records
     ctx->d_blk_cnt = w;            // B records of 4 x u64
-    HIP_TRY(ctx, hipMemcpy(ctx->d_ctg_off, pr->cand_ctg_off, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_blk_ctg, blk_ctg.data(), sizeof(uint32_t) * B, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(ctx->d_n_one, 0, sizeof(uint32_t) * ((size_t)K + 8)));
-    HIP_TRY(ctx, hipMemset(ctx->ws_start.ptr, 0, C));
-    hipLaunchKernelGGL(plan_mark_starts, dim3((K + 255) / 256), dim3(256), 0, 0, ctx->d_ctg_off, K,
+    // staging: ctg_off, then the contig of the first candidate of every 256-candidate block
+    uint32_t *h_off = ctx->plan_stage, *h_blk = ctx->plan_stage + (K + 1);
+    memcpy(h_off, pr->cand_ctg_off, sizeof(uint32_t) * (K + 1));
+    {
+        uint32_t k = 0;
+        for (uint32_t b = 0; b < B; ++b) {
+            const uint32_t c = b * kCandPerBlock;
+            while (c >= pr->cand_ctg_off[k + 1]) ++k;
+            h_blk[b] = k;
+        }
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctg_off, h_off, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, stream));
+    if (B) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blk_ctg, h_blk, sizeof(uint32_t) * B, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->plan_ev, stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_n_one, 0, sizeof(uint32_t) * ((size_t)K + 8), stream));
+    if (C) HIP_TRY(ctx, hipMemsetAsync(ctx->ws_start.ptr, 0, C, stream));
+    hipLaunchKernelGGL(plan_mark_starts, dim3((K + 255) / 256), dim3(256), 0, stream, ctx->d_ctg_off, K,
                        (uint8_t *)ctx->ws_start.ptr);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipDeviceSynchronize());
     ctx->plan_off.assign(pr->cand_ctg_off, pr->cand_ctg_off + K + 1);
     ctx->plan_C = C;
-    (void)stream;
+    ctx->plan_stream = stream;
     return DUET_OK;
 }
 
@@ -928,6 +945,7 @@ duet_ctx *duet_ctx_create(int device_id)
         e = hipStreamCreateWithFlags(&ctx->cl_side[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cl_join[i], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->plan_ev, hipEventDisableTiming);
     if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         duet_g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         delete ctx;
@@ -956,6 +974,8 @@ void duet_ctx_destroy(duet_ctx *ctx)
         if (ctx->cl_join[i]) (void)hipEventDestroy(ctx->cl_join[i]);
     }
     if (ctx->cl_fork) (void)hipEventDestroy(ctx->cl_fork);
+    if (ctx->plan_ev) (void)hipEventDestroy(ctx->plan_ev);
+    if (ctx->plan_stage) (void)hipHostFree(ctx->plan_stage);
     delete ctx;
 }
 

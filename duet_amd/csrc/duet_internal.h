@@ -26,6 +26,10 @@ struct duet_ctx {
     // E/F plan (workspace keyed by the contig layout)
     std::vector<uint32_t> plan_off;        // cached cand_ctg_off
     uint32_t plan_C = 0;
+    hipStream_t plan_stream = (hipStream_t)-1;   // the stream the plan was built on
+    uint32_t *plan_stage = nullptr;        // pinned staging block for the plan uploads
+    size_t plan_stage_cap = 0;
+    hipEvent_t plan_ev = nullptr;          // recorded after the staging block has been read
     DevBuf ws_small;                        // ctg_off | n_one | status | blk_ctg | blk_cnt
     DevBuf ws_start, ws_ent, ws_one, ws_tmp, ws_c2;
     uint32_t *d_ctg_off = nullptr, *d_n_one = nullptr, *d_status = nullptr, *d_blk_ctg = nullptr,
