@@ -5,18 +5,25 @@
 // so there is no reference code to follow; the rule implemented here is this repository's own deterministic
 // statement of the published SVIM 1.4.2 scheme, normative text in oracle/cluster_oracle.c / DESIGN.md section 9.
 //
-// Pipeline (all on one stream):
+// Pipeline:
 //   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, val = mark index
 //   radix sort     stable LSD, 8-bit digits: rx_hist -> scan -> rx_scatter per pass (ballot-ranked, no atomics
 //                  on the data path, so the order is deterministic)
-//   cl_heads1/2    partition starts: contig/type change, centre gap > part_gap, or part_max marks reached
-//   cl_parts       partition start list (from an exclusive scan of the head flags)
-//   cl_cluster     16 / 32 / 64 lanes per partition (one lane for <= 8 marks): span-position distances into an LDS
-//                  triangle (fp64), average linkage by repeated group-wide argmin + Lance-Williams update
-//   cl_emit        per partition: clusters by smallest member, members in sorted order -> order[], cand_*[]
+//   partitions     two scans straight off the sorted keys: a max-scan finds each position's natural partition start
+//                  (contig/type change or centre gap > part_gap) and stores the start flags (natural start, then
+//                  every part_max marks); a sum-scan of the flags stores partition ids and the partition start list
+//   cl_classes     work lists by partition size (<= 8 / 16 / 32 / 64 / 128 marks)
+//   cl_fast        per size class, GROUP lanes per partition: clusters read off the threshold graph where that is
+//                  provably what average linkage produces (see the comment above cl_fast); the rest -> "hard" lists
+//   cl_agglom      exact binary64 average linkage for the hard lists (nearest-neighbour cache per row)
+//                  both write, per mark, its place in the partition's output and, per cluster head, rank/end/means
+//   scan + cl_emit clusters per partition -> candidate bases; one thread per mark writes order[] and cand_*[]
+// The four size-class chains (fast pass, then exact pass) are independent and run on side streams.
 //
-// Bit-exactness vs the oracle: distances and updates are the same binary64 expressions in the same order
-// (-ffp-contract=off); the argmin breaks ties by the smallest (first, second) index pair.
+// Bit-exactness vs the oracle: what is emitted depends only on the final clusters; cl_agglom evaluates the same
+// binary64 expressions in the same order as the oracle (-ffp-contract=off; ties to the smallest (first, second)
+// index pair), and cl_fast only accepts partitions whose final clusters it can prove (guard bands wider than any
+// rounding error), so both produce the oracle's clusters.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -98,8 +105,56 @@ __global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint
 template <int OP>
 __device__ __forceinline__ uint32_t scan_op(uint32_t a, uint32_t b) { return OP == 0 ? a + b : (a > b ? a : b); }
 
-template <int OP>
-__global__ __launch_bounds__(kScanThreads) void scan_reduce(const uint32_t *in, uint32_t n, uint32_t *part)
+// element sources / sinks of the scans: what used to be separate elementwise kernels rides on the scan's own
+// loads and stores
+struct LoadPlain {
+    const uint32_t *in;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return in[i]; }
+};
+// i if sorted position i starts a natural partition (contig/type change or centre gap), else 0: everything needed
+// is in the sorted keys -- (contig, type) in the high bits, the centre in the low bits
+struct LoadHead {
+    const uint64_t *keys;
+    uint32_t centre_bits, part_gap;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const
+    {
+        if (i == 0) return 0u;
+        const uint64_t a = keys[i - 1], b = keys[i];
+        const uint64_t cm = (1ull << centre_bits) - 1ull;
+        const bool cut = (a >> centre_bits) != (b >> centre_bits) || (b & cm) - (a & cm) > (uint64_t)part_gap;
+        return cut ? i : 0u;
+    }
+};
+// clusters of the partition that starts at sorted position i, 0 elsewhere
+struct LoadPcat {
+    const uint32_t *flag, *pid, *pc;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return flag[i] ? pc[pid[i]] : 0u; }
+};
+struct StorePlain {
+    uint32_t *out;
+    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { out[i] = v; }
+};
+// v = start of i's natural partition (inclusive max of LoadHead): a partition starts there and every part_max marks after
+struct StoreFlag {
+    uint32_t *flag;
+    uint32_t part_max;
+    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { flag[i] = ((i - v) % part_max) == 0 ? 1u : 0u; }
+};
+// v = partitions that start before i (exclusive sum of the flags), in = i's own flag
+struct StoreParts {
+    uint32_t *pid, *part_start, *counters;
+    uint32_t M;
+    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t in) const
+    {
+        pid[i] = v;
+        if (in) part_start[v] = i;
+        if (i == M - 1) part_start[v + in] = M;
+        if (i < 12) counters[i] = 0;                          // class + hard list counts of the kernels that follow
+    }
+};
+
+template <int OP, class Load>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint32_t n, uint32_t *part)
 {
     __shared__ uint32_t s_w[kScanThreads / 64];
     const uint32_t tid = threadIdx.x;
@@ -107,7 +162,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_reduce(const uint32_t *in, 
     uint32_t acc = 0;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j)
-        if (base + j < n) acc = scan_op<OP>(acc, in[base + j]);
+        if (base + j < n) acc = scan_op<OP>(acc, in(base + j));
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc = scan_op<OP>(acc, __shfl_xor(acc, d, 64));
     if ((tid & 63) == 0) s_w[tid >> 6] = acc;
@@ -154,9 +209,8 @@ __global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, u
 }
 
 // out[i] = exclusive sum (OP 0) / inclusive max (OP 1) of in[0..i] given the per-tile carries in part[]
-template <int OP>
-__global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *in, uint32_t n, const uint32_t *part,
-                                                           uint32_t *out)
+template <int OP, class Load, class Store>
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32_t n, const uint32_t *part, const Store out)
 {
     __shared__ uint32_t s_w[kScanThreads / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -165,7 +219,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *in, u
     uint32_t acc = 0;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
-        v[j] = base + j < n ? in[base + j] : 0u;
+        v[j] = base + j < n ? in(base + j) : 0u;
         acc = scan_op<OP>(acc, v[j]);
     }
     uint32_t x = acc;
@@ -183,11 +237,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *in, u
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
         if (OP == 0) {
-            if (base + j < n) out[base + j] = run;
+            if (base + j < n) out(base + j, run, v[j]);
             run += v[j];
         } else {
             run = scan_op<OP>(run, v[j]);
-            if (base + j < n) out[base + j] = run;
+            if (base + j < n) out(base + j, run, v[j]);
         }
     }
 }
@@ -244,38 +298,6 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
 // partitions
 // ---------------------------------------------------------------------------------------------
 
-// headpos[i] = i if sorted position i starts a natural partition (contig/type change or centre gap), else 0.
-// Everything needed is in the sorted keys: (contig, type) in the high bits, the centre in the low bits.
-__global__ void cl_heads1(const ClParams p, const uint64_t *keys, uint32_t *headpos)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.M) return;
-    uint32_t h = 0;
-    if (i > 0) {
-        const uint64_t a = keys[i - 1], b = keys[i];
-        const uint64_t cm = (1ull << p.centre_bits) - 1ull;
-        const bool cut = (a >> p.centre_bits) != (b >> p.centre_bits) || (b & cm) - (a & cm) > (uint64_t)p.part_gap;
-        h = cut ? i : 0u;
-    }
-    headpos[i] = h;
-}
-
-// flag[i] = 1 if i starts a partition: natural head, or every part_max marks after it
-__global__ void cl_heads2(const ClParams p, const uint32_t *head_of, uint32_t *flag)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.M) return;
-    flag[i] = ((i - head_of[i]) % p.part_max) == 0 ? 1u : 0u;
-}
-
-__global__ void cl_parts(const ClParams p, const uint32_t *flag, const uint32_t *pid, uint32_t *part_start,
-                         const uint32_t *n_parts)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < p.M && flag[i]) part_start[pid[i]] = i;
-    if (i == 0) part_start[*n_parts] = p.M;
-}
-
 // work lists by partition size (which agglomeration kernel variant takes it); list order is irrelevant --
 // every partition writes to its own fixed output range -- so a (wave-aggregated) atomic append is fine
 constexpr int kClasses = 5;
@@ -304,14 +326,6 @@ __global__ __launch_bounds__(1024) void cl_classes(const ClParams p, uint32_t *l
     if (threadIdx.x < kClasses && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
     if (cls >= 0) lists[(size_t)cls * p.M + s_base[cls] + at] = part;
-}
-
-// pcat[i] = clusters of the partition that starts at sorted position i, 0 elsewhere (may alias flag)
-__global__ void cl_pcat(const ClParams p, const uint32_t *flag, const uint32_t *pid, uint32_t *pcat)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.M) return;
-    pcat[i] = flag[i] ? p.pc[pid[i]] : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -999,13 +1013,13 @@ uint32_t bits_for(uint64_t max_value)
     return b ? b : 1;
 }
 
-template <int OP>
-void launch_scan(const uint32_t *in, uint32_t n, uint32_t *part, uint32_t *out, uint32_t *total, hipStream_t st)
+template <int OP, class Load, class Store>
+void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uint32_t *total, hipStream_t st)
 {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(scan_reduce<OP>, dim3(nb), dim3(kScanThreads), 0, st, in, n, part);
+    hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part);
     hipLaunchKernelGGL(scan_spine<OP>, dim3(1), dim3(1024), 0, st, part, nb, total);
-    hipLaunchKernelGGL(scan_apply<OP>, dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out);
+    hipLaunchKernelGGL((scan_apply<OP, Load, Store>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out);
 }
 
 }  // namespace
@@ -1071,19 +1085,17 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     const uint32_t nh = 256 * nb_rx;
     for (uint32_t shift = 0; shift < key_bits; shift += 8) {
         hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, M, shift, nb_rx, hist);
-        launch_scan<0>(hist, nh, spart, hist, nullptr, st);      // in place: scan_apply reads a tile before writing it
+        launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st);     // in place: scan_apply reads a tile before writing it
         hipLaunchKernelGGL(rx_scatter, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin,
                            (const uint32_t *)vin, M, shift, nb_rx, (const uint32_t *)hist, kout, vout);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
     }
     p.sorted = vin;
-    hipLaunchKernelGGL(cl_heads1, g256, b256, 0, st, p, (const uint64_t *)kin, tmpA);
-    launch_scan<1>(tmpA, M, spart, tmpB, nullptr, st);            // tmpB[i] = start of i's natural partition
-    hipLaunchKernelGGL(cl_heads2, g256, b256, 0, st, p, (const uint32_t *)tmpB, tmpA);     // tmpA = head flags
-    launch_scan<0>(tmpA, M, spart, tmpB, scal, st);               // tmpB = partition id, scal[0] = #partitions
-    hipLaunchKernelGGL(cl_parts, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, part_start,
-                       (const uint32_t *)scal);
+    // partitions: natural starts by a max-scan straight off the sorted keys (stores the start flags), then a sum-scan
+    // of the flags that stores each position's partition id and the partition start list
+    launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap}, M, spart, StoreFlag{tmpA, p.part_max}, nullptr, st);
+    launch_scan<0>(LoadPlain{tmpA}, M, spart, StoreParts{tmpB, part_start, scal + 2, M}, scal, st);   // scal[0] = #partitions
     p.part_start = part_start; p.n_parts = scal; p.pc = pc;
     p.e_info = e_info;
     p.e_pos = (uint32_t *)kout;                                   // the spare key buffer: 2 x M words
@@ -1099,7 +1111,6 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     }
     p.fast = (pr->max_dist >= 0 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
-    HIP_TRY(ctx, hipMemsetAsync(cnts, 0, 4 * 12, st));
     hipLaunchKernelGGL(cl_classes, dim3((M + 1023) / 1024), dim3(1024), 0, st, p, lists, cnts);
     // Four independent chains (a size class's fast pass, then the exact pass over what it declined); the long
     // serial merge chains of the few large partitions run on side streams beside the bulk.
@@ -1133,8 +1144,7 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     }
     // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
-    hipLaunchKernelGGL(cl_pcat, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB, pcat);
-    launch_scan<0>(pcat, M, spart, cbase, res->n_cands, st);      // cbase[s] = first candidate of the partition at s
+    launch_scan<0>(LoadPcat{tmpA, tmpB, pc}, M, spart, StorePlain{cbase}, res->n_cands, st);   // cbase[s] = first candidate of the partition at s
     p.cbase = cbase;
     p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
     p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
