@@ -199,7 +199,8 @@ def main():
     n_max = soa.n_cands                      # every rank has exactly 100000 candidates
     dp = DeviceProblem(soa, 50, 2, device='cuda:%d' % local_rank, n_cands_max=n_max, n_out=2 if world > 1 else 1)
 
-    dt, prof, iso, gathered = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod)
+    with torch.cuda.stream(torch.cuda.Stream()):             # a stream of its own, not the legacy default stream
+        dt, prof, iso, gathered = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod)
 
     # correctness of what was timed (rank-local, against the C oracle) -- outside the timed region
     pred, ps = dp.results((args.steps - 1) % len(dp.out_blocks))

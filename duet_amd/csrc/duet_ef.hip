@@ -1017,6 +1017,7 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     if ((rc = ensure_plan(ctx, pr, stream))) return rc;
 
     Params p;
+    memset(&p, 0, sizeof(p));
     p.K = pr->n_contigs; p.C = pr->n_cands; p.M = pr->n_marks;
     p.read_tag = pr->n_reads ? pr->read_tag : (const uint64_t *)ctx->d_n_one;   // always >= 1 readable word
     p.cand_pos = pr->cand_pos; p.cand_svlen = pr->cand_svlen; p.cand_svread = pr->cand_svread;
