@@ -246,26 +246,43 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32
     }
 }
 
-// stable scatter of one 8-bit digit; hist holds the scanned (digit-major) offsets
+// stable scatter of one 8-bit digit; hist holds the scanned (digit-major) offsets.
+// Each wave of a block owns a contiguous quarter of the block's 4096 keys and ranks it on its own (ballot match
+// inside the wave, a running per-digit count in the wave's LDS row: no workgroup barrier inside the loop; block
+// order = wave, round, lane = input order, so the sort stays stable).  The tile is then laid out digit-sorted in
+// LDS and written from there: consecutive lanes hold consecutive keys of one digit run, so each run leaves as whole
+// cache lines in one go.  (Writing straight from the ranking loop touched every run one 8-byte key at a time; with
+// thousands of blocks in flight the partly written lines fell out of L2 and the scatter ran at half this speed.)
 __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in, const uint32_t *vals_in, uint32_t n,
                                                          uint32_t shift, uint32_t nb, const uint32_t *hist,
                                                          uint64_t *keys_out, uint32_t *vals_out)
 {
-    __shared__ uint32_t s_base[256];
-    __shared__ uint32_t s_wcnt[kRxThreads / 64][256];
+    constexpr int kWaves = kRxThreads / 64, kPerWave = kRxTile / kWaves;
+    __shared__ uint64_t s_key[kRxTile];
+    __shared__ uint32_t s_val[kRxTile];
+    __shared__ uint32_t s_gbase[256];                      // global position of the block's first key of each digit
+    __shared__ uint32_t s_start[256];                      // where each digit starts inside the tile
+    __shared__ uint32_t s_wloc[kWaves][256];               // per wave: keys of each digit so far; then the wave's offset
+    __shared__ uint32_t s_wsum[kWaves];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    s_base[tid] = hist[(size_t)tid * nb + blockIdx.x];
+    s_gbase[tid] = hist[(size_t)tid * nb + blockIdx.x];
 #pragma unroll
-    for (int w = 0; w < kRxThreads / 64; ++w) s_wcnt[w][tid] = 0;
+    for (int w = 0; w < kWaves; ++w) s_wloc[w][tid] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kRxTile;
+    const uint32_t base = blockIdx.x * kRxTile, wbase = base + wave * kPerWave;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint64_t key[kRxItems];
+    uint32_t val[kRxItems], lrank[kRxItems];
+#pragma unroll
     for (int it = 0; it < kRxItems; ++it) {
-        const uint32_t i = base + it * kRxThreads + tid;
-        const bool valid = i < n;
-        const uint64_t key = valid ? keys_in[i] : 0ull;
-        const uint32_t val = valid ? vals_in[i] : 0u;
-        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        const uint32_t i = wbase + it * 64 + lane;
+        key[it] = i < n ? keys_in[i] : ~0ull;
+        val[it] = i < n ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        const bool valid = wbase + it * 64 + lane < n;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
         unsigned long long same = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -274,23 +291,57 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
             same &= bit ? bm : ~bm;
         }
         const uint32_t rank = (uint32_t)__popcll(same & lt);
-        if (valid && rank == 0) s_wcnt[wave][d] = (uint32_t)__popcll(same);
-        __syncthreads();
-        if (valid) {
-            uint32_t at = s_base[d] + rank;
-            for (uint32_t w = 0; w < wave; ++w) at += s_wcnt[w][d];
-            keys_out[at] = key;
-            vals_out[at] = val;
-        }
-        __syncthreads();
-        uint32_t tot = 0;
+        const uint32_t seen = s_wloc[wave][d];
+        lrank[it] = seen + rank;
+        __builtin_amdgcn_wave_barrier();                   // every lane has read the count before its leader bumps it
+        if (valid && rank == 0) s_wloc[wave][d] = seen + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // digit starts inside the tile (exclusive scan of the digit totals over the 256 threads) and, per wave, the
+    // keys of the same digit in earlier waves
+    {
+        uint32_t t = 0;
 #pragma unroll
-        for (int w = 0; w < kRxThreads / 64; ++w) {
-            tot += s_wcnt[w][tid];
-            s_wcnt[w][tid] = 0;
+        for (int w = 0; w < kWaves; ++w) {
+            const uint32_t c = s_wloc[w][tid];
+            s_wloc[w][tid] = t;
+            t += c;
         }
-        s_base[tid] += tot;
+        uint32_t x = t;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t y = __shfl_up(x, dd, 64);
+            if ((int)lane >= dd) x += y;
+        }
+        if (lane == 63) s_wsum[wave] = x;
         __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < wave; ++w) carry += s_wsum[w];
+        s_start[tid] = carry + x - t;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        if (wbase + it * 64 + lane < n) {
+            const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
+            const uint32_t at = s_start[d] + s_wloc[wave][d] + lrank[it];
+            s_key[at] = key[it];
+            s_val[at] = val[it];
+        }
+    }
+    __syncthreads();
+    const uint32_t count = min((uint32_t)kRxTile, n - base);
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        const uint32_t q = it * kRxThreads + tid;
+        if (q < count) {
+            const uint64_t k = s_key[q];
+            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t at = s_gbase[d] + (q - s_start[d]);
+            keys_out[at] = k;
+            vals_out[at] = s_val[q];
+        }
     }
 }
 
