@@ -60,6 +60,8 @@ struct ClParams {
     const uint32_t *n_parts;                          // device scalar
     float inv_norm, t_lo[3], t_hi[3];                 // cl_fast: 1/normalizer; max_dist / {1, 2, 4} * (1 -/+ 1e-5) in binary32
     uint32_t fast;                                    // 0: parameters outside cl_fast's vetted range, everything goes to cl_agglom
+    uint8_t *label8;                                  // [M] per sorted position: its cluster's smallest member (row inside the partition)
+    uint8_t *comp8;                                   // [M] rows left to the exact pass: smallest row of their component; else 0xFF
     uint32_t *e_info, *e_pos, *e_span;                // [M] per sorted position: rank | end << 8 | cluster << 16 | head << 24; head means
     uint32_t *pc;                                     // [P] clusters per partition
     const uint32_t *cbase;                            // [M] at a partition's start position: its first candidate
@@ -142,14 +144,13 @@ struct StoreFlag {
 };
 // v = partitions that start before i (exclusive sum of the flags), in = i's own flag
 struct StoreParts {
-    uint32_t *pid, *part_start, *counters;
+    uint32_t *pid, *part_start;
     uint32_t M;
     __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t in) const
     {
         pid[i] = v;
         if (in) part_start[v] = i;
         if (i == M - 1) part_start[v + in] = M;
-        if (i < 12) counters[i] = 0;                          // class + hard list counts of the kernels that follow
     }
 };
 
@@ -176,8 +177,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint3
 
 // single block: part[i] <- combination of part[0..i) (exclusive); *total <- combination of everything
 template <int OP>
-__global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, uint32_t *total)
+__global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, uint32_t *total, uint32_t *zero14)
 {
+    if (zero14 && threadIdx.x < 14) zero14[threadIdx.x] = 0;     // the work-list counters of the kernels that follow
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -457,33 +459,51 @@ __device__ __forceinline__ double sp_distance(uint32_t pi, uint32_t spi, uint32_
     return dp + ds;
 }
 
+// Work item: one connected component of a partition's threshold graph (list entry = partition, then
+// root row | rows << 8), gathered in row order from the partition through comp8; writes label8 for its rows.
 template <int GROUP, int R>
-__global__ __launch_bounds__(64) void cl_agglom(const ClParams p, const uint32_t *list, const uint32_t *count)
+struct ExactSmem {
+    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, S = NMAX | 1;
+    double d[SUBS][NMAX * S];
+    uint32_t pos[SUBS][NMAX], span[SUBS][NMAX], size[SUBS][NMAX];
+    uint8_t row[SUBS][NMAX];
+};
+
+template <int GROUP, int R>
+__device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
 {
-    constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, S = NMAX | 1;
-    __shared__ double s_d[SUBS][NMAX * S];
-    __shared__ uint32_t s_pos[SUBS][NMAX], s_span[SUBS][NMAX], s_size[SUBS][NMAX];
-    __shared__ uint8_t s_lab[SUBS][NMAX];
+    constexpr int NMAX = GROUP * R, S = NMAX | 1;
+    ExactSmem<GROUP, R> &X = *reinterpret_cast<ExactSmem<GROUP, R> *>(smem);
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
-    double *D = s_d[sub];
-    const uint32_t L = *count;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    double *D = X.d[sub];
     const double inf = __builtin_inf();
-    for (uint32_t base = blockIdx.x * SUBS; base < L; base += gridDim.x * SUBS) {
+    {
         const uint32_t li = base + sub;
         const bool has = li < L;
-        const uint32_t part = has ? list[li] : 0u;
+        const uint32_t part = has ? list[2 * (size_t)li] : 0u, item = has ? list[2 * (size_t)li + 1] : 0u;
         const uint32_t s = has ? p.part_start[part] : 0u;
-        const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+        const uint32_t np = has ? p.part_start[part + 1] - s : 0u;       // rows of the partition
+        const uint32_t root = item & 0xFFu, n = has ? item >> 8 : 0u;    // n = rows of the component
         __syncthreads();
+        // gather the component's rows, in row order
+        uint32_t filled = 0;
+        uint32_t np_max = np;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t k = sl + r * GROUP;
-            if (k < n) {
-                const uint32_t a = p.sorted[s + k];
-                s_pos[sub][k] = p.pos[a];
-                s_span[sub][k] = p.span[a];
-                s_size[sub][k] = 1;
+        for (int d = 32; d > 0; d >>= 1) np_max = max(np_max, (uint32_t)__shfl_xor((int)np_max, d, 64));
+        for (uint32_t k0 = 0; k0 < np_max; k0 += GROUP) {
+            const uint32_t row = k0 + sl;
+            const bool mem = row < np && p.comp8[s + row] == root;
+            const unsigned long long bal = (__ballot(mem) >> (sub * GROUP)) & gm;
+            if (mem) {
+                const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
+                const uint32_t a = p.sorted[s + row];
+                X.pos[sub][ci] = p.pos[a];
+                X.span[sub][ci] = p.span[a];
+                X.size[sub][ci] = 1;
+                X.row[sub][ci] = (uint8_t)row;
             }
+            filled += (uint32_t)__popcll(bal);
         }
         __syncthreads();
         // every unordered pair once: row k takes the columns k+1 .. k+n/2 (mod n); for even n the distance-n/2
@@ -493,12 +513,12 @@ __global__ __launch_bounds__(64) void cl_agglom(const ClParams p, const uint32_t
         for (int r = 0; r < R; ++r) {
             const uint32_t k = sl + r * GROUP;
             if (k < n) {
-                const uint32_t pk = s_pos[sub][k], spk = s_span[sub][k];
+                const uint32_t pk = X.pos[sub][k], spk = X.span[sub][k];
                 const uint32_t tmax = (!(n & 1u) && k >= half) ? half - 1 : half;
                 for (uint32_t t = 1; t <= tmax; ++t) {
                     uint32_t j = k + t;
                     j = j >= n ? j - n : j;
-                    const double v = sp_distance(pk, spk, s_pos[sub][j], s_span[sub][j], p.normalizer);
+                    const double v = sp_distance(pk, spk, X.pos[sub][j], X.span[sub][j], p.normalizer);
                     D[k * S + j] = v;
                     D[j * S + k] = v;
                 }
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(64) void cl_agglom(const ClParams p, const uint32_t
             if (__ballot(do_merge)) {
                 const uint32_t a = g, b = info & 0xFFFFu;
                 uint32_t za = 0, zb = 0;
-                if (do_merge) { za = s_size[sub][a]; zb = s_size[sub][b]; }
+                if (do_merge) { za = X.size[sub][a]; zb = X.size[sub][b]; }
                 const double na = (double)za, nb = (double)zb;
                 double cv[R];
 #pragma unroll
@@ -591,50 +611,40 @@ __global__ __launch_bounds__(64) void cl_agglom(const ClParams p, const uint32_t
                     if (do_merge && k == a) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; }
                     if (do_merge && k == b) alive[r] = false;
                 }
-                if (do_merge && sl == 0) s_size[sub][a] = za + zb;
+                if (do_merge && sl == 0) X.size[sub][a] = za + zb;
             }
             __syncthreads();
         }
-        // what cl_emit needs, while the partition is still in LDS: each mark's place in the partition's output
-        // and, at each cluster's smallest member, the cluster's rank, end and floor means
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (sl + r * GROUP < n) s_lab[sub][sl + r * GROUP] = (uint8_t)lab[r];
-        __syncthreads();
-        uint32_t roots = 0, cr[R], before[R], sameb[R], size[R];
-        uint64_t sp[R], ss[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { cr[r] = before[r] = sameb[r] = size[r] = 0; sp[r] = ss[r] = 0; }
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t lj = s_lab[sub][j], pj = s_pos[sub][j], spj = s_span[sub][j];
-            const bool isroot = lj == j;
-            roots += isroot;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP, my = lab[r];
-                cr[r] += isroot && j < my;
-                before[r] += lj < my;
-                const bool same = lj == my;
-                sameb[r] += same && j < k;
-                size[r] += same;
-                sp[r] += same ? pj : 0u;
-                ss[r] += same ? spj : 0u;
-            }
-        }
+        // the component's clusters, named after their smallest row of the partition
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t k = sl + r * GROUP;
-            if (k < n) {
-                const bool root = lab[r] == k;
-                p.e_info[s + k] = (before[r] + sameb[r]) | ((before[r] + size[r]) << 8) | (cr[r] << 16) | (root ? 1u << 24 : 0u);
-                if (root) {
-                    p.e_pos[s + k] = (uint32_t)(sp[r] / size[r]);
-                    p.e_span[s + k] = (uint32_t)(ss[r] / size[r]);
-                }
-            }
+            if (k < n) p.label8[s + X.row[sub][k]] = X.row[sub][lab[r]];
         }
-        if (has && sl == 0) p.pc[part] = roots;
     }
+}
+
+// components of up to 64 rows, every size class in one launch (largest first); the rare larger ones have a launch
+// of their own (their distance matrix takes most of a CU's LDS)
+__global__ __launch_bounds__(64) void cl_exact_small(const ClParams p, const uint32_t *lists, const uint32_t *cnts)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 1>)];
+    static_assert(sizeof(ExactSmem<64, 1>) >= sizeof(ExactSmem<32, 1>) && sizeof(ExactSmem<64, 1>) >= sizeof(ExactSmem<16, 1>), "");
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2];
+    const uint32_t b2 = c2, b1 = b2 + (c1 + 1) / 2, b0 = b1 + (c0 + 3) / 4;
+    const size_t M = p.M;
+    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
+        if (vb < b2) exact_unit<64, 1>(p, lists + 2 * M, c2, vb, smem);
+        else if (vb < b1) exact_unit<32, 1>(p, lists + 1 * M, c1, (vb - b2) * 2, smem);
+        else exact_unit<16, 1>(p, lists, c0, (vb - b1) * 4, smem);
+    }
+}
+
+__global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint32_t *list, const uint32_t *count)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 2>)];
+    const uint32_t L = *count;
+    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2>(p, list, L, vb, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -693,6 +703,82 @@ struct BitSet {
 
 __device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
 
+// What cl_emit needs, per mark: its place in the partition's output, and at each cluster's smallest member the
+// cluster's rank, end and floor means.  F[r] = the cluster (bit set over the partition's rows) of this lane's row
+// sl + r * GROUP; groups with go == false only keep the collective operations company.  Uses s_mask as scratch.
+template <int GROUP, int R, int NW, int NMAX>
+__device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t part, uint32_t s, uint32_t n, uint32_t sub,
+                                          uint32_t sl, const BitSet<NW> (&F)[R], uint64_t (*s_mask)[NW], const uint2 *s_ps)
+{
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    __syncthreads();
+    uint32_t rt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        rt[r] = k < n ? F[r].first() : k;
+        if (go && k < n)
+            for (int i = 0; i < NW; ++i) s_mask[k][i] = F[r].w[i];
+    }
+    __syncthreads();
+    BitSet<NW> heads;                                       // cluster heads of the group, held by every lane of the group
+    heads.clear();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long b = (__ballot(go && sl + r * GROUP < n && rt[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
+        heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+    }
+    if (!go) return;
+    uint32_t before[R];
+    uint64_t sp[R], ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { before[r] = 0; sp[r] = ss[r] = 0; }
+    for (int i = 0; i < NW; ++i) {
+        uint64_t hm = heads.w[i];
+        while (hm) {
+            const uint32_t h = 64u * i + (uint32_t)__ffsll((long long)hm) - 1u;
+            hm &= hm - 1ull;
+            uint32_t sz = 0;
+            for (int c = 0; c < NW; ++c) sz += __popcll(s_mask[h][c]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) before[r] += h < rt[r] ? sz : 0u;
+        }
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint2 q = s_ps[j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool in = F[r].test(j);
+            sp[r] += in ? q.x : 0u;
+            ss[r] += in ? q.y : 0u;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        if (k < n) {
+            const bool head = rt[r] == k;
+            const uint32_t size = F[r].count();
+            p.e_info[s + k] = (before[r] + F[r].count_below(k)) | ((before[r] + size) << 8) |
+                              (heads.count_below(rt[r]) << 16) | (head ? 1u << 24 : 0u);
+            if (head) {
+                p.e_pos[s + k] = (uint32_t)(sp[r] / size);
+                p.e_span[s + k] = (uint32_t)(ss[r] / size);
+            }
+        }
+    }
+    if (sl == 0) p.pc[part] = heads.count();
+}
+
+// work lists the fast pass leaves behind: per size class of the components (<= 16 / 32 / 64 / 128 rows) the
+// components for cl_exact (two words each), per size class of the partitions the partitions for cl_rank
+struct ClWork {
+    uint32_t *comp_list;      // [4][M]
+    uint32_t *comp_count;     // [4]
+    uint32_t *rank_list;      // [kClasses][M]
+    uint32_t *rank_count;     // [kClasses]
+};
+
 constexpr int kLevels = 3;              // thresholds max_dist, max_dist / 2, max_dist / 4
 
 // Average linkage over m <= KA "atoms" (clusters already known to form first), every lane of the group running
@@ -733,21 +819,28 @@ __device__ __forceinline__ bool atoms_linkage(uint32_t m, double *D, double *sz,
 }
 
 template <int GROUP, int R, int KA>
-__global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *list, const uint32_t *count, uint32_t *hard_list,
-                                              uint32_t *hard_count)
+struct FastSmem {
+    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
+    uint2 ps[SUBS][NMAX];                                    // (pos, span)
+    uint64_t mask[SUBS][NMAX][NW];
+    double D[SUBS][KA][KA], sz[SUBS][KA];
+    uint32_t csz[SUBS][NMAX];                                // rows per component, at the component's smallest row
+    uint32_t lab[SUBS][KA], aroot[SUBS][KA];
+    uint8_t atom[SUBS][NMAX];
+};
+
+// one wave's worth of partitions (64 / GROUP of them, list[base ...]) of one size class
+template <int GROUP, int R, int KA>
+__device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, const ClWork &work,
+                                          unsigned char *smem)
 {
-    constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
+    constexpr int NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
     static_assert(NMAX <= 128 && (R == 1 || (GROUP * R) % 64 == 0 || GROUP * R <= 64), "unsupported shape");
-    __shared__ uint2 s_ps[SUBS][NMAX];                       // (pos, span)
-    __shared__ uint64_t s_mask[SUBS][NMAX][NW];
-    __shared__ uint8_t s_atom[SUBS][NMAX];
-    __shared__ double s_D[SUBS][KA][KA], s_sz[SUBS][KA];
-    __shared__ uint32_t s_lab[SUBS][KA], s_aroot[SUBS][KA];
+    FastSmem<GROUP, R, KA> &S = *reinterpret_cast<FastSmem<GROUP, R, KA> *>(smem);
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
-    const uint32_t L = *count;
     auto group_any = [&](bool x) -> bool { return ((__ballot(x) >> (sub * GROUP)) & gm) != 0ull; };
-    for (uint32_t base = blockIdx.x * SUBS; base < L; base += gridDim.x * SUBS) {
+    {
         const uint32_t li = base + sub;
         const bool has = li < L;
         const uint32_t part = has ? list[li] : 0u;
@@ -764,7 +857,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                 const uint32_t a = p.sorted[s + k];
                 pk[r] = p.pos[a];
                 spk[r] = p.span[a];
-                s_ps[sub][k] = make_uint2(pk[r], spk[r]);
+                S.ps[sub][k] = make_uint2(pk[r], spk[r]);
             }
             ek[r] = pk[r] + spk[r];
             ck[r] = pk[r] + (spk[r] >> 1);
@@ -773,7 +866,9 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
         __syncthreads();
         // closed neighbourhoods at the three thresholds; amb: some pair sits inside a threshold's guard band
         BitSet<NW> N[kLevels][R];
-        bool amb[kLevels];
+        bool amb[kLevels], amb0r[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) amb0r[r] = false;
 #pragma unroll
         for (int l = 0; l < kLevels; ++l) {
             amb[l] = false;
@@ -781,7 +876,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
             for (int r = 0; r < R; ++r) N[l][r].clear();
         }
         for (uint32_t j = 0; j < n; ++j) {
-            const uint2 q = s_ps[sub][j];
+            const uint2 q = S.ps[sub][j];
             const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -792,6 +887,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                 for (int l = 0; l < kLevels; ++l) {
                     const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
                     amb[l] = amb[l] || e_hi != e_lo;
+                    if (l == 0) amb0r[r] = amb0r[r] || e_hi != e_lo;
                     N[l][r].set_if(e_hi, j);
                 }
             }
@@ -811,7 +907,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
             for (int r = 0; r < R; ++r) {
                 const uint32_t k = sl + r * GROUP;
                 if (k < n)
-                    for (int i = 0; i < NW; ++i) s_mask[sub][k][i] = Nl[r].w[i];
+                    for (int i = 0; i < NW; ++i) S.mask[sub][k][i] = Nl[r].w[i];
             }
             __syncthreads();
             bool differs = false;
@@ -821,7 +917,7 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                 if (k < n) {
                     const uint32_t f = Nl[r].first();
                     BitSet<NW> o;
-                    for (int i = 0; i < NW; ++i) o.w[i] = s_mask[sub][f][i];
+                    for (int i = 0; i < NW; ++i) o.w[i] = S.mask[sub][f][i];
                     differs = differs || !o.equals(Nl[r]);
                 }
             }
@@ -861,17 +957,17 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                 const uint32_t k = sl + r * GROUP;
                 ai[r] = two ? heads.count_below(ra[r]) : 0u;
                 if (two && k < n) {
-                    for (int i = 0; i < NW; ++i) s_mask[sub][k][i] = A[r].w[i];      // the chosen level's atoms
-                    s_atom[sub][k] = (uint8_t)ai[r];
+                    for (int i = 0; i < NW; ++i) S.mask[sub][k][i] = A[r].w[i];      // the chosen level's atoms
+                    S.atom[sub][k] = (uint8_t)ai[r];
                     if (ra[r] == k) {
-                        s_aroot[sub][ai[r]] = k;
-                        s_sz[sub][ai[r]] = (double)A[r].count();
-                        s_lab[sub][ai[r]] = ai[r];
+                        S.aroot[sub][ai[r]] = k;
+                        S.sz[sub][ai[r]] = (double)A[r].count();
+                        S.lab[sub][ai[r]] = ai[r];
                     }
                 }
             }
             if (two)
-                for (uint32_t e = sl; e < (uint32_t)(KA * KA); e += GROUP) s_D[sub][e / KA][e % KA] = 0.0;
+                for (uint32_t e = sl; e < (uint32_t)(KA * KA); e += GROUP) S.D[sub][e / KA][e % KA] = 0.0;
             __syncthreads();
             if (__ballot(two)) {
                 float acc[R][KA];
@@ -881,8 +977,8 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                     for (int b = 0; b < KA; ++b) acc[r][b] = 0.f;
                 const uint32_t n2 = two ? n : 0u;
                 for (uint32_t j = 0; j < n2; ++j) {
-                    const uint2 q = s_ps[sub][j];
-                    const uint32_t aj = s_atom[sub][j];
+                    const uint2 q = S.ps[sub][j];
+                    const uint32_t aj = S.atom[sub][j];
                     const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -898,97 +994,241 @@ __global__ __launch_bounds__(64) void cl_fast(const ClParams p, const uint32_t *
                     if (two && sl + r * GROUP < n)
 #pragma unroll
                         for (int b = 0; b < KA; ++b)
-                            if ((uint32_t)b != ai[r] && (uint32_t)b < m) atomicAdd(&s_D[sub][ai[r]][b], (double)acc[r][b]);
+                            if ((uint32_t)b != ai[r] && (uint32_t)b < m) atomicAdd(&S.D[sub][ai[r]][b], (double)acc[r][b]);
                 __syncthreads();
                 if (two) {
                     // averages into the upper triangle (lanes share the pairs), then every lane of the group
                     // runs the linkage on them (all lanes write the same values)
                     for (uint32_t e = sl; e < m * m; e += GROUP) {
                         const uint32_t a = e / m, b = e % m;
-                        if (a < b) s_D[sub][a][b] = (s_D[sub][a][b] + s_D[sub][b][a]) / (2.0 * s_sz[sub][a] * s_sz[sub][b]);
+                        if (a < b) S.D[sub][a][b] = (S.D[sub][a][b] + S.D[sub][b][a]) / (2.0 * S.sz[sub][a] * S.sz[sub][b]);
                     }
                 }
                 __syncthreads();
                 bool okl = false;
-                if (two) okl = atoms_linkage<KA>(m, &s_D[sub][0][0], s_sz[sub], s_lab[sub], p.max_dist);
+                if (two) okl = atoms_linkage<KA>(m, &S.D[sub][0][0], S.sz[sub], S.lab[sub], p.max_dist);
                 __syncthreads();
                 if (two && okl) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const uint32_t mine = s_lab[sub][ai[r]];
+                        const uint32_t mine = S.lab[sub][ai[r]];
                         F[r].clear();
                         for (uint32_t b = 0; b < m; ++b)
-                            if (s_lab[sub][b] == mine)
-                                for (int i = 0; i < NW; ++i) F[r].w[i] |= s_mask[sub][s_aroot[sub][b]][i];
+                            if (S.lab[sub][b] == mine)
+                                for (int i = 0; i < NW; ++i) F[r].w[i] |= S.mask[sub][S.aroot[sub][b]][i];
                     }
                     solved = true;
                 }
             }
         }
-        if (!solved) {
-            if (has && sl == 0) {
-                const uint32_t hc = n <= 16 ? 0u : (n <= 32 ? 1u : (n <= 64 ? 2u : 3u));
-                hard_list[(size_t)hc * p.M + atomicAdd(&hard_count[hc], 1u)] = part;
+        if (__ballot(has && !solved)) {
+            // Not settled as a whole: settle it component by component.  A row is clean when it and all its
+            // neighbours (level 0) have guard-band-free neighbourhoods equal to that of their smallest member: its
+            // component is then a clique and one cluster.  The other rows are labelled with the smallest row of their
+            // component (min-label propagation over the neighbourhoods) and handed to cl_exact component by
+            // component; cl_rank finishes the partition once every row has its label.
+            const bool todo = has && !solved;
+            __syncthreads();
+            BitSet<NW> pass;
+            pass.clear();
+            bool clean[R];
+            // s_mask may hold another level by now: put level 0 back, then test the rows
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                if (todo && k < n)
+                    for (int i = 0; i < NW; ++i) S.mask[sub][k][i] = N[0][r].w[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                bool ok = todo && !unfit && k < n && !amb0r[r];
+                if (ok) {
+                    const uint32_t f = N[0][r].first();
+                    BitSet<NW> o;
+                    for (int i = 0; i < NW; ++i) o.w[i] = S.mask[sub][f][i];
+                    ok = o.equals(N[0][r]);
+                }
+                const unsigned long long b = (__ballot(ok) >> (sub * GROUP)) & gm;
+                pass.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+            }
+            uint32_t lab[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                bool c = todo && !unfit && k < n;
+                for (int i = 0; i < NW; ++i) c = c && (N[0][r].w[i] & ~pass.w[i]) == 0ull;
+                clean[r] = c;
+                lab[r] = unfit ? 0u : k;                     // unfit: the masks mean nothing, the partition is one component
+                if (todo && k < n) { S.atom[sub][k] = (uint8_t)lab[r]; S.csz[sub][k] = 0; }
+            }
+            __syncthreads();
+            for (;;) {
+                bool changed = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t k = sl + r * GROUP;
+                    if (todo && !unfit && k < n && !clean[r]) {
+                        uint32_t m = lab[r];
+                        for (int i = 0; i < NW; ++i) {
+                            uint64_t w = N[0][r].w[i];
+                            while (w) {
+                                const uint32_t j = 64u * i + (uint32_t)__ffsll((long long)w) - 1u;
+                                w &= w - 1ull;
+                                m = min(m, (uint32_t)S.atom[sub][j]);
+                            }
+                        }
+                        changed = changed || m != lab[r];
+                        lab[r] = m;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (todo && sl + r * GROUP < n && !clean[r]) S.atom[sub][sl + r * GROUP] = (uint8_t)lab[r];
+                __syncthreads();
+                if (!__ballot(changed)) break;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (todo && sl + r * GROUP < n && !clean[r]) atomicAdd(&S.csz[sub][lab[r]], 1u);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t k = sl + r * GROUP;
+                if (todo && k < n) {
+                    p.label8[s + k] = clean[r] ? (uint8_t)N[0][r].first() : (uint8_t)0xFF;
+                    p.comp8[s + k] = clean[r] ? (uint8_t)0xFF : (uint8_t)lab[r];
+                    if (!clean[r] && lab[r] == k) {
+                        const uint32_t m = S.csz[sub][k];
+                        const uint32_t hc = m <= 16 ? 0u : (m <= 32 ? 1u : (m <= 64 ? 2u : 3u));
+                        const uint32_t at = atomicAdd(&work.comp_count[hc], 1u);
+                        work.comp_list[(size_t)hc * p.M + 2 * (size_t)at] = part;
+                        work.comp_list[(size_t)hc * p.M + 2 * (size_t)at + 1] = k | (m << 8);
+                    }
+                }
+            }
+            if (todo && sl == 0) {
+                const int rc = size_class(n);
+                work.rank_list[(size_t)rc * p.M + atomicAdd(&work.rank_count[rc], 1u)] = part;
             }
         }
-        // cluster heads of the group, as a bit set every lane of the group holds
+        emit_prep<GROUP, R, NW, NMAX>(p, has && solved, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub]);
+    }
+}
+
+// every size class in one launch, largest partitions first (they are the longest chains): a virtual block is one
+// wave's worth of partitions of one class
+constexpr size_t kFastSmemBytes = sizeof(FastSmem<64, 2, 16>) > sizeof(FastSmem<8, 1, 4>) ? sizeof(FastSmem<64, 2, 16>) : sizeof(FastSmem<8, 1, 4>);
+static_assert(kFastSmemBytes >= sizeof(FastSmem<64, 1, 8>) && kFastSmemBytes >= sizeof(FastSmem<32, 1, 4>) &&
+              kFastSmemBytes >= sizeof(FastSmem<16, 1, 4>), "shared scratch too small");
+
+// one size class per launch: what large inputs use (the fused kernel needs the registers of all five variants at
+// once, which halves the occupancy; with millions of partitions per class there is nothing to gain from fusing)
+template <int GROUP, int R, int KA>
+__global__ __launch_bounds__(64) void cl_fast_one(const ClParams p, const uint32_t *list, const uint32_t *count, const ClWork work)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(FastSmem<GROUP, R, KA>)];
+    const uint32_t L = *count;
+    for (uint32_t base = blockIdx.x * (64 / GROUP); base < L; base += gridDim.x * (64 / GROUP))
+        fast_unit<GROUP, R, KA>(p, list, L, base, work, smem);
+}
+
+__global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const ClWork work)
+{
+    __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3], c4 = cnts[4];
+    const uint32_t b4 = c4, b3 = b4 + c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    const size_t M = p.M;
+    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
+        if (vb < b4) fast_unit<64, 2, 16>(p, lists + 4 * M, c4, vb, work, smem);
+        else if (vb < b3) fast_unit<64, 1, 8>(p, lists + 3 * M, c3, vb - b4, work, smem);
+        else if (vb < b2) fast_unit<32, 1, 4>(p, lists + 2 * M, c2, (vb - b3) * 2, work, smem);
+        else if (vb < b1) fast_unit<16, 1, 4>(p, lists + 1 * M, c1, (vb - b2) * 4, work, smem);
+        else fast_unit<8, 1, 4>(p, lists, c0, (vb - b1) * 8, work, smem);
+    }
+}
+
+// Partitions the fast pass did not settle as a whole, after cl_exact: every row has its label; group the rows by
+// label and finish like cl_fast does.
+template <int GROUP, int R>
+struct RankSmem {
+    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
+    uint2 ps[SUBS][NMAX];
+    uint64_t mask[SUBS][NMAX][NW];
+};
+
+template <int GROUP, int R>
+__device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
+{
+    constexpr int NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
+    RankSmem<GROUP, R> &S = *reinterpret_cast<RankSmem<GROUP, R> *>(smem);
+    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    {
+        const uint32_t li = base + sub;
+        const bool has = li < L;
+        const uint32_t part = has ? list[li] : 0u;
+        const uint32_t s = has ? p.part_start[part] : 0u;
+        const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
         __syncthreads();
-        uint32_t rt[R];
+        uint32_t lab[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t k = sl + r * GROUP;
-            rt[r] = k < n ? F[r].first() : k;
-            if (k < n)
-                for (int i = 0; i < NW; ++i) s_mask[sub][k][i] = F[r].w[i];
+            lab[r] = 0xFFFFu;
+            if (k < n) {
+                const uint32_t a = p.sorted[s + k];
+                S.ps[sub][k] = make_uint2(p.pos[a], p.span[a]);
+                lab[r] = p.label8[s + k];
+            }
         }
-        __syncthreads();
-        BitSet<NW> heads;
+        BitSet<NW> heads, F[R];
         heads.clear();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const unsigned long long b = (__ballot(solved && sl + r * GROUP < n && rt[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
+            F[r].clear();
+            const unsigned long long b = (__ballot(lab[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
             heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
         }
-        if (!solved) continue;
-        uint32_t before[R];
-        uint64_t sp[R], ss[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { before[r] = 0; sp[r] = ss[r] = 0; }
-        for (int i = 0; i < NW; ++i) {
-            uint64_t hm = heads.w[i];
-            while (hm) {
-                const uint32_t h = 64u * i + (uint32_t)__ffsll((long long)hm) - 1u;
-                hm &= hm - 1ull;
-                uint32_t sz = 0;
-                for (int c = 0; c < NW; ++c) sz += __popcll(s_mask[sub][h][c]);
-#pragma unroll
-                for (int r = 0; r < R; ++r) before[r] += h < rt[r] ? sz : 0u;
-            }
-        }
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint2 q = s_ps[sub][j];
+        // one round per cluster head of any group of the wave (wave-uniform trip count: ballots inside)
+        BitSet<NW> left = heads;
+        for (;;) {
+            bool any = false;
+            for (int i = 0; i < NW; ++i) any = any || left.w[i] != 0ull;
+            if (!__ballot(any)) break;
+            const uint32_t h = any ? left.first() : 0xFFFFFFu;
+            BitSet<NW> mh;
+            mh.clear();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool in = F[r].test(j);
-                sp[r] += in ? q.x : 0u;
-                ss[r] += in ? q.y : 0u;
+                const unsigned long long b = (__ballot(any && lab[r] == h) >> (sub * GROUP)) & gm;
+                mh.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
             }
-        }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t k = sl + r * GROUP;
-            if (k < n) {
-                const bool head = rt[r] == k;
-                const uint32_t size = F[r].count();
-                p.e_info[s + k] = (before[r] + F[r].count_below(k)) | ((before[r] + size) << 8) |
-                                  (heads.count_below(rt[r]) << 16) | (head ? 1u << 24 : 0u);
-                if (head) {
-                    p.e_pos[s + k] = (uint32_t)(sp[r] / size);
-                    p.e_span[s + k] = (uint32_t)(ss[r] / size);
-                }
-            }
+            for (int r = 0; r < R; ++r)
+                if (any && lab[r] == h) F[r] = mh;
+            if (any)
+                for (int i = 0; i < NW; ++i) left.w[i] &= (h >> 6) == (uint32_t)i ? ~(1ull << (h & 63u)) : ~0ull;
         }
-        if (has && sl == 0) p.pc[part] = heads.count();
+        emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub]);
+    }
+}
+
+__global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(RankSmem<64, 2>)];
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3], c4 = cnts[4];
+    const uint32_t b4 = c4, b3 = b4 + c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    const size_t M = p.M;
+    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
+        if (vb < b4) rank_unit<64, 2>(p, lists + 4 * M, c4, vb, smem);
+        else if (vb < b3) rank_unit<64, 1>(p, lists + 3 * M, c3, vb - b4, smem);
+        else if (vb < b2) rank_unit<32, 1>(p, lists + 2 * M, c2, (vb - b3) * 2, smem);
+        else if (vb < b1) rank_unit<16, 1>(p, lists + 1 * M, c1, (vb - b2) * 4, smem);
+        else rank_unit<8, 1>(p, lists, c0, (vb - b1) * 8, smem);
     }
 }
 
@@ -1065,11 +1305,12 @@ uint32_t bits_for(uint64_t max_value)
 }
 
 template <int OP, class Load, class Store>
-void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uint32_t *total, hipStream_t st)
+void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uint32_t *total, hipStream_t st,
+                 uint32_t *zero14 = nullptr)
 {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part);
-    hipLaunchKernelGGL(scan_spine<OP>, dim3(1), dim3(1024), 0, st, part, nb, total);
+    hipLaunchKernelGGL(scan_spine<OP>, dim3(1), dim3(1024), 0, st, part, nb, total, zero14);
     hipLaunchKernelGGL((scan_apply<OP, Load, Store>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out);
 }
 
@@ -1101,7 +1342,7 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 64, (size_t)M * 4 * (kClasses + 4), ((size_t)M + 1) * 4 * 2};
+                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 64, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2};
     int rc;
     for (int i = 0; i < 14; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
@@ -1146,15 +1387,21 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     // partitions: natural starts by a max-scan straight off the sorted keys (stores the start flags), then a sum-scan
     // of the flags that stores each position's partition id and the partition start list
     launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap}, M, spart, StoreFlag{tmpA, p.part_max}, nullptr, st);
-    launch_scan<0>(LoadPlain{tmpA}, M, spart, StoreParts{tmpB, part_start, scal + 2, M}, scal, st);   // scal[0] = #partitions
+    launch_scan<0>(LoadPlain{tmpA}, M, spart, StoreParts{tmpB, part_start, M}, scal, st, scal + 2);   // scal[0] = #partitions
     p.part_start = part_start; p.n_parts = scal; p.pc = pc;
     p.e_info = e_info;
     p.e_pos = (uint32_t *)kout;                                   // the spare key buffer: 2 x M words
     p.e_span = p.e_pos + M;
     const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
-    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses + 4][M]: by size class, then the hard lists
-    uint32_t *hard = lists + (size_t)kClasses * M;
-    uint32_t *cnts = scal + 2, *hcnt = scal + 8;
+    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M] partitions by size class, then the work lists
+    uint32_t *cnts = scal + 2;
+    ClWork work;
+    work.comp_list = lists + (size_t)kClasses * M;               // [4][M]
+    work.rank_list = work.comp_list + 4 * (size_t)M;             // [kClasses][M]
+    work.comp_count = scal + 7;
+    work.rank_count = scal + 11;
+    p.label8 = (uint8_t *)ctx->cl_ws[13].ptr;
+    p.comp8 = p.label8 + M;
     p.inv_norm = (float)(1.0 / pr->normalizer);
     for (int l = 0; l < 3; ++l) {
         p.t_lo[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 - 1e-5));
@@ -1163,36 +1410,32 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     p.fast = (pr->max_dist >= 0 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
     hipLaunchKernelGGL(cl_classes, dim3((M + 1023) / 1024), dim3(1024), 0, st, p, lists, cnts);
-    // Four independent chains (a size class's fast pass, then the exact pass over what it declined); the long
-    // serial merge chains of the few large partitions run on side streams beside the bulk.
+    // fast pass (every size class in one launch), the exact agglomeration of the components it declined (the few of
+    // more than 64 rows on a side stream beside the rest), then the ranks of the partitions those belong to
+    const uint32_t gridw = M < 32768u ? M : 32768u;
+    if (M <= (4u << 20)) {
+        hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
+    } else {
+        hipLaunchKernelGGL((cl_fast_one<64, 2, 16>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 4 * (size_t)M),
+                           (const uint32_t *)(cnts + 4), work);
+        hipLaunchKernelGGL((cl_fast_one<64, 1, 8>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
+                           (const uint32_t *)(cnts + 3), work);
+        hipLaunchKernelGGL((cl_fast_one<32, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
+                           (const uint32_t *)(cnts + 2), work);
+        hipLaunchKernelGGL((cl_fast_one<16, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
+                           (const uint32_t *)(cnts + 1), work);
+        hipLaunchKernelGGL((cl_fast_one<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), work);
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
-    for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[i], ctx->cl_fork, 0));
-    {
-        hipStream_t s3 = ctx->cl_side[0];                        // 65..128 marks
-        hipLaunchKernelGGL((cl_fast<64, 2, 16>), dim3(grid), dim3(64), 0, s3, p, (const uint32_t *)(lists + 4 * (size_t)M),
-                           (const uint32_t *)(cnts + 4), hard, hcnt);
-        hipLaunchKernelGGL((cl_agglom<64, 2>), dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, s3, p,
-                           (const uint32_t *)(hard + 3 * (size_t)M), (const uint32_t *)(hcnt + 3));
-        hipStream_t s2 = ctx->cl_side[1];                        // 33..64
-        hipLaunchKernelGGL((cl_fast<64, 1, 8>), dim3(grid), dim3(64), 0, s2, p, (const uint32_t *)(lists + 3 * (size_t)M),
-                           (const uint32_t *)(cnts + 3), hard, hcnt);
-        hipLaunchKernelGGL((cl_agglom<64, 1>), dim3(grid), dim3(64), 0, s2, p, (const uint32_t *)(hard + 2 * (size_t)M),
-                           (const uint32_t *)(hcnt + 2));
-        hipStream_t s1 = ctx->cl_side[2];                        // 17..32
-        hipLaunchKernelGGL((cl_fast<32, 1, 4>), dim3(grid), dim3(64), 0, s1, p, (const uint32_t *)(lists + 2 * (size_t)M),
-                           (const uint32_t *)(cnts + 2), hard, hcnt);
-        hipLaunchKernelGGL((cl_agglom<32, 1>), dim3(grid), dim3(64), 0, s1, p, (const uint32_t *)(hard + (size_t)M),
-                           (const uint32_t *)(hcnt + 1));
-        // <= 16 on the caller's stream
-        hipLaunchKernelGGL((cl_fast<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), hard, hcnt);
-        hipLaunchKernelGGL((cl_fast<16, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
-                           (const uint32_t *)(cnts + 1), hard, hcnt);
-        hipLaunchKernelGGL((cl_agglom<16, 1>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)hard, (const uint32_t *)(hcnt + 0));
-    }
-    for (int i = 0; i < 3; ++i) {
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[i], ctx->cl_side[i]));
-        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[i], 0));
-    }
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+    hipLaunchKernelGGL(cl_exact_big, dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, ctx->cl_side[0], p,
+                       (const uint32_t *)(work.comp_list + 3 * (size_t)M), (const uint32_t *)(work.comp_count + 3));
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+    hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
+                       (const uint32_t *)work.comp_count);
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
+    hipLaunchKernelGGL(cl_rank_all, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.rank_list,
+                       (const uint32_t *)work.rank_count);
     // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
     launch_scan<0>(LoadPcat{tmpA, tmpB, pc}, M, spart, StorePlain{cbase}, res->n_cands, st);   // cbase[s] = first candidate of the partition at s
@@ -1205,7 +1448,7 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
         uint32_t h[16];
         HIP_TRY(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u hard %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11]);
+        fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u components %u %u %u %u partitions to rank %u %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
     }
     return DUET_OK;
 }
