@@ -56,6 +56,8 @@ struct ClParams {
     const uint8_t *type;
     const uint32_t *pos, *span;
     const uint32_t *sorted;                           // mark index at each sorted position
+    const uint2 *ps;                                  // (pos, span) per mark, side by side: one gather instead of two
+    const uint64_t *skeys;                            // the sorted keys (contig | type | centre)
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
     float inv_norm, t_lo[3], t_hi[3];                 // cl_fast: 1/normalizer; max_dist / {1, 2, 4} * (1 -/+ 1e-5) in binary32
@@ -77,12 +79,14 @@ __device__ __forceinline__ uint64_t centre_of(uint32_t pos, uint32_t span) { ret
 // keys + radix sort
 // ---------------------------------------------------------------------------------------------
 
-__global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals)
+__global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.M) return;
     const uint64_t hi = ((uint64_t)p.contig[i] << p.type_bits) | (uint64_t)p.type[i];
-    keys[i] = (hi << p.centre_bits) | centre_of(p.pos[i], p.span[i]);
+    const uint32_t ps_ = p.pos[i], sp_ = p.span[i];
+    keys[i] = (hi << p.centre_bits) | centre_of(ps_, sp_);
+    ps[i] = make_uint2(ps_, sp_);
     vals[i] = i;
 }
 
@@ -385,10 +389,10 @@ __global__ __launch_bounds__(1024) void cl_classes(const ClParams p, uint32_t *l
 // agglomeration
 // ---------------------------------------------------------------------------------------------
 //
-// GROUP lanes of a wavefront work on one partition of up to GROUP * R marks; lane sl owns the rows
-// sl, sl + GROUP, ... of the partition's full symmetric distance matrix in LDS (odd row stride: a lane reading
-// its own row at a group-uniform column is conflict-free).  A wave carries 64 / GROUP partitions in lockstep;
-// control flow is wave-uniform and groups that have nothing to do in a phase are predicated off.
+// GROUP lanes of a wavefront work on one component of up to GROUP * R marks; lane sl owns the rows
+// sl, sl + GROUP, ... of the component's distance matrix, whose upper triangle lives in LDS.  A wave carries
+// 64 / GROUP components in lockstep; control flow is wave-uniform and groups that have nothing to do in a phase
+// are predicated off.
 //
 // The oracle's merge step is "global argmin over the active upper triangle, ties to the smallest (row, col)".
 // Here every row caches (rmin, rarg) = its minimum over the active columns to its right and the smallest
@@ -463,8 +467,8 @@ __device__ __forceinline__ double sp_distance(uint32_t pi, uint32_t spi, uint32_
 // root row | rows << 8), gathered in row order from the partition through comp8; writes label8 for its rows.
 template <int GROUP, int R>
 struct ExactSmem {
-    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, S = NMAX | 1;
-    double d[SUBS][NMAX * S];
+    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R;
+    double d[SUBS][NMAX * (NMAX - 1) / 2];                   // upper triangle, row by row
     uint32_t pos[SUBS][NMAX], span[SUBS][NMAX], size[SUBS][NMAX];
     uint8_t row[SUBS][NMAX];
 };
@@ -472,12 +476,14 @@ struct ExactSmem {
 template <int GROUP, int R>
 __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
 {
-    constexpr int NMAX = GROUP * R, S = NMAX | 1;
+    constexpr int NMAX = GROUP * R;
     ExactSmem<GROUP, R> &X = *reinterpret_cast<ExactSmem<GROUP, R> *>(smem);
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     double *D = X.d[sub];
     const double inf = __builtin_inf();
+    // d(i, j), i < j, in the upper triangle: half the LDS of a square matrix, so twice the waves per CU
+    auto tri = [](uint32_t i, uint32_t j) -> uint32_t { return i * (2u * NMAX - i - 1u) / 2u + (j - i - 1u); };
     {
         const uint32_t li = base + sub;
         const bool has = li < L;
@@ -498,8 +504,9 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
             if (mem) {
                 const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
                 const uint32_t a = p.sorted[s + row];
-                X.pos[sub][ci] = p.pos[a];
-                X.span[sub][ci] = p.span[a];
+                const uint2 q = p.ps[a];
+                X.pos[sub][ci] = q.x;
+                X.span[sub][ci] = q.y;
                 X.size[sub][ci] = 1;
                 X.row[sub][ci] = (uint8_t)row;
             }
@@ -519,8 +526,7 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
                     uint32_t j = k + t;
                     j = j >= n ? j - n : j;
                     const double v = sp_distance(pk, spk, X.pos[sub][j], X.span[sub][j], p.normalizer);
-                    D[k * S + j] = v;
-                    D[j * S + k] = v;
+                    D[k < j ? tri(k, j) : tri(j, k)] = v;
                 }
             }
         }
@@ -537,7 +543,7 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
             alive[r] = k < n;
             stale[r] = false;
             for (uint32_t j = k + 1; j < n; ++j) {
-                const double v = D[k * S + j];
+                const double v = D[tri(k, j)];
                 if (v < rmin[r]) { rmin[r] = v; rarg[r] = j; }
             }
         }
@@ -566,7 +572,7 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t k = sl + r * GROUP;
-                    cv[r] = (do_rescan && alive[r] && k > g) ? D[k * S + g] : inf;
+                    cv[r] = (do_rescan && alive[r] && k > g) ? D[tri(g, k)] : inf;
                 }
                 double nv;
                 uint32_t nc;
@@ -586,10 +592,10 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
                     const uint32_t k = sl + r * GROUP;
                     cv[r] = inf;
                     if (do_merge && alive[r] && k != a && k != b) {
-                        const double da = D[k * S + a], db = D[k * S + b];
+                        const uint32_t ia = k < a ? tri(k, a) : tri(a, k);
+                        const double da = D[ia], db = D[k < b ? tri(k, b) : tri(b, k)];
                         const double v = (na * da + nb * db) / (na + nb);
-                        D[k * S + a] = v;
-                        D[a * S + k] = v;
+                        D[ia] = v;
                         if (k < a) {
                             const bool hit = rarg[r] == a || rarg[r] == b;
                             if (v < rmin[r]) { rmin[r] = v; rarg[r] = a; stale[r] = false; }
@@ -701,14 +707,15 @@ struct BitSet {
     __device__ __forceinline__ bool equals(const BitSet &o) const { bool e = true; for (int i = 0; i < NW; ++i) e = e && w[i] == o.w[i]; return e; }
 };
 
-__device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+__device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b) { return __usad(a, b, 0u); }      // v_sad_u32
 
 // What cl_emit needs, per mark: its place in the partition's output, and at each cluster's smallest member the
 // cluster's rank, end and floor means.  F[r] = the cluster (bit set over the partition's rows) of this lane's row
 // sl + r * GROUP; groups with go == false only keep the collective operations company.  Uses s_mask as scratch.
 template <int GROUP, int R, int NW, int NMAX>
 __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t part, uint32_t s, uint32_t n, uint32_t sub,
-                                          uint32_t sl, const BitSet<NW> (&F)[R], uint64_t (*s_mask)[NW], const uint2 *s_ps)
+                                          uint32_t sl, const BitSet<NW> (&F)[R], uint64_t (*s_mask)[NW], const uint2 *s_ps,
+                                          unsigned long long (*s_sum)[2])
 {
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     __syncthreads();
@@ -717,8 +724,22 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
     for (int r = 0; r < R; ++r) {
         const uint32_t k = sl + r * GROUP;
         rt[r] = k < n ? F[r].first() : k;
-        if (go && k < n)
+        if (go && k < n) {
             for (int i = 0; i < NW; ++i) s_mask[k][i] = F[r].w[i];
+            s_sum[k][0] = 0;
+            s_sum[k][1] = 0;
+        }
+    }
+    __syncthreads();
+    // every mark adds its (pos, span) to its cluster's sums, kept at the cluster head
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        if (go && k < n) {
+            const uint2 q = s_ps[k];
+            atomicAdd(&s_sum[rt[r]][0], (unsigned long long)q.x);
+            atomicAdd(&s_sum[rt[r]][1], (unsigned long long)q.y);
+        }
     }
     __syncthreads();
     BitSet<NW> heads;                                       // cluster heads of the group, held by every lane of the group
@@ -730,9 +751,8 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
     }
     if (!go) return;
     uint32_t before[R];
-    uint64_t sp[R], ss[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { before[r] = 0; sp[r] = ss[r] = 0; }
+    for (int r = 0; r < R; ++r) before[r] = 0;
     for (int i = 0; i < NW; ++i) {
         uint64_t hm = heads.w[i];
         while (hm) {
@@ -744,15 +764,6 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
             for (int r = 0; r < R; ++r) before[r] += h < rt[r] ? sz : 0u;
         }
     }
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint2 q = s_ps[j];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool in = F[r].test(j);
-            sp[r] += in ? q.x : 0u;
-            ss[r] += in ? q.y : 0u;
-        }
-    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t k = sl + r * GROUP;
@@ -762,8 +773,10 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
             p.e_info[s + k] = (before[r] + F[r].count_below(k)) | ((before[r] + size) << 8) |
                               (heads.count_below(rt[r]) << 16) | (head ? 1u << 24 : 0u);
             if (head) {
-                p.e_pos[s + k] = (uint32_t)(sp[r] / size);
-                p.e_span[s + k] = (uint32_t)(ss[r] / size);
+                // floor means.  A sum stays below 2^40 and size <= 128, so the correctly rounded binary64 quotient
+                // lies strictly between the same two integers as the true one (or is that integer): no 64-bit division
+                p.e_pos[s + k] = (uint32_t)((double)s_sum[k][0] / (double)size);
+                p.e_span[s + k] = (uint32_t)((double)s_sum[k][1] / (double)size);
             }
         }
     }
@@ -777,6 +790,7 @@ struct ClWork {
     uint32_t *comp_count;     // [4]
     uint32_t *rank_list;      // [kClasses][M]
     uint32_t *rank_count;     // [kClasses]
+    uint32_t *why;            // diagnostics (DUET_CL_DEBUG): why the whole-partition test gave up, or null
 };
 
 constexpr int kLevels = 3;              // thresholds max_dist, max_dist / 2, max_dist / 4
@@ -825,6 +839,7 @@ struct FastSmem {
     uint64_t mask[SUBS][NMAX][NW];
     double D[SUBS][KA][KA], sz[SUBS][KA];
     uint32_t csz[SUBS][NMAX];                                // rows per component, at the component's smallest row
+    unsigned long long sum[SUBS][NMAX][2];
     uint32_t lab[SUBS][KA], aroot[SUBS][KA];
     uint8_t atom[SUBS][NMAX];
 };
@@ -855,8 +870,9 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
             pk[r] = spk[r] = 0;
             if (k < n) {
                 const uint32_t a = p.sorted[s + k];
-                pk[r] = p.pos[a];
-                spk[r] = p.span[a];
+                const uint2 q = p.ps[a];
+                pk[r] = q.x;
+                spk[r] = q.y;
                 S.ps[sub][k] = make_uint2(pk[r], spk[r]);
             }
             ek[r] = pk[r] + spk[r];
@@ -864,7 +880,8 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
             bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits: leave it to the exact path
         }
         __syncthreads();
-        // closed neighbourhoods at the three thresholds; amb: some pair sits inside a threshold's guard band
+        // closed neighbourhoods at the thresholds; amb: some pair sits inside a threshold's guard band.  Level 0
+        // (max_dist itself) for everybody; the finer levels only where level 0 does not settle the partition.
         BitSet<NW> N[kLevels][R];
         bool amb[kLevels], amb0r[R];
 #pragma unroll
@@ -883,22 +900,16 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
                 const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
                 const float dp = (float)m * p.inv_norm;
-#pragma unroll
-                for (int l = 0; l < kLevels; ++l) {
-                    const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
-                    amb[l] = amb[l] || e_hi != e_lo;
-                    if (l == 0) amb0r[r] = amb0r[r] || e_hi != e_lo;
-                    N[l][r].set_if(e_hi, j);
-                }
+                const bool e_hi = fs <= (p.t_hi[0] - dp) * fm, e_lo = fs <= (p.t_lo[0] - dp) * fm;
+                amb0r[r] = amb0r[r] || e_hi != e_lo;
+                N[0][r].set_if(e_hi, j);
             }
         }
 #pragma unroll
-        for (int l = 0; l < kLevels; ++l)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                N[l][r].set_if(k < n, k);
-            }
+        for (int r = 0; r < R; ++r) {
+            N[0][r].set_if(sl + r * GROUP < n, sl + r * GROUP);
+            amb[0] = amb[0] || amb0r[r];
+        }
         // every component of a level's graph is a clique <=> each mark's neighbourhood equals that of its
         // smallest member; leaves the level's masks in s_mask
         auto cliques = [&](const BitSet<NW> (&Nl)[R]) -> bool {
@@ -934,10 +945,32 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
             // atoms: the cliques of the finest usable level -- they are complete clusters before anything else
             // happens (every pair inside is closer than every pair across), so what remains is average linkage over
             // the atoms, decided from binary32 estimates of their average distances when that is safe
+            const uint32_t nw = want2 ? n : 0u;
+            for (uint32_t j = 0; j < nw; ++j) {
+                const uint2 q = S.ps[sub][j];
+                const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
+                    const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
+                    const float dp = (float)m * p.inv_norm;
+#pragma unroll
+                    for (int l = 1; l < kLevels; ++l) {
+                        const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
+                        amb[l] = amb[l] || e_hi != e_lo;
+                        N[l][r].set_if(e_hi, j);
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 1; l < kLevels; ++l)
+#pragma unroll
+                for (int r = 0; r < R; ++r) N[l][r].set_if(want2 && sl + r * GROUP < n, sl + r * GROUP);
             const bool amb2 = group_any(amb[2]), cl2 = cliques(N[2]);
             const bool amb1 = group_any(amb[1]), cl1 = cliques(N[1]);
             const bool ok2 = !amb2 && cl2, ok1 = !amb1 && cl1;
             bool two = want2 && (ok1 || ok2);
+            if (work.why && want2 && !two && sl == 0) atomicAdd(&work.why[GROUP == 64 ? (R == 2 ? 0 : 4) : 8], 1u);       // no clean level
             BitSet<NW> A[R];
             uint32_t ra[R], ai[R];
             BitSet<NW> heads;
@@ -950,6 +983,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
             }
             const uint32_t m = heads.count();
+            if (work.why && two && m > (uint32_t)KA && sl == 0) atomicAdd(&work.why[(GROUP == 64 ? (R == 2 ? 0 : 4) : 8) + 1], 1u);   // too many atoms
             two = two && m <= (uint32_t)KA;
             __syncthreads();
 #pragma unroll
@@ -1008,6 +1042,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 bool okl = false;
                 if (two) okl = atoms_linkage<KA>(m, &S.D[sub][0][0], S.sz[sub], S.lab[sub], p.max_dist);
                 __syncthreads();
+                if (work.why && two && !okl && sl == 0) atomicAdd(&work.why[(GROUP == 64 ? (R == 2 ? 0 : 4) : 8) + 2], 1u);       // a decision too close
                 if (two && okl) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -1115,7 +1150,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 work.rank_list[(size_t)rc * p.M + atomicAdd(&work.rank_count[rc], 1u)] = part;
             }
         }
-        emit_prep<GROUP, R, NW, NMAX>(p, has && solved, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub]);
+        emit_prep<GROUP, R, NW, NMAX>(p, has && solved, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub]);
     }
 }
 
@@ -1158,6 +1193,7 @@ struct RankSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
     uint2 ps[SUBS][NMAX];
     uint64_t mask[SUBS][NMAX][NW];
+    unsigned long long sum[SUBS][NMAX][2];
 };
 
 template <int GROUP, int R>
@@ -1181,7 +1217,7 @@ __device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *lis
             lab[r] = 0xFFFFu;
             if (k < n) {
                 const uint32_t a = p.sorted[s + k];
-                S.ps[sub][k] = make_uint2(p.pos[a], p.span[a]);
+                S.ps[sub][k] = p.ps[a];
                 lab[r] = p.label8[s + k];
             }
         }
@@ -1213,7 +1249,7 @@ __device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *lis
             if (any)
                 for (int i = 0; i < NW; ++i) left.w[i] &= (h >> 6) == (uint32_t)i ? ~(1ull << (h & 63u)) : ~0ull;
         }
-        emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub]);
+        emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub]);
     }
 }
 
@@ -1245,8 +1281,9 @@ __global__ void cl_emit(const ClParams p, const uint32_t *flag, const uint32_t *
     if (info >> 24) {
         const uint32_t cand = p.cbase[s] + ((info >> 16) & 0xFFu);
         p.cand_off[cand + 1] = s + ((info >> 8) & 0xFFu);
-        p.cand_contig[cand] = p.contig[a];
-        p.cand_type[cand] = p.type[a];
+        const uint64_t hi = p.skeys[i] >> p.centre_bits;                    // contig | type, straight from the sorted key
+        p.cand_contig[cand] = (uint16_t)(hi >> p.type_bits);
+        p.cand_type[cand] = (uint8_t)(hi & ((1ull << p.type_bits) - 1ull));
         p.cand_pos[cand] = p.e_pos[i];
         p.cand_span[cand] = p.e_span[i];
     }
@@ -1342,7 +1379,7 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 64, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2};
+                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 128, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2 + (size_t)M * 8};
     int rc;
     for (int i = 0; i < 14; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
@@ -1371,7 +1408,9 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     p.contig = pr->mark_contig; p.type = pr->mark_type; p.pos = pr->mark_pos; p.span = pr->mark_span;
 
     const dim3 g256((M + 255) / 256), b256(256);
-    hipLaunchKernelGGL(cl_keys, g256, b256, 0, st, p, keysA, valsA);
+    uint2 *ps = (uint2 *)((uint32_t *)ctx->cl_ws[13].ptr + 2 * ((size_t)M + 1));
+    hipLaunchKernelGGL(cl_keys, g256, b256, 0, st, p, keysA, valsA, ps);
+    p.ps = ps;
     uint64_t *kin = keysA, *kout = keysB;
     uint32_t *vin = valsA, *vout = valsB;
     const uint32_t nh = 256 * nb_rx;
@@ -1384,6 +1423,7 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
         uint32_t *tv = vin; vin = vout; vout = tv;
     }
     p.sorted = vin;
+    p.skeys = kin;
     // partitions: natural starts by a max-scan straight off the sorted keys (stores the start flags), then a sum-scan
     // of the flags that stores each position's partition id and the partition start list
     launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap}, M, spart, StoreFlag{tmpA, p.part_max}, nullptr, st);
@@ -1400,6 +1440,11 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     work.rank_list = work.comp_list + 4 * (size_t)M;             // [kClasses][M]
     work.comp_count = scal + 7;
     work.rank_count = scal + 11;
+    work.why = nullptr;
+    if (getenv("DUET_CL_DEBUG")) {
+        work.why = scal + 16;
+        HIP_TRY(ctx, hipMemsetAsync(work.why, 0, 64, st));
+    }
     p.label8 = (uint8_t *)ctx->cl_ws[13].ptr;
     p.comp8 = p.label8 + M;
     p.inv_norm = (float)(1.0 / pr->normalizer);
@@ -1445,10 +1490,12 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB);
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
-        uint32_t h[16];
+        uint32_t h[32];
         HIP_TRY(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u components %u %u %u %u partitions to rank %u %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+        fprintf(stderr, "[duet_cluster] gave up (no clean level / too many atoms / decision too close): >64: %u %u %u  33..64: %u %u %u  <=32: %u %u %u\n",
+                h[16], h[17], h[18], h[20], h[21], h[22], h[24], h[25], h[26]);
     }
     return DUET_OK;
 }
