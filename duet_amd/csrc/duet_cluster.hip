@@ -13,17 +13,19 @@
 //                  (contig/type change or centre gap > part_gap) and stores the start flags (natural start, then
 //                  every part_max marks); a sum-scan of the flags stores partition ids and the partition start list
 //   cl_classes     work lists by partition size (<= 8 / 16 / 32 / 64 / 128 marks)
-//   cl_fast        per size class, GROUP lanes per partition: clusters read off the threshold graph where that is
-//                  provably what average linkage produces (see the comment above cl_fast); the rest -> "hard" lists
-//   cl_agglom      exact binary64 average linkage for the hard lists (nearest-neighbour cache per row)
-//                  both write, per mark, its place in the partition's output and, per cluster head, rank/end/means
+//   fast pass      per size class, GROUP lanes per partition: clusters read off the threshold graph where that is
+//                  provably what average linkage produces (see the comment above fast_unit); what it cannot settle
+//                  goes, component by component, on work lists
+//   exact pass     binary64 average linkage for the listed components (nearest-neighbour cache per row)
+//   rank pass      finishes the partitions that had listed components
+//                  fast and rank passes write, per mark, its place in the partition's output and, per cluster head,
+//                  rank/end/means
 //   scan + cl_emit clusters per partition -> candidate bases; one thread per mark writes order[] and cand_*[]
-// The four size-class chains (fast pass, then exact pass) are independent and run on side streams.
 //
-// Bit-exactness vs the oracle: what is emitted depends only on the final clusters; cl_agglom evaluates the same
+// Bit-exactness vs the oracle: what is emitted depends only on the final clusters; the exact pass evaluates the same
 // binary64 expressions in the same order as the oracle (-ffp-contract=off; ties to the smallest (first, second)
-// index pair), and cl_fast only accepts partitions whose final clusters it can prove (guard bands wider than any
-// rounding error), so both produce the oracle's clusters.
+// index pair), and the fast pass only accepts clusters it can prove (guard bands wider than any rounding error),
+// so both produce the oracle's clusters.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -61,7 +63,12 @@ struct ClParams {
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
     float inv_norm, t_lo[3], t_hi[3];                 // cl_fast: 1/normalizer; max_dist / {1, 2, 4} * (1 -/+ 1e-5) in binary32
-    uint32_t fast;                                    // 0: parameters outside cl_fast's vetted range, everything goes to cl_agglom
+    uint32_t fast;                                    // 0: parameters outside cl_fast's vetted range, everything goes to the exact pass
+    // fused SVIM-mode pipeline (all null otherwise): cl_emit also writes the columns ef_classify reads
+    const uint32_t *sv_mark_in, *sv_depth, *sv_depth_off;
+    uint32_t sv_depth_bin;
+    uint32_t *sv_mark_out, *sv_svread, *sv_refread;
+    uint8_t *sv_gt;
     uint8_t *label8;                                  // [M] per sorted position: its cluster's smallest member (row inside the partition)
     uint8_t *comp8;                                   // [M] rows left to the exact pass: smallest row of their component; else 0xFF
     uint32_t *e_info, *e_pos, *e_span;                // [M] per sorted position: rank | end << 8 | cluster << 16 | head << 24; head means
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint3
 // mark's closed neighbourhood as a bit mask, and accepts the partition when no pair falls inside the guard
 // band and every neighbourhood equals the neighbourhood of its smallest member (<=> every component is a
 // clique).  Everything else -- about one partition in a few hundred on SV-like data, nearly all on random data
-// -- is appended to a "hard" list and gets the exact binary64 agglomeration (cl_agglom).  Both paths produce
+// -- gets the exact binary64 agglomeration (exact_unit), component by component.  Both paths produce
 // the oracle's clusters; tests/test_gpu_cluster.py and tools/stress.py cover both.
 
 template <int NW>
@@ -1278,14 +1285,30 @@ __global__ void cl_emit(const ClParams p, const uint32_t *flag, const uint32_t *
     const uint32_t s = p.part_start[part];
     const uint32_t a = p.sorted[i];
     p.order[s + (info & 0xFFu)] = a;
+    if (p.sv_mark_out) p.sv_mark_out[s + (info & 0xFFu)] = p.sv_mark_in[a];
     if (info >> 24) {
         const uint32_t cand = p.cbase[s] + ((info >> 16) & 0xFFu);
         p.cand_off[cand + 1] = s + ((info >> 8) & 0xFFu);
         const uint64_t hi = p.skeys[i] >> p.centre_bits;                    // contig | type, straight from the sorted key
-        p.cand_contig[cand] = (uint16_t)(hi >> p.type_bits);
+        const uint32_t k = (uint32_t)(hi >> p.type_bits), pos = p.e_pos[i];
+        p.cand_contig[cand] = (uint16_t)k;
         p.cand_type[cand] = (uint8_t)(hi & ((1ull << p.type_bits) - 1ull));
-        p.cand_pos[cand] = p.e_pos[i];
+        p.cand_pos[cand] = pos;
         p.cand_span[cand] = p.e_span[i];
+        if (p.sv_svread) {
+            // what a caller VCF would have carried: support = members, reference reads = depth(contig, pos) - support
+            const uint32_t support = ((info >> 8) & 0xFFu) - (info & 0xFFu);      // a head's rank is its cluster's start
+            const uint32_t nb = p.sv_depth_off[k + 1] - p.sv_depth_off[k];
+            uint32_t d = 0;
+            if (nb) {
+                uint32_t bin = pos / p.sv_depth_bin;
+                bin = bin < nb ? bin : nb - 1;
+                d = p.sv_depth[p.sv_depth_off[k] + bin];
+            }
+            p.sv_svread[cand] = support;
+            p.sv_refread[cand] = d > support ? d - support : 0u;
+            p.sv_gt[cand] = 1;
+        }
     }
     if (i == 0) p.cand_off[0] = 0;
 }
@@ -1306,32 +1329,6 @@ __global__ void sv_contig_offsets(const uint16_t *cand_contig, const uint32_t *n
         if (cand_contig[mid] < k) lo = mid + 1; else hi = mid;
     }
     ctg_off[k] = k == K ? N : lo;
-}
-
-__global__ void sv_adapt_cands(uint32_t N, const uint32_t *cand_off, const uint16_t *cand_contig, const uint32_t *cand_pos,
-                               const uint32_t *depth, const uint32_t *depth_off_dev, uint32_t depth_bin,
-                               uint32_t *svread, uint32_t *refread, uint8_t *gt_ok)
-{
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    const uint32_t support = cand_off[c + 1] - cand_off[c];
-    const uint32_t k = cand_contig[c];
-    const uint32_t nb = depth_off_dev[k + 1] - depth_off_dev[k];
-    uint32_t d = 0;
-    if (nb) {
-        uint32_t bin = cand_pos[c] / depth_bin;
-        bin = bin < nb ? bin : nb - 1;
-        d = depth[depth_off_dev[k] + bin];
-    }
-    svread[c] = support;
-    refread[c] = d > support ? d - support : 0u;
-    gt_ok[c] = 1;
-}
-
-__global__ void sv_adapt_marks(uint32_t M, const uint32_t *order, const uint32_t *raw_mark_read, uint32_t *mark_read)
-{
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < M) mark_read[m] = raw_mark_read[order[m]];
 }
 
 uint32_t bits_for(uint64_t max_value)
@@ -1355,7 +1352,30 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+struct SvExtra {
+    const uint32_t *mark_in, *depth, *depth_off;
+    uint32_t depth_bin;
+    uint32_t *mark_out, *svread, *refread;
+    uint8_t *gt;
+};
+int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluster_result *res, void *stream_, const SvExtra *sv);
+}  // namespace
+
+extern "C" {
+
 int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluster_result *res, void *stream_)
+{
+    return cluster_run(ctx, pr, res, stream_, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluster_result *res, void *stream_, const SvExtra *sv)
 {
     if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
     if (!pr || !res) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
@@ -1485,6 +1505,10 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
     launch_scan<0>(LoadPcat{tmpA, tmpB, pc}, M, spart, StorePlain{cbase}, res->n_cands, st);   // cbase[s] = first candidate of the partition at s
     p.cbase = cbase;
+    if (sv) {
+        p.sv_mark_in = sv->mark_in; p.sv_depth = sv->depth; p.sv_depth_off = sv->depth_off; p.sv_depth_bin = sv->depth_bin;
+        p.sv_mark_out = sv->mark_out; p.sv_svread = sv->svread; p.sv_refread = sv->refread; p.sv_gt = sv->gt;
+    }
     p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
     p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
     hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB);
@@ -1499,6 +1523,10 @@ int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *pr, const
     }
     return DUET_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluster_result *res)
 {
@@ -1561,17 +1589,21 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     const uint32_t M = pr->marks.n_marks, K = pr->n_contigs;
     *n_cands_host = 0;
     if (M == 0) return DUET_OK;
-    int rc = duet_cluster_run_device(ctx, &pr->marks, res, st);
-    if (rc) return rc;
-    // workspace: ctg_off (device + host), adapted candidate columns, gathered marks, device depth_off
-    const size_t sz[6] = {((size_t)K + 1) * 4 * 2, (size_t)M * 4, (size_t)M * 4, (size_t)M, (size_t)M * 4, 0};
+    if (!pr->mark_read || !pr->depth) return duet_fail(ctx, DUET_ERR_INVALID, "null array");
+    // workspace: ctg_off + depth_off on the device, the adapted candidate columns, the gathered marks
+    int rc;
+    const size_t sz[5] = {((size_t)K + 1) * 4 * 2, (size_t)M * 4, (size_t)M * 4, (size_t)M, (size_t)M * 4};
     for (int i = 0; i < 5; ++i)
         if ((rc = duet_reserve(ctx, ctx->sv_ws[i], sz[i]))) return rc;
     uint32_t *d_ctg_off = (uint32_t *)ctx->sv_ws[0].ptr, *d_depth_off = d_ctg_off + (K + 1);
-    uint32_t *d_svread = (uint32_t *)ctx->sv_ws[1].ptr, *d_refread = (uint32_t *)ctx->sv_ws[2].ptr;
-    uint8_t *d_gt = (uint8_t *)ctx->sv_ws[3].ptr;
-    uint32_t *d_mark = (uint32_t *)ctx->sv_ws[4].ptr;
     HIP_TRY(ctx, hipMemcpyAsync(d_depth_off, pr->depth_off, ((size_t)K + 1) * 4, hipMemcpyHostToDevice, st));
+    // clustering; its emit kernel also writes what a caller VCF would have carried (support, reference reads, GT)
+    // and the marks' read indices in output order
+    SvExtra sv;
+    sv.mark_in = pr->mark_read; sv.depth = pr->depth; sv.depth_off = d_depth_off; sv.depth_bin = pr->depth_bin;
+    sv.mark_out = (uint32_t *)ctx->sv_ws[4].ptr; sv.svread = (uint32_t *)ctx->sv_ws[1].ptr;
+    sv.refread = (uint32_t *)ctx->sv_ws[2].ptr; sv.gt = (uint8_t *)ctx->sv_ws[3].ptr;
+    if ((rc = cluster_run(ctx, &pr->marks, res, st, &sv))) return rc;
     hipLaunchKernelGGL(sv_contig_offsets, dim3((K + 1 + 255) / 256), dim3(256), 0, st, (const uint16_t *)res->cand_contig,
                        (const uint32_t *)res->n_cands, K, d_ctg_off);
     std::vector<uint32_t> ctg_off(K + 1);
@@ -1580,19 +1612,13 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     const uint32_t N = ctg_off[K];
     *n_cands_host = N;
     if (N == 0) return DUET_OK;
-    hipLaunchKernelGGL(sv_adapt_cands, dim3((N + 255) / 256), dim3(256), 0, st, N, (const uint32_t *)res->cand_off,
-                       (const uint16_t *)res->cand_contig, (const uint32_t *)res->cand_pos, pr->depth,
-                       (const uint32_t *)d_depth_off, pr->depth_bin, d_svread, d_refread, d_gt);
-    hipLaunchKernelGGL(sv_adapt_marks, dim3((M + 255) / 256), dim3(256), 0, st, M, (const uint32_t *)res->order,
-                       pr->mark_read, d_mark);
-    HIP_TRY(ctx, hipGetLastError());
     duet_ef_problem ef;
     memset(&ef, 0, sizeof(ef));
     ef.n_contigs = K; ef.n_cands = N; ef.n_marks = M; ef.n_reads = pr->n_reads;
     ef.cand_ctg_off = ctg_off.data();
     ef.read_tag = pr->read_tag;
-    ef.cand_pos = res->cand_pos; ef.cand_svlen = res->cand_span; ef.cand_svread = d_svread; ef.cand_refread = d_refread;
-    ef.cand_gt_ok = d_gt; ef.cand_off = res->cand_off; ef.mark_read = d_mark;
+    ef.cand_pos = res->cand_pos; ef.cand_svlen = res->cand_span; ef.cand_svread = sv.svread; ef.cand_refread = sv.refread;
+    ef.cand_gt_ok = sv.gt; ef.cand_off = res->cand_off; ef.mark_read = sv.mark_out;
     ef.svlen_thres = pr->svlen_thres; ef.suppread_thres = pr->suppread_thres;
     return duet_ef_run_device(ctx, &ef, out_pred, out_ps, st);
 }
