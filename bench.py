@@ -260,6 +260,8 @@ def main():
             out['extra'] = extra_points(ctx, torch, engine, synth, DeviceProblem, args.large)
             out['extra']['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
             out['extra']['fused_clustered_and_phased_config2'] = fused_point(ctx, torch, engine, synth, [contig])
+            out['extra']['fused_clustered_and_phased_2e7_marks'] = fused_point(ctx, torch, engine, synth,
+                                                                               synth.bench_genome(20000000, 3), runs=5)
             out['extra']['three_timed_regions_config2'] = abi_and_e2e(ctx, soa, contig, float(iso.total_ms))
             out['extra']['concurrent_jobs_config2'] = concurrent_jobs(torch, _lib, DeviceProblem, soa, args.steps)
         print(json.dumps(out))
@@ -360,7 +362,7 @@ def cluster_point(ctx, torch, synth, contigs):
             'note': 'latency-bound at this size: ~45 small launches; the few 65..100-mark partitions are the critical path'}
 
 
-def fused_point(ctx, torch, engine, synth, contigs):
+def fused_point(ctx, torch, engine, synth, contigs, runs=20):
     """The metric read literally -- marks clustered AND phased: duet_svim_phase_device on raw shuffled marks
     (A0 sort + linkage + emit, adapter, E/F) resident in HBM, checked against the two C oracles composed."""
     from duet_amd.devmem import DeviceSvim
@@ -372,7 +374,7 @@ def fused_point(ctx, torch, engine, synth, contigs):
     for _ in range(3):
         ds.run_fused(ctx)
     torch.cuda.synchronize()
-    n = 20
+    n = runs
     t0 = time.perf_counter()
     for _ in range(n):
         ds.run_fused(ctx)
