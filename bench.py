@@ -325,12 +325,36 @@ def abi_and_e2e(ctx, soa, contig, kernels_ms):
             sv_phasing(home, 50, 2, 4, False)
         t_e2e = (time.perf_counter() - t0) / 3
         size = os.path.getsize(os.path.join(home, 'phased_sv.vcf'))
+        # the last step alone: (pred, ps) -> text of the rows, on the device vs on the host (one thread)
+        from duet_amd.native import NativeIngest
+        from duet_amd.read_file import init_chrom_list
+        from duet_amd.devmem import DeviceProblem, device_rows
+        ing = NativeIngest.load(os.path.join(home, 'sv_calling', 'variants.vcf'), home + '/snp_phasing/',
+                                init_chrom_list(False, home), 4)
+        rows = ing.rows()
+        dpx = DeviceProblem(ing.soa, 50, 2)
+        stx = dpx.run(ctx)
+        ctx.check(stx)
+        pr_, ps_ = dpx.results()
+        device_rows(ctx, dpx, rows, stream=stx)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            body, n_rows = device_rows(ctx, dpx, rows, stream=stx)
+        t_rows_dev = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        for _ in range(3):
+            host_text = ing.emit(pr_, ps_, False)
+        t_rows_host = (time.perf_counter() - t0) / 3
+        rows_ok = bool(ing.header(False) + body == host_text)
+        ing.close()
     finally:
         shutil.rmtree(home, ignore_errors=True)
     M = soa.n_marks
     return {'t_kernels_ms': kernels_ms, 'marks_per_s_kernels': M / (kernels_ms * 1e-3) if kernels_ms else None,
             't_abi_ms': t_abi * 1e3, 'marks_per_s_abi': M / t_abi,
             't_e2e_ms': t_e2e * 1e3, 'marks_per_s_e2e': M / t_e2e, 'phased_sv_vcf_bytes': size,
+            'rows': {'n_rows': int(n_rows), 't_device_ms_incl_upload_and_download': t_rows_dev * 1e3,
+                     't_host_ms_1_thread': t_rows_host * 1e3, 'identical': rows_ok},
             'note': 't_abi = duet_ef_run_host on pageable host arrays (PCIe both ways); t_e2e = duet_amd.sv_phasing.sv_phasing '
                     'with the native ingest (libduet_ingest.so), 4 host threads, files in the page cache'}
 

@@ -23,7 +23,7 @@ KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
 # every symbol include/duet_ef.h declares (checked by tests/test_abi.py)
 EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
            'duet_ctx_set_profiling', 'duet_ctx_set_debug', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
-           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device')
+           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_rows_run_device')
 
 
 class EfProblem(ctypes.Structure):
@@ -61,6 +61,15 @@ class SvimProblem(ctypes.Structure):
                 ('n_reads', ctypes.c_uint32), ('n_contigs', ctypes.c_uint32), ('depth', ctypes.c_void_p),
                 ('depth_off', ctypes.c_void_p), ('depth_bin', ctypes.c_uint32), ('svlen_thres', ctypes.c_uint32),
                 ('suppread_thres', ctypes.c_uint32), ('reserved', ctypes.c_uint32)]
+
+
+class RowsProblem(ctypes.Structure):
+    _fields_ = [('n_contigs', ctypes.c_uint32), ('n_cands', ctypes.c_uint32), ('cand_ctg_off', ctypes.c_void_p),
+                ('pred', ctypes.c_void_p), ('ps', ctypes.c_void_p), ('cand_pos', ctypes.c_void_p),
+                ('cand_svlen', ctypes.c_void_p), ('cand_plus', ctypes.c_void_p), ('cand_chrom_rank', ctypes.c_void_p),
+                ('n_chrom_texts', ctypes.c_uint32), ('max_pos', ctypes.c_uint32), ('pool', ctypes.c_void_p),
+                ('pool_bytes', ctypes.c_uint64), ('str_off', ctypes.c_void_p), ('cand_off', ctypes.c_void_p),
+                ('mark_read', ctypes.c_void_p), ('read_tag', ctypes.c_void_p)]
 
 
 class DuetLibraryError(RuntimeError):
@@ -106,6 +115,8 @@ def load():
     lib.duet_cluster_run_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ClusterProblem),
                                             ctypes.POINTER(ClusterResult), ctypes.c_void_p]
     lib.duet_cluster_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ClusterProblem), ctypes.POINTER(ClusterResult)]
+    lib.duet_rows_run_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(RowsProblem), ctypes.c_void_p, ctypes.c_uint64,
+                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
     lib.duet_svim_phase_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(SvimProblem), ctypes.POINTER(ClusterResult),
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
     _lib = lib
@@ -189,6 +200,16 @@ class Context(object):
         return st
 
     # -- stage A0: span-position clustering ---------------------------------------------------------
+    def rows_device(self, prob, out_ptr, cap, stream):
+        """duet_rows_run_device: -> (bytes written, rows)."""
+        n = ctypes.c_uint64(0)
+        rows = ctypes.c_uint32(0)
+        rc = self.lib.duet_rows_run_device(self.handle, ctypes.byref(prob), ctypes.c_void_p(out_ptr), ctypes.c_uint64(cap),
+                                           ctypes.byref(n), ctypes.byref(rows), ctypes.c_void_p(stream))
+        if rc:
+            self._raise(rc)
+        return n.value, rows.value
+
     def cluster_host(self, contig, mtype, pos, span, max_dist=0.9, part_gap=1000, part_max=100, normalizer=900.0,
                      hints=True):
         """Cluster SV marks (host numpy arrays) into candidates on the GPU.

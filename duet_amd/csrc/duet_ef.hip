@@ -968,6 +968,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf &b : ctx->cl_in) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->cl_out) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->sv_ws) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->rows_ws) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (int i = 0; i < 3; ++i) {
         if (ctx->cl_side[i]) (void)hipStreamDestroy(ctx->cl_side[i]);

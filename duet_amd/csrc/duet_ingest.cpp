@@ -198,6 +198,12 @@ struct duet_ingest {
     std::vector<uint64_t> read_tag;
     std::vector<Span> c_chrom, c_ref, c_alt, c_type;
     bool parsed = false;
+    // device-side row emission: the texts of every candidate in one pool (built on first request)
+    std::vector<char> pool;
+    std::vector<uint32_t> str_off;
+    std::vector<uint16_t> chrom_rank;
+    uint32_t n_chrom_texts = 0, max_pos = 0;
+    bool rows_ready = false;
 };
 
 namespace {
@@ -337,6 +343,36 @@ bool aux_has_space(const unsigned char *b, const Aux &a)
 }
 
 }  // namespace
+
+// header lines of phased_sv.vcf (write_file.py:19-45) appended to `out`
+static int build_header(duet_ingest *g, int include_all_ctgs, std::string &out)
+{
+    out +=
+        "##fileformat=VCFv4.2\n"
+        "##source=Duet\n"
+        "##ALT=<ID=INS,Description=\"Insertion of novel sequence relative to the reference\">\n"
+        "##ALT=<ID=DEL,Description=\"Deletion relative to the reference\">\n"
+        "##FILTER=<ID=PASS,Description=\"SV calls passed phasing criterion\">\n"
+        "##INFO=<ID=SVLEN,Number=1,Type=Integer,Description=\"Estimated length of the variant\">\n"
+        "##FORMAT=<ID=HP,Number=1,Type=String,Description=\"Haplotype of the SV call\">\n"
+        "##FORMAT=<ID=PS,Number=1,Type=String,Description=\"Phase set which the SV call belongs to\">\n";
+    if (include_all_ctgs) {
+        for (const Span &l : g->contig_lines) { out.append(l.p, l.n); out += '\n'; }
+    } else {
+        const size_t lim = std::min<size_t>(24, g->contigs.size());
+        if (g->contigs.size() < 24) return unsupported(g, "default mode walks 24 contigs");   // upstream: IndexError
+        for (size_t k = 0; k < lim; ++k) {
+            const std::string a = "##contig=<ID=chr" + g->contigs[k] + ",", b = "##contig=<ID=" + g->contigs[k] + ",";
+            for (const Span &l : g->contig_lines)
+                if (find_sub(l.p, l.n, a.data(), a.size()) || find_sub(l.p, l.n, b.data(), b.size())) {
+                    out.append(l.p, l.n);
+                    out += '\n';
+                }
+        }
+    }
+    out += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tVALUE\n";
+    return DUET_INGEST_OK;
+}
 
 extern "C" {
 
@@ -794,30 +830,10 @@ int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, in
     if (C && (!pred || !ps)) return DUET_INGEST_INVALID;
     std::string out;
     out.reserve(4096 + C * 48);
-    out +=
-        "##fileformat=VCFv4.2\n"
-        "##source=Duet\n"
-        "##ALT=<ID=INS,Description=\"Insertion of novel sequence relative to the reference\">\n"
-        "##ALT=<ID=DEL,Description=\"Deletion relative to the reference\">\n"
-        "##FILTER=<ID=PASS,Description=\"SV calls passed phasing criterion\">\n"
-        "##INFO=<ID=SVLEN,Number=1,Type=Integer,Description=\"Estimated length of the variant\">\n"
-        "##FORMAT=<ID=HP,Number=1,Type=String,Description=\"Haplotype of the SV call\">\n"
-        "##FORMAT=<ID=PS,Number=1,Type=String,Description=\"Phase set which the SV call belongs to\">\n";
-    if (include_all_ctgs) {
-        for (const Span &l : g->contig_lines) { out.append(l.p, l.n); out += '\n'; }
-    } else {
-        const size_t lim = std::min<size_t>(24, g->contigs.size());
-        if (g->contigs.size() < 24) return unsupported(g, "default mode walks 24 contigs");   // upstream: IndexError
-        for (size_t k = 0; k < lim; ++k) {
-            const std::string a = "##contig=<ID=chr" + g->contigs[k] + ",", b = "##contig=<ID=" + g->contigs[k] + ",";
-            for (const Span &l : g->contig_lines)
-                if (find_sub(l.p, l.n, a.data(), a.size()) || find_sub(l.p, l.n, b.data(), b.size())) {
-                    out.append(l.p, l.n);
-                    out += '\n';
-                }
-        }
+    {
+        const int hrc = build_header(g, include_all_ctgs, out);
+        if (hrc) return hrc;
     }
-    out += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tVALUE\n";
 
     // emission order (:206-228): contig, PS-class 0/1/2, file order; candidates are already contig-major
     std::vector<uint32_t> idx;
@@ -884,6 +900,76 @@ int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, in
     buf[out.size()] = 0;
     *text = buf;
     *len = out.size();
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_header(duet_ingest *g, int include_all_ctgs, char **text, uint64_t *len)
+{
+    if (!g || !g->parsed || !text || !len) return DUET_INGEST_INVALID;
+    std::string out;
+    const int rc = build_header(g, include_all_ctgs, out);
+    if (rc) return rc;
+    char *buf = (char *)malloc(out.size() + 1);
+    if (!buf) return DUET_INGEST_INVALID;
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    *text = buf;
+    *len = out.size();
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
+{
+    if (!g || !g->parsed || !o) return DUET_INGEST_INVALID;
+    const size_t C = g->cand_pos.size();
+    if (!g->rows_ready) {
+        size_t total = 0;
+        for (size_t c = 0; c < C; ++c) total += g->c_chrom[c].n + g->c_ref[c].n + g->c_alt[c].n + g->c_type[c].n;
+        if (total >= 0xFFFFFFF0ull) return unsupported(g, "candidate texts exceed 4 GiB");
+        g->pool.resize(total ? total : 1);
+        g->str_off.resize(4 * C + 1);
+        size_t at = 0;
+        uint32_t mp = 0;
+        for (size_t c = 0; c < C; ++c) {
+            const Span *f[4] = {&g->c_chrom[c], &g->c_ref[c], &g->c_alt[c], &g->c_type[c]};
+            for (int i = 0; i < 4; ++i) {
+                g->str_off[4 * c + i] = (uint32_t)at;
+                if (f[i]->n) memcpy(&g->pool[at], f[i]->p, f[i]->n);
+                at += f[i]->n;
+            }
+            mp = std::max(mp, g->cand_pos[c]);
+        }
+        g->str_off[4 * C] = (uint32_t)at;
+        g->max_pos = mp;
+        // rank of each CHROM text among the distinct ones, in byte order (what Python's string compare does at :229)
+        std::vector<std::string> texts;
+        {
+            std::unordered_map<std::string, int> seen;
+            for (size_t c = 0; c < C; ++c) {
+                std::string t(g->c_chrom[c].p, g->c_chrom[c].n);
+                if (seen.emplace(t, 1).second) texts.push_back(std::move(t));
+            }
+        }
+        std::sort(texts.begin(), texts.end(), [](const std::string &x, const std::string &y) {
+            const int c = memcmp(x.data(), y.data(), std::min(x.size(), y.size()));
+            return c ? c < 0 : x.size() < y.size();
+        });
+        if (texts.size() > 65536) return unsupported(g, "more than 65536 distinct CHROM texts");
+        std::unordered_map<std::string, uint16_t> rank;
+        for (size_t i = 0; i < texts.size(); ++i) rank.emplace(texts[i], (uint16_t)i);
+        g->chrom_rank.resize(C);
+        for (size_t c = 0; c < C; ++c) g->chrom_rank[c] = rank[std::string(g->c_chrom[c].p, g->c_chrom[c].n)];
+        g->n_chrom_texts = (uint32_t)texts.size();
+        g->rows_ready = true;
+    }
+    o->n_cands = (uint32_t)C;
+    o->pool = g->pool.data();
+    o->pool_bytes = g->str_off.empty() ? 0 : g->str_off[4 * C];
+    o->str_off = g->str_off.data();
+    o->cand_chrom_rank = g->chrom_rank.data();
+    o->n_chrom_texts = g->n_chrom_texts;
+    o->max_pos = g->max_pos;
+    o->cand_plus = g->cand_plus.data();
     return DUET_INGEST_OK;
 }
 

@@ -38,6 +38,7 @@ struct duet_ctx {
     DevBuf h_in[9], h_out[2];
     // clustering (A0) workspace and host-run staging
     DevBuf cl_ws[14], cl_in[4], cl_out[6];
+    DevBuf rows_ws[8];                     // device-side row emission
     DevBuf sv_ws[5];                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};

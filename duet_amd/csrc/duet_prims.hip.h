@@ -1,0 +1,276 @@
+// duet_prims.hip.h -- device primitives shared by the translation units of libduet_ef.so: block-tiled scans whose
+// element sources / sinks are functors, and a stable LSD radix sort of (u64 key, u32 value) pairs.  Included inside
+// each unit's anonymous namespace.
+#ifndef DUET_PRIMS_HIP_H
+#define DUET_PRIMS_HIP_H
+
+constexpr int kRxThreads = 256;
+constexpr int kRxItems = 16;
+constexpr int kRxTile = kRxThreads * kRxItems;        // keys per radix block
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t nb,
+                                                      uint32_t *hist /* [256][nb] */)
+{
+    __shared__ uint32_t s_h[256];
+    const uint32_t tid = threadIdx.x;
+    s_h[tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRxTile;
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        const uint32_t i = base + it * kRxThreads + tid;
+        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)tid * nb + blockIdx.x] = s_h[tid];
+}
+
+// generic block-tiled scan: op 0 = exclusive sum, op 1 = inclusive max
+template <int OP>
+__device__ __forceinline__ uint32_t scan_op(uint32_t a, uint32_t b) { return OP == 0 ? a + b : (a > b ? a : b); }
+
+struct LoadPlain {
+    const uint32_t *in;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return in[i]; }
+};
+struct StorePlain {
+    uint32_t *out;
+    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { out[i] = v; }
+};
+template <int OP, class Load>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint32_t n, uint32_t *part)
+{
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+        if (base + j < n) acc = scan_op<OP>(acc, in(base + j));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc = scan_op<OP>(acc, __shfl_xor(acc, d, 64));
+    if ((tid & 63) == 0) s_w[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kScanThreads / 64; ++w) t = scan_op<OP>(t, s_w[w]);
+        part[blockIdx.x] = t;
+    }
+}
+
+// single block: part[i] <- combination of part[0..i) (exclusive); *total <- combination of everything
+template <int OP>
+__global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, uint32_t *total, uint32_t *zero14)
+{
+    if (zero14 && threadIdx.x < 14) zero14[threadIdx.x] = 0;     // the work-list counters of the kernels that follow
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? part[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if ((int)lane >= d) x = scan_op<OP>(x, y);
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (uint32_t w = 0; w < wave; ++w) before = scan_op<OP>(before, s_w[w]);
+        // exclusive value for element i: everything before it
+        uint32_t excl = before;
+        const uint32_t prev_in_wave = __shfl_up(x, 1, 64);
+        if (lane > 0) excl = scan_op<OP>(before, prev_in_wave);
+        if (i < n) part[i] = excl;
+        __syncthreads();
+        if (tid == 1023) s_carry = scan_op<OP>(before, x);
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = s_carry;
+}
+
+// out[i] = exclusive sum (OP 0) / inclusive max (OP 1) of in[0..i] given the per-tile carries in part[]
+template <int OP, class Load, class Store>
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32_t n, const uint32_t *part, const Store out)
+{
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = base + j < n ? in(base + j) : 0u;
+        acc = scan_op<OP>(acc, v[j]);
+    }
+    uint32_t x = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x = scan_op<OP>(x, y);
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t run = part[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) run = scan_op<OP>(run, s_w[w]);
+    const uint32_t prev = __shfl_up(x, 1, 64);
+    if (lane > 0) run = scan_op<OP>(run, prev);
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (OP == 0) {
+            if (base + j < n) out(base + j, run, v[j]);
+            run += v[j];
+        } else {
+            run = scan_op<OP>(run, v[j]);
+            if (base + j < n) out(base + j, run, v[j]);
+        }
+    }
+}
+
+// stable scatter of one 8-bit digit; hist holds the scanned (digit-major) offsets.
+// Each wave of a block owns a contiguous quarter of the block's 4096 keys and ranks it on its own (ballot match
+// inside the wave, a running per-digit count in the wave's LDS row: no workgroup barrier inside the loop; block
+// order = wave, round, lane = input order, so the sort stays stable).  The tile is then laid out digit-sorted in
+// LDS and written from there: consecutive lanes hold consecutive keys of one digit run, so each run leaves as whole
+// cache lines in one go.  (Writing straight from the ranking loop touched every run one 8-byte key at a time; with
+// thousands of blocks in flight the partly written lines fell out of L2 and the scatter ran at half this speed.)
+__global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in, const uint32_t *vals_in, uint32_t n,
+                                                         uint32_t shift, uint32_t nb, const uint32_t *hist,
+                                                         uint64_t *keys_out, uint32_t *vals_out)
+{
+    constexpr int kWaves = kRxThreads / 64, kPerWave = kRxTile / kWaves;
+    __shared__ uint64_t s_key[kRxTile];
+    __shared__ uint32_t s_val[kRxTile];
+    __shared__ uint32_t s_gbase[256];                      // global position of the block's first key of each digit
+    __shared__ uint32_t s_start[256];                      // where each digit starts inside the tile
+    __shared__ uint32_t s_wloc[kWaves][256];               // per wave: keys of each digit so far; then the wave's offset
+    __shared__ uint32_t s_wsum[kWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    s_gbase[tid] = hist[(size_t)tid * nb + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s_wloc[w][tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRxTile, wbase = base + wave * kPerWave;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint64_t key[kRxItems];
+    uint32_t val[kRxItems], lrank[kRxItems];
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        const uint32_t i = wbase + it * 64 + lane;
+        key[it] = i < n ? keys_in[i] : ~0ull;
+        val[it] = i < n ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        const bool valid = wbase + it * 64 + lane < n;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bm = __ballot(bit);
+            same &= bit ? bm : ~bm;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & lt);
+        const uint32_t seen = s_wloc[wave][d];
+        lrank[it] = seen + rank;
+        __builtin_amdgcn_wave_barrier();                   // every lane has read the count before its leader bumps it
+        if (valid && rank == 0) s_wloc[wave][d] = seen + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // digit starts inside the tile (exclusive scan of the digit totals over the 256 threads) and, per wave, the
+    // keys of the same digit in earlier waves
+    {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const uint32_t c = s_wloc[w][tid];
+            s_wloc[w][tid] = t;
+            t += c;
+        }
+        uint32_t x = t;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t y = __shfl_up(x, dd, 64);
+            if ((int)lane >= dd) x += y;
+        }
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < wave; ++w) carry += s_wsum[w];
+        s_start[tid] = carry + x - t;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        if (wbase + it * 64 + lane < n) {
+            const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
+            const uint32_t at = s_start[d] + s_wloc[wave][d] + lrank[it];
+            s_key[at] = key[it];
+            s_val[at] = val[it];
+        }
+    }
+    __syncthreads();
+    const uint32_t count = min((uint32_t)kRxTile, n - base);
+#pragma unroll
+    for (int it = 0; it < kRxItems; ++it) {
+        const uint32_t q = it * kRxThreads + tid;
+        if (q < count) {
+            const uint64_t k = s_key[q];
+            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t at = s_gbase[d] + (q - s_start[d]);
+            keys_out[at] = k;
+            vals_out[at] = s_val[q];
+        }
+    }
+}
+
+uint32_t bits_for(uint64_t max_value)
+{
+    uint32_t b = 0;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b ? b : 1;
+}
+
+template <int OP, class Load, class Store>
+void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uint32_t *total, hipStream_t st,
+                 uint32_t *zero14 = nullptr)
+{
+    const uint32_t nb = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part);
+    hipLaunchKernelGGL(scan_spine<OP>, dim3(1), dim3(1024), 0, st, part, nb, total, zero14);
+    hipLaunchKernelGGL((scan_apply<OP, Load, Store>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out);
+}
+
+// stable LSD radix sort of n (key, value) pairs on the low key_bits of the keys; buffers A hold the input, the result
+// ends in whichever pair of buffers *keys_out / *vals_out point to afterwards.  hist: 256 * ceil(n / kRxTile) words,
+// spart: ceil(256 * ceil(n / kRxTile) / kScanTile) + 1 words.
+inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, uint32_t n, uint32_t key_bits,
+                             uint32_t *hist, uint32_t *spart, hipStream_t st, uint64_t **keys_out, uint32_t **vals_out,
+                             uint64_t **keys_spare)
+{
+    const uint32_t nb_rx = (n + kRxTile - 1) / kRxTile, nh = 256 * nb_rx;
+    uint64_t *kin = keysA, *kout = keysB;
+    uint32_t *vin = valsA, *vout = valsB;
+    for (uint32_t shift = 0; shift < key_bits; shift += 8) {
+        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, n, shift, nb_rx, hist);
+        launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st);     // in place: scan_apply reads a tile before writing it
+        hipLaunchKernelGGL(rx_scatter, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, (const uint32_t *)vin, n, shift,
+                           nb_rx, (const uint32_t *)hist, kout, vout);
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *tv = vin; vin = vout; vout = tv;
+    }
+    *keys_out = kin;
+    *vals_out = vin;
+    if (keys_spare) *keys_spare = kout;
+}
+
+#endif

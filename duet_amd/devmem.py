@@ -52,6 +52,40 @@ class DeviceProblem(object):
         return unpack_block(self.out_blocks[slot].cpu().numpy(), self.n_max, self.soa.n_cands)
 
 
+def device_rows(ctx, dp, rows, slot=0, stream=None):
+    """Rows of phased_sv.vcf for the results in dp.out_blocks[slot], formatted on the device
+    (duet_rows_run_device). `rows` = NativeIngest.rows().  -> (bytes of the rows, number of rows)."""
+    torch = dp.torch
+    if stream is None:
+        stream = torch.cuda.current_stream(dp.device).cuda_stream
+    soa = dp.soa
+
+    def up(a):
+        a = np.ascontiguousarray(a)
+        t = torch.zeros(a.nbytes + 64, dtype=torch.uint8, device=dp.device)
+        if a.nbytes:
+            t[:a.nbytes] = torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dp.device)
+        return t
+
+    keep = [up(rows['pool']), up(rows['str_off']), up(rows['chrom_rank']), up(rows['plus'])]
+    ctg_off = np.ascontiguousarray(soa.cand_ctg_off, dtype=np.uint32)
+    blk = dp.out_blocks[slot]
+    p = _lib.RowsProblem()
+    p.n_contigs, p.n_cands = soa.n_contigs, soa.n_cands
+    p.cand_ctg_off = ctg_off.ctypes.data
+    p.pred, p.ps = blk.data_ptr() + 4 * dp.n_max, blk.data_ptr()
+    ef = dp.problem
+    p.cand_pos, p.cand_svlen = ef.cand_pos, ef.cand_svlen
+    p.cand_plus, p.cand_chrom_rank = keep[3].data_ptr(), keep[2].data_ptr()
+    p.n_chrom_texts, p.max_pos = int(rows['n_chrom_texts']), int(rows['max_pos'])
+    p.pool, p.pool_bytes, p.str_off = keep[0].data_ptr(), int(rows['pool_bytes']), keep[1].data_ptr()
+    p.cand_off, p.mark_read, p.read_tag = ef.cand_off, ef.mark_read, ef.read_tag
+    cap = int(rows['pool_bytes']) + 96 * soa.n_cands + 64
+    out = torch.empty(cap, dtype=torch.uint8, device=dp.device)
+    n, n_rows = ctx.rows_device(p, out.data_ptr(), cap, stream)
+    return out[:n].cpu().numpy().tobytes(), n_rows
+
+
 class DeviceCluster(object):
     """Raw SV marks uploaded once + result buffers, for repeated duet_cluster_run_device (stage A0)."""
 

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libduet_ingest.so')
 OK, UNSUPPORTED = 0, 1
 
 EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam',
-           'duet_ingest_parse_vcf', 'duet_ingest_get_arrays', 'duet_ingest_emit', 'duet_ingest_free')
+           'duet_ingest_parse_vcf', 'duet_ingest_get_arrays', 'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
+           'duet_ingest_get_rows')
 
 
 class IngestArrays(ctypes.Structure):
@@ -25,6 +26,12 @@ class IngestArrays(ctypes.Structure):
                 ('n_reads', ctypes.c_uint32)] + \
                [(n, ctypes.c_void_p) for n in ('cand_ctg_off', 'read_off', 'read_tag', 'cand_pos', 'cand_svlen',
                                                'cand_svread', 'cand_refread', 'cand_gt_ok', 'cand_off', 'mark_read')]
+
+
+class IngestRows(ctypes.Structure):
+    _fields_ = [('n_cands', ctypes.c_uint32), ('n_chrom_texts', ctypes.c_uint32), ('max_pos', ctypes.c_uint32),
+                ('pool', ctypes.c_void_p), ('pool_bytes', ctypes.c_uint64), ('str_off', ctypes.c_void_p),
+                ('cand_chrom_rank', ctypes.c_void_p), ('cand_plus', ctypes.c_void_p)]
 
 
 _lib = None
@@ -47,6 +54,9 @@ def load():
         lib.duet_ingest_get_arrays.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestArrays)]
         lib.duet_ingest_emit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+        lib.duet_ingest_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                           ctypes.POINTER(ctypes.c_uint64)]
+        lib.duet_ingest_get_rows.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestRows)]
         lib.duet_ingest_free.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_free.restype = None
         _lib = lib
@@ -56,7 +66,7 @@ def load():
 def _view(ptr, n, dtype):
     if not n or not ptr:
         return np.zeros(0, dtype=dtype)
-    ct = {np.uint8: ctypes.c_uint8, np.uint32: ctypes.c_uint32, np.uint64: ctypes.c_uint64}[dtype]
+    ct = {np.uint8: ctypes.c_uint8, np.uint16: ctypes.c_uint16, np.uint32: ctypes.c_uint32, np.uint64: ctypes.c_uint64}[dtype]
     return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(n,))
 
 
@@ -116,6 +126,29 @@ class NativeIngest(object):
             return ctypes.string_at(text.value, n.value)
         finally:
             self.lib.duet_ingest_free(text)
+
+    def header(self, include_all_ctgs):
+        """The header lines of phased_sv.vcf as bytes."""
+        text = ctypes.c_void_p()
+        n = ctypes.c_uint64()
+        rc = self.lib.duet_ingest_header(self.handle, 1 if include_all_ctgs else 0, ctypes.byref(text), ctypes.byref(n))
+        if rc != OK:
+            raise RuntimeError('duet_ingest_header: ' + self.lib.duet_ingest_error(self.handle).decode('utf-8', 'replace'))
+        try:
+            return ctypes.string_at(text.value, n.value)
+        finally:
+            self.lib.duet_ingest_free(text)
+
+    def rows(self):
+        """What the device-side row emission needs (views owned by the native object), or None when it declines:
+        dict(pool u8[], str_off u32[4C+1], chrom_rank u16[C], plus u8[C], n_chrom_texts, max_pos)."""
+        r = IngestRows()
+        if self.lib.duet_ingest_get_rows(self.handle, ctypes.byref(r)) != OK:
+            return None
+        C = r.n_cands
+        return dict(pool=_view(r.pool, r.pool_bytes, np.uint8), str_off=_view(r.str_off, 4 * C + 1, np.uint32),
+                    chrom_rank=_view(r.cand_chrom_rank, C, np.uint16), plus=_view(r.cand_plus, C, np.uint8),
+                    n_chrom_texts=r.n_chrom_texts, max_pos=r.max_pos, pool_bytes=r.pool_bytes)
 
     def close(self):
         if self.handle:

@@ -7,7 +7,8 @@ Two host paths feed the same HIP kernels:
                including its exceptions.
 The native path declines anything it does not vouch for (non-ASCII bytes, malformed numbers, missing
 fields ...) and the Python path then takes over, so the observable behaviour is upstream's either way.
-Set DUET_NATIVE_INGEST=0 to force the Python path.
+Set DUET_NATIVE_INGEST=0 to force the Python path; DUET_DEVICE_ROWS=0 keeps the native path but formats the rows on
+the host instead of on the device.
 """
 
 import logging
@@ -39,9 +40,20 @@ def _native(home, svlen_thres, suppread_thres, thread, include_all_ctgs, caller_
         logging.info('integrate read weight information')
         logging.info('calculate read weight statistics')
         logging.info('predict SV haplotypes in the callset')
-        pred, ps = engine.run_ef(ing.soa, svlen_thres, suppread_thres)
-        logging.info('write phased callset into .vcf file')
-        text = ing.emit(pred, ps, include_all_ctgs)
+        rows = None if os.environ.get('DUET_DEVICE_ROWS') == '0' else ing.rows()
+        if rows is not None and ing.soa.n_cands:
+            # (pred, ps) stay on the device; it also orders and formats the rows (duet_rows_run_device)
+            from duet_amd.devmem import DeviceProblem, device_rows
+            ctx = engine.default_context()
+            dp = DeviceProblem(ing.soa, svlen_thres, suppread_thres)
+            stream = dp.run(ctx)
+            ctx.check(stream)
+            logging.info('write phased callset into .vcf file')
+            text = ing.header(include_all_ctgs) + device_rows(ctx, dp, rows, stream=stream)[0]
+        else:
+            pred, ps = engine.run_ef(ing.soa, svlen_thres, suppread_thres)
+            logging.info('write phased callset into .vcf file')
+            text = ing.emit(pred, ps, include_all_ctgs)
     finally:
         ing.close()
     with open(out_vcf, 'wb') as out:

@@ -218,6 +218,38 @@ typedef struct duet_svim_problem {
 int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *prob, const duet_cluster_result *res,
                            uint8_t *out_pred, uint32_t *out_ps, uint32_t *n_cands_host, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Rows of phased_sv.vcf on the device: from (pred, ps) to the text of the data rows.
+ * Replaces, for the rows: the emission order of src/duet/sv_phasing_fn.py:204-228 (contig order, PS-class 0/1/2,
+ * file order, pred 0 dropped), the stable sort of :229 (CHROM as text, POS as int), print_sv of
+ * src/duet/write_file.py:6-17 and the SVLEN sign rule of sv_phasing_fn.py:225.  The header lines stay with the host.
+ *
+ * All pointers are device memory except cand_ctg_off.  The texts of candidate c are
+ * pool[str_off[4c] .. str_off[4c+1]) = CHROM, then REF, ALT and SVTYPE up to str_off[4c+4].
+ * cand_chrom_rank[c] = rank of c's CHROM text among the n_chrom_texts distinct CHROM texts in byte order
+ * (shorter text first on a common prefix), which is how Python compares the strings at :229. */
+typedef struct duet_rows_problem {
+    uint32_t n_contigs, n_cands;
+    const uint32_t *cand_ctg_off;        /* HOST [K+1] */
+    const uint8_t *pred;                 /* [C] from duet_ef_run_device */
+    const uint32_t *ps;                  /* [C] */
+    const uint32_t *cand_pos, *cand_svlen;
+    const uint8_t *cand_plus;            /* [C] 1: SVTYPE is exactly INS or DUP, SVLEN is written positive */
+    const uint16_t *cand_chrom_rank;     /* [C] */
+    uint32_t n_chrom_texts;
+    uint32_t max_pos;                    /* 0 = unknown (32 key bits for POS) */
+    const char *pool;
+    uint64_t pool_bytes;
+    const uint32_t *str_off;             /* [4C+1] */
+    const uint32_t *cand_off, *mark_read;/* the E/F problem's CSR and tag table: the PS-class is recomputed from them */
+    const uint64_t *read_tag;
+} duet_rows_problem;
+
+/* Writes the rows, in final order, to out_text (device, out_cap bytes; pool_bytes + 96 * n_cands always suffices);
+ * *out_len = bytes written, *n_rows = rows.  Synchronises `stream` (twice). */
+int duet_rows_run_device(duet_ctx *ctx, const duet_rows_problem *prob, char *out_text, uint64_t out_cap, uint64_t *out_len,
+                         uint32_t *n_rows, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,23 @@ int duet_ingest_emit(duet_ingest *ing, const uint8_t *pred, const uint32_t *ps, 
                      char **text, uint64_t *len);
 void duet_ingest_free(void *p);
 
+/* The header lines alone (write_file.py:19-45), for callers that produce the rows elsewhere (duet_rows_run_device). */
+int duet_ingest_header(duet_ingest *ing, int include_all_ctgs, char **text, uint64_t *len);
+
+/* What duet_rows_run_device (duet_ef.h) needs besides the arrays above: the CHROM / REF / ALT / SVTYPE texts of every
+ * candidate in one pool (4 offsets per candidate), the byte-order rank of each candidate's CHROM text among the
+ * distinct CHROM texts (the sort of sv_phasing_fn.py:229 compares them as strings), and the SVLEN sign flags
+ * (sv_phasing_fn.py:225).  Views into memory owned by the duet_ingest object. */
+typedef struct duet_ingest_rows {
+    uint32_t n_cands, n_chrom_texts, max_pos;
+    const char *pool;
+    uint64_t pool_bytes;
+    const uint32_t *str_off;            /* [4C+1] */
+    const uint16_t *cand_chrom_rank;    /* [C] */
+    const uint8_t *cand_plus;           /* [C] */
+} duet_ingest_rows;
+int duet_ingest_get_rows(duet_ingest *ing, duet_ingest_rows *out);
+
 #ifdef __cplusplus
 }
 #endif
