@@ -204,6 +204,15 @@ struct duet_ingest {
     std::vector<uint16_t> chrom_rank;
     uint32_t n_chrom_texts = 0, max_pos = 0;
     bool rows_ready = false;
+    // SVIM-mode signature extraction (optional, set before add_bam): CIGAR indels -> raw SV marks, binned depth
+    bool extract = false;
+    uint32_t min_sv_size = 40, min_mapq = 20, depth_bin = 1000;
+    std::vector<uint16_t> m_contig;
+    std::vector<uint8_t> m_type;
+    std::vector<uint32_t> m_pos, m_span, m_local, m_read;      // m_local: index in the contig's tag table or kAbsent
+    std::vector<std::vector<uint32_t>> depth;                   // per contig
+    std::vector<uint32_t> depth_flat, depth_off, tag_off;
+    std::vector<uint64_t> tag_flat;
 };
 
 namespace {
@@ -422,6 +431,9 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     }
     NameTable &tab = g->tables[contig];
     std::vector<uint64_t> &tags = g->tags[contig];
+    struct Pend { const char *name; uint32_t len; uint8_t type; uint32_t pos, span; };
+    std::vector<Pend> pend;
+    std::vector<int64_t> dep;
     while (p + 4 <= n) {
         const size_t bs = u32(p), end = p + 4 + bs;
         if (end > n || bs < 32) return unsupported(g, "truncated BAM record");
@@ -433,6 +445,38 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
         const size_t name_len = l_name ? l_name - 1 : 0;
         q += l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
         if (q > end) return unsupported(g, "corrupt BAM record");
+        if (g->extract) {
+            // SVIM-mode signatures: insertions / deletions of at least min_sv_size inside the alignment's CIGAR
+            // (primary and supplementary alignments with MAPQ >= min_mapq), and the alignment's span for the depth
+            const unsigned flag = b[p + 18] | (b[p + 19] << 8), mapq = b[p + 13];
+            const int32_t pos0 = (int32_t)u32(p + 8);
+            if (!(flag & 0x104) && mapq >= g->min_mapq && pos0 >= 0) {
+                uint64_t ref = (uint64_t)pos0;
+                const size_t cg = p + 36 + l_name;
+                for (unsigned i = 0; i < n_cig; ++i) {
+                    const uint32_t v = u32(cg + 4 * (size_t)i), op = v & 15u, len = v >> 4;
+                    if (op == 1 || op == 2) {
+                        if (len >= g->min_sv_size && ref < 0xFFFFFFFEull) {
+                            pend.push_back({name, (uint32_t)name_len, (uint8_t)(op == 1 ? 1 : 0), (uint32_t)ref + 1u, len});
+                        }
+                        if (op == 2) ref += len;
+                    } else if (op == 0 || op == 3 || op == 7 || op == 8) {
+                        ref += len;
+                    }
+                }
+                // depth[b] counts the alignments that cover the middle of bin b
+                const uint64_t w = g->depth_bin, half = w / 2, s0 = (uint64_t)pos0, e0 = ref;
+                if (e0 > s0) {
+                    const uint64_t lo = s0 <= half ? 0 : (s0 - half + w - 1) / w;            // first b with b*w + half >= s0
+                    const uint64_t hi = e0 <= half ? 0 : (e0 - half + w - 1) / w;            // first b with b*w + half >= e0
+                    if (hi > lo) {
+                        if (dep.size() < hi + 1) dep.resize(hi + 1, 0);
+                        dep[lo] += 1;
+                        dep[hi] -= 1;
+                    }
+                }
+            }
+        }
         // the last three aux fields are the last three whitespace tokens of the text line -- provided there
         // are at least three and none of them contains whitespace
         Aux last[3];
@@ -485,6 +529,24 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
             if (added) tags.push_back(word); else tags[idx] = word;      // later lines win (:29)
         }
         p = end;
+    }
+    if (g->extract) {
+        for (const Pend &m : pend) {
+            const int id = tab.find_hashed(m.name, m.len, NameTable::hash(m.name, m.len));
+            g->m_contig.push_back((uint16_t)contig);
+            g->m_type.push_back(m.type);
+            g->m_pos.push_back(m.pos);
+            g->m_span.push_back(m.span);
+            g->m_local.push_back(id < 0 ? kAbsent : (uint32_t)id);
+        }
+        if (g->depth.size() < g->contigs.size()) g->depth.resize(g->contigs.size());
+        std::vector<uint32_t> &d = g->depth[contig];
+        d.assign(dep.empty() ? 0 : dep.size() - 1, 0);
+        int64_t run = 0;
+        for (size_t i = 0; i + 1 < dep.size(); ++i) {
+            run += dep[i];
+            d[i] = (uint32_t)run;
+        }
     }
     return DUET_INGEST_OK;
 }
@@ -970,6 +1032,53 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
     o->n_chrom_texts = g->n_chrom_texts;
     o->max_pos = g->max_pos;
     o->cand_plus = g->cand_plus.data();
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_set_extraction(duet_ingest *g, int enable, uint32_t min_sv_size, uint32_t min_mapq, uint32_t depth_bin)
+{
+    if (!g || depth_bin == 0) return DUET_INGEST_INVALID;
+    if (g->contigs.size() > 65535) return unsupported(g, "more than 65535 contigs");
+    g->extract = enable != 0;
+    g->min_sv_size = min_sv_size;
+    g->min_mapq = min_mapq;
+    g->depth_bin = depth_bin;
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_get_marks(duet_ingest *g, duet_ingest_marks *o)
+{
+    if (!g || !o || !g->extract) return DUET_INGEST_INVALID;
+    const size_t K = g->contigs.size(), M = g->m_pos.size();
+    g->tag_off.assign(K + 1, 0);
+    g->tag_flat.clear();
+    for (size_t k = 0; k < K; ++k) {
+        g->tag_off[k + 1] = g->tag_off[k] + (uint32_t)g->tags[k].size();
+        g->tag_flat.insert(g->tag_flat.end(), g->tags[k].begin(), g->tags[k].end());
+    }
+    g->m_read.resize(M);
+    for (size_t i = 0; i < M; ++i)
+        g->m_read[i] = g->m_local[i] == kAbsent ? kAbsent : g->tag_off[g->m_contig[i]] + g->m_local[i];
+    g->depth.resize(K);
+    g->depth_off.assign(K + 1, 0);
+    g->depth_flat.clear();
+    for (size_t k = 0; k < K; ++k) {
+        g->depth_off[k + 1] = g->depth_off[k] + (uint32_t)g->depth[k].size();
+        g->depth_flat.insert(g->depth_flat.end(), g->depth[k].begin(), g->depth[k].end());
+    }
+    o->n_marks = (uint32_t)M;
+    o->n_contigs = (uint32_t)K;
+    o->n_reads = (uint32_t)g->tag_flat.size();
+    o->depth_bin = g->depth_bin;
+    o->mark_contig = g->m_contig.data();
+    o->mark_type = g->m_type.data();
+    o->mark_pos = g->m_pos.data();
+    o->mark_span = g->m_span.data();
+    o->mark_read = g->m_read.data();
+    o->read_tag = g->tag_flat.data();
+    o->read_off = g->tag_off.data();
+    o->depth = g->depth_flat.data();
+    o->depth_off = g->depth_off.data();
     return DUET_INGEST_OK;
 }
 

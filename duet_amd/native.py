@@ -18,7 +18,7 @@ OK, UNSUPPORTED = 0, 1
 
 EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam',
            'duet_ingest_parse_vcf', 'duet_ingest_get_arrays', 'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
-           'duet_ingest_get_rows')
+           'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks')
 
 
 class IngestArrays(ctypes.Structure):
@@ -32,6 +32,13 @@ class IngestRows(ctypes.Structure):
     _fields_ = [('n_cands', ctypes.c_uint32), ('n_chrom_texts', ctypes.c_uint32), ('max_pos', ctypes.c_uint32),
                 ('pool', ctypes.c_void_p), ('pool_bytes', ctypes.c_uint64), ('str_off', ctypes.c_void_p),
                 ('cand_chrom_rank', ctypes.c_void_p), ('cand_plus', ctypes.c_void_p)]
+
+
+class IngestMarks(ctypes.Structure):
+    _fields_ = [('n_marks', ctypes.c_uint32), ('n_contigs', ctypes.c_uint32), ('n_reads', ctypes.c_uint32),
+                ('depth_bin', ctypes.c_uint32)] + \
+               [(n, ctypes.c_void_p) for n in ('mark_contig', 'mark_type', 'mark_pos', 'mark_span', 'mark_read', 'read_tag',
+                                               'read_off', 'depth', 'depth_off')]
 
 
 _lib = None
@@ -57,6 +64,8 @@ def load():
         lib.duet_ingest_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                            ctypes.POINTER(ctypes.c_uint64)]
         lib.duet_ingest_get_rows.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestRows)]
+        lib.duet_ingest_set_extraction.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        lib.duet_ingest_get_marks.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestMarks)]
         lib.duet_ingest_free.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_free.restype = None
         _lib = lib
@@ -111,6 +120,45 @@ class NativeIngest(object):
                            cand_refread=_view(a.cand_refread, C, np.uint32), cand_gt_ok=_view(a.cand_gt_ok, C, np.uint8),
                            cand_off=_view(a.cand_off, C + 1, np.uint32), mark_read=_view(a.mark_read, M, np.uint32))
         return cls(h, lib, soa)
+
+    @classmethod
+    def extract(cls, sam_home, chrom_list, thread=4, min_sv_size=40, min_mapq=20, depth_bin=1000):
+        """SVIM mode: the haplotagged BAMs alone -> raw SV marks (CIGAR insertions / deletions), tag tables, binned depth.
+        -> (NativeIngest, dict(contig, type, pos, span, read, read_tag, read_off, depth, depth_off, depth_bin)) with
+        numpy COPIES of the arrays, or (None, reason)."""
+        lib = load()
+        if lib is None:
+            return None, 'libduet_ingest.so is missing'
+        names = (ctypes.c_char_p * len(chrom_list))(*[c.encode('utf-8') for c in chrom_list])
+        h = lib.duet_ingest_create(len(chrom_list), names)
+        if not h:
+            return None, 'duet_ingest_create failed'
+
+        def decline():
+            why = lib.duet_ingest_error(h).decode('utf-8', 'replace')
+            lib.duet_ingest_destroy(h)
+            return None, why
+
+        if lib.duet_ingest_set_extraction(h, 1, int(min_sv_size), int(min_mapq), int(depth_bin)) != OK:
+            return decline()
+        for k, c in enumerate(chrom_list):
+            for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
+                if os.path.exists(cand):
+                    if lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) != OK:
+                        return decline()
+                    break
+        m = IngestMarks()
+        if lib.duet_ingest_get_marks(h, ctypes.byref(m)) != OK:
+            return decline()
+        M, K, R = m.n_marks, m.n_contigs, m.n_reads
+        depth_off = _view(m.depth_off, K + 1, np.uint32).copy()
+        out = dict(contig=_view(m.mark_contig, M, np.uint16).copy(), type=_view(m.mark_type, M, np.uint8).copy(),
+                   pos=_view(m.mark_pos, M, np.uint32).copy(), span=_view(m.mark_span, M, np.uint32).copy(),
+                   read=_view(m.mark_read, M, np.uint32).copy(), read_tag=_view(m.read_tag, R, np.uint64).copy(),
+                   read_off=_view(m.read_off, K + 1, np.uint32).copy(),
+                   depth=_view(m.depth, int(depth_off[-1]) if K else 0, np.uint32).copy(), depth_off=depth_off,
+                   depth_bin=int(m.depth_bin))
+        return cls(h, lib, None), out
 
     def emit(self, pred, ps, include_all_ctgs):
         """Full text of phased_sv.vcf (header + rows) as bytes."""

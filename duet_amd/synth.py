@@ -469,6 +469,77 @@ def sam_lines(c):
     return out
 
 
+def svim_sam_lines(c, seed, min_sv=40, pos_jitter=15, len_jitter_pct=4):
+    """`samtools view` style text for contig c in which the SV evidence sits INSIDE the alignments (SVIM mode): the
+    first line of every read that supports candidates carries one CIGAR insertion / deletion per supported INS / DEL
+    candidate (jittered position and length), the other lines are plain matches.  Tags as in sam_lines()."""
+    rng = SplitMix(0x51A70000 + seed)
+    names = c.names_of(c.line_name_id)
+    L = len(names)
+    events = {}
+    C = len(c.cand_pos)
+    for j in range(C):
+        t = c.cand_svtype[j]
+        ln = abs(int(c.cand_svlen[j])) if int(c.cand_svlen[j]) > -(1 << 61) else 0
+        if t not in ('INS', 'DEL') or ln < min_sv:
+            continue
+        for nid in c.mark_name_id[c.cand_off[j]:c.cand_off[j + 1]]:
+            events.setdefault(int(nid), []).append((int(c.cand_pos[j]), t, ln))
+    jit = rng.between(L * 4 + 8, 0, 2 * pos_jitter)
+    ljit = rng.between(L * 4 + 8, -len_jitter_pct, len_jitter_pct)
+    mapq = rng.between(L, 0, 60)
+    seen = set()
+    out = []
+    u = 0
+    for i in range(L):
+        nid = int(c.line_name_id[i])
+        ev = events.get(nid) if nid not in seen else None
+        seen.add(nid)
+        flag = 0 if i < L // 2 else 2048
+        start = max(1, int(c.line_pos[i]))
+        cigar = '%dM' % (200 + i % 300)
+        if ev:
+            ev = sorted(ev)
+            start = max(1, ev[0][0] - 400 - (i % 200))
+            ref = start
+            ops = []
+            for (p0, t, ln) in ev:
+                p1 = p0 + int(jit[u % len(jit)]) - pos_jitter
+                ln1 = max(1, ln * (100 + int(ljit[u % len(ljit)])) // 100)
+                u += 1
+                if p1 <= ref:                      # would overlap the previous event: this read does not show it
+                    continue
+                ops.append('%dM' % (p1 - ref))
+                ref = p1
+                if t == 'INS':
+                    ops.append('%dI' % ln1)
+                else:
+                    ops.append('%dD' % ln1)
+                    ref += ln1
+            ops.append('%dM' % (300 + i % 100))
+            cigar = ''.join(ops)
+        core = '%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t*\t*\tNM:i:%d' % (names[i], flag, c.spelled, start, int(mapq[i]), cigar, i % 50)
+        if c.line_tagged[i]:
+            core += '\tHP:i:%d\tPC:i:%d\tPS:i:%d' % (int(c.line_hap[i]), int(c.line_pc[i]), int(c.line_ps[i]))
+        out.append(core)
+    return out
+
+
+def write_svim_workdir(home, contigs, seed=1, write_sam=True):
+    """<home>/snp_phasing/<spelled>.bam (+ .bam.sam) with CIGAR-borne SV evidence: the input of SVIM mode."""
+    os.makedirs(os.path.join(home, 'snp_phasing'), exist_ok=True)
+    for c in contigs:
+        if not c.has_bam:
+            continue
+        stem = os.path.join(home, 'snp_phasing', c.spelled + '.bam')
+        lines = svim_sam_lines(c, seed)
+        if write_sam:
+            with open(stem + '.sam', 'w') as f:
+                f.write(''.join(l + '\n' for l in lines))
+        bamio.write_bam_from_sam_lines(stem, [(c.spelled, c.length)], lines)
+    return home
+
+
 def write_workdir(home, contigs, dialect='cutesv', seed=1, write_bam=True, write_sam=True, **vcf_kw):
     """Lay out Duet's <OUTPUT> directory for step E/F (sv_phasing.py:12-14):
     <home>/sv_calling/variants.vcf and <home>/snp_phasing/<spelled>.bam (+ .bam.sam text that a

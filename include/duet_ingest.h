@@ -76,6 +76,27 @@ typedef struct duet_ingest_rows {
 } duet_ingest_rows;
 int duet_ingest_get_rows(duet_ingest *ing, duet_ingest_rows *out);
 
+/* SVIM-mode signature extraction (the reference delegates it to the external `svim
+ * alignment`, src/duet/sv_calling.py:13-15, so this is the repository's own rule, parity unpinned -- normative text:
+ * oracle/svim_oracle.py).  When enabled BEFORE duet_ingest_add_bam, every primary or supplementary alignment with
+ * MAPQ >= min_mapq contributes (a) one raw SV mark per CIGAR insertion / deletion of at least min_sv_size bases:
+ * type 1 = INS / 0 = DEL, pos = 1-based reference position of the event, span = its length, read = the alignment's
+ * entry in the contig's tag table (or 0xFFFFFFFF); (b) +1 to depth[b] of every bin b of depth_bin bases whose
+ * middle it covers.  The marks are what duet_cluster_run_* / duet_svim_phase_device (duet_ef.h) take. */
+int duet_ingest_set_extraction(duet_ingest *ing, int enable, uint32_t min_sv_size, uint32_t min_mapq, uint32_t depth_bin);
+
+typedef struct duet_ingest_marks {      /* views into memory owned by the duet_ingest object */
+    uint32_t n_marks, n_contigs, n_reads, depth_bin;
+    const uint16_t *mark_contig;        /* [M] */
+    const uint8_t *mark_type;           /* [M] */
+    const uint32_t *mark_pos, *mark_span, *mark_read;   /* [M] */
+    const uint64_t *read_tag;           /* [R] all contigs' tag tables, concatenated */
+    const uint32_t *read_off;           /* [K+1] */
+    const uint32_t *depth;              /* [depth_off[K]] */
+    const uint32_t *depth_off;          /* [K+1] */
+} duet_ingest_marks;
+int duet_ingest_get_marks(duet_ingest *ing, duet_ingest_marks *out);
+
 #ifdef __cplusplus
 }
 #endif

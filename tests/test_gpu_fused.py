@@ -49,3 +49,24 @@ def test_fused_pipeline_matches_oracle_composition(kind, seed):
         assert np.array_equal(got['ps'], want_ps)
     assert int((want_pred != 0).sum()) > 0
     ctx.close()
+
+
+@pytest.mark.parametrize('kind,seed', [('chr21', 3), ('genome_small', 5)])
+def test_svim_mode_from_bams_matches_the_cpu_pipeline(kind, seed):
+    """BAMs alone -> native signature extraction -> A0 -> E/F on the device, against oracle/svim_oracle.py's CPU
+    pipeline (Python extraction, C cluster oracle, adapter, C E/F oracle)."""
+    import shutil
+    import tempfile
+    from duet_amd import svim_mode
+    from oracle import svim_oracle
+    home = tempfile.mkdtemp(prefix='duet_svim_')
+    try:
+        synth.write_svim_workdir(home, H.case_contigs(kind, seed), seed)
+        got = svim_mode.phase_from_bams(home, 50, 2, 2)
+        want = svim_oracle.phase_workdir(home, got['chroms'], 50, 2)
+        for f in ('cand_contig', 'cand_type', 'cand_pos', 'cand_span', 'support', 'pred', 'ps'):
+            assert np.array_equal(got[f], want[f]), f
+        assert int((got['pred'] != 0).sum()) > 0
+        assert svim_mode.rows_text(home, got).count('\n') == int((got['pred'] != 0).sum())
+    finally:
+        shutil.rmtree(home, ignore_errors=True)

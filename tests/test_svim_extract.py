@@ -1,0 +1,62 @@
+# coding=utf-8
+"""SVIM-mode signature extraction: the native BAM pass (libduet_ingest.so) against the Python statement of the rule
+(oracle/svim_oracle.py) on synthetic haplotagged BAMs whose SV evidence sits in the CIGARs.  CPU only."""
+import shutil
+import tempfile
+
+import numpy as np
+import pytest
+
+from duet_amd import synth
+from duet_amd.native import NativeIngest
+from duet_amd.read_file import init_chrom_list
+from oracle import svim_oracle
+from tests import helpers as H
+
+
+@pytest.mark.parametrize('kind,seed', [('chr21', 3), ('fuzz', 2), ('genome_small', 5)])
+def test_native_extraction_matches_the_rule(kind, seed):
+    home = tempfile.mkdtemp(prefix='duet_svim_')
+    try:
+        contigs = H.case_contigs(kind, seed)
+        synth.write_svim_workdir(home, contigs, seed)
+        chroms = init_chrom_list(False, home)
+        want = svim_oracle.extract_workdir(home, chroms)
+        ing, got = NativeIngest.extract(home + '/snp_phasing/', chroms, thread=2)
+        assert ing is not None, got
+        for f in ('contig', 'type', 'pos', 'span'):
+            assert np.array_equal(got[f], want[f]), f
+        assert len(got['pos']) > 0
+        # the marks' reads resolve to the same tags
+        tags = [None if r == 0xFFFFFFFF else int(got['read_tag'][r]) for r in got['read']]
+        assert tags == [None if t is None else svim_oracle.pack_tag(t) for t in want['tag']]
+        for k in range(len(chroms)):
+            d = got['depth'][got['depth_off'][k]:got['depth_off'][k + 1]]
+            assert d.tolist() == want['depth'][k], k
+        ing.close()
+    finally:
+        shutil.rmtree(home, ignore_errors=True)
+
+
+def test_filters(tmp_path):
+    """Unmapped / secondary / low-MAPQ alignments and short indels leave no marks."""
+    from duet_amd import bamio
+    lines = ['a\t0\tchr1\t1000\t60\t100M50I100M\t*\t0\t0\t*\t*\tNM:i:1\tHP:i:1\tPC:i:10\tPS:i:7',
+             'b\t256\tchr1\t1000\t60\t100M50I100M\t*\t0\t0\t*\t*\tNM:i:1',
+             'c\t4\tchr1\t1000\t60\t100M50I100M\t*\t0\t0\t*\t*\tNM:i:1',
+             'd\t0\tchr1\t1000\t19\t100M50D100M\t*\t0\t0\t*\t*\tNM:i:1',
+             'e\t2048\tchr1\t5000\t20\t10S100M39I5M40D7N3=2X41I9H\t*\t0\t0\t*\t*\tNM:i:1']
+    d = tmp_path / 'snp_phasing'
+    d.mkdir()
+    stem = str(d / 'chr1.bam')
+    with open(stem + '.sam', 'w') as f:
+        f.write(''.join(l + '\n' for l in lines))
+    bamio.write_bam_from_sam_lines(stem, [('chr1', 249250621)], lines)
+    chroms = init_chrom_list(False, str(tmp_path))
+    want = svim_oracle.extract_workdir(str(tmp_path), chroms)
+    ing, got = NativeIngest.extract(str(d) + '/', chroms)
+    assert ing is not None, got
+    assert got['pos'].tolist() == want['pos'].tolist() == [1100, 5105, 5157]
+    assert got['type'].tolist() == [1, 0, 1] and got['span'].tolist() == [50, 40, 41]
+    assert got['read'].tolist() == [0, 0xFFFFFFFF, 0xFFFFFFFF]
+    ing.close()
