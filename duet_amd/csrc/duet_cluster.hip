@@ -58,8 +58,8 @@ struct ClParams {
     const uint64_t *skeys;                            // the sorted keys (contig | type | centre)
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
-    float inv_norm, t_lo[3], t_hi[3];                 // cl_fast: 1/normalizer; max_dist / {1, 2, 4} * (1 -/+ 1e-5) in binary32
-    uint32_t fast;                                    // 0: parameters outside cl_fast's vetted range, everything goes to the exact pass
+    float inv_norm, t_lo[3], t_hi[3];                 // fast pass: 1/normalizer; max_dist / {1, 2, 4} * (1 -/+ 1e-5) in binary32
+    uint32_t fast;                                    // 0: parameters outside the fast pass's vetted range, everything goes to the exact pass
     // fused SVIM-mode pipeline (all null otherwise): cl_emit also writes the columns ef_classify reads
     const uint32_t *sv_mark_in, *sv_depth, *sv_depth_off;
     uint32_t sv_depth_bin;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint3
 //     every cross distance the oracle ever computes stays above max_dist;
 //   * a component in which EVERY pair has d <= max_dist * (1 - 9e-6) ends as exactly one cluster: while two of
 //     its clusters remain, their computed distance is below max_dist, so the oracle keeps merging.
-// cl_fast evaluates d in binary32 (relative error < 4e-7, hence the 1e-5 guard band around max_dist), builds each
+// The fast pass evaluates d in binary32 (relative error < 4e-7, hence the 1e-5 guard band around max_dist), builds each
 // mark's closed neighbourhood as a bit mask, and accepts the partition when no pair falls inside the guard
 // band and every neighbourhood equals the neighbourhood of its smallest member (<=> every component is a
 // clique).  Everything else -- about one partition in a few hundred on SV-like data, nearly all on random data
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32
 }
 
 // Partitions the fast pass did not settle as a whole, after cl_exact: every row has its label; group the rows by
-// label and finish like cl_fast does.
+// label and finish like the fast pass does.
 template <int GROUP, int R>
 struct RankSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
@@ -1168,7 +1168,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
     uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
     uint32_t *e_info = (uint32_t *)ctx->cl_ws[9].ptr;
-    uint32_t *pcat = (uint32_t *)ctx->cl_ws[13].ptr, *cbase = pcat + (M + 1);
+    uint32_t *cbase = (uint32_t *)ctx->cl_ws[13].ptr + (M + 1);      // (the first M + 1 words hold label8 / comp8)
     uint32_t *pc = (uint32_t *)ctx->cl_ws[10].ptr;
     uint32_t *scal = (uint32_t *)ctx->cl_ws[11].ptr;      // [0] = n_parts
 
