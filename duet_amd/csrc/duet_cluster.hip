@@ -1331,14 +1331,17 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
                            uint32_t *out_ps, uint32_t *n_cands_host, void *stream_)
 {
     if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
-    if (!pr || !res || !out_pred || !out_ps || !n_cands_host) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
+    if (!pr || !res || !out_pred || !out_ps) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
     if (!pr->depth_off || pr->depth_bin == 0 || pr->n_contigs == 0 || pr->n_contigs > 65535)
         return duet_fail(ctx, DUET_ERR_INVALID, "bad depth / contig description");
     hipStream_t st = (hipStream_t)stream_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t M = pr->marks.n_marks, K = pr->n_contigs;
-    *n_cands_host = 0;
-    if (M == 0) return DUET_OK;
+    if (n_cands_host) *n_cands_host = 0;
+    if (M == 0) {
+        if (res->n_cands) HIP_TRY(ctx, hipMemsetAsync(res->n_cands, 0, 4, st));
+        return DUET_OK;
+    }
     if (!pr->mark_read || !pr->depth) return duet_fail(ctx, DUET_ERR_INVALID, "null array");
     // workspace: ctg_off + depth_off on the device, the adapted candidate columns, the gathered marks
     int rc;
@@ -1356,6 +1359,19 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     if ((rc = cluster_run(ctx, &pr->marks, res, st, &sv))) return rc;
     hipLaunchKernelGGL(sv_contig_offsets, dim3((K + 1 + 255) / 256), dim3(256), 0, st, (const uint16_t *)res->cand_contig,
                        (const uint32_t *)res->n_cands, K, d_ctg_off);
+    if (!n_cands_host) {
+        // fully asynchronous: E/F is planned on the device from the contig offsets just computed; buffers and grids are
+        // sized for the upper bound (a candidate has at least one mark) and the kernels read the real count
+        duet_ef_problem ef;
+        memset(&ef, 0, sizeof(ef));
+        ef.n_contigs = K; ef.n_cands = M; ef.n_marks = M; ef.n_reads = pr->n_reads;
+        ef.read_tag = pr->read_tag;
+        ef.cand_pos = res->cand_pos; ef.cand_svlen = res->cand_span; ef.cand_svread = sv.svread; ef.cand_refread = sv.refread;
+        ef.cand_gt_ok = sv.gt; ef.cand_off = res->cand_off; ef.mark_read = sv.mark_out;
+        ef.svlen_thres = pr->svlen_thres; ef.suppread_thres = pr->suppread_thres;
+        return duet_ef_run_planned_on_device(ctx, &ef, M, (const uint32_t *)res->n_cands, (const uint32_t *)d_ctg_off, out_pred,
+                                             out_ps, st);
+    }
     std::vector<uint32_t> ctg_off(K + 1);
     HIP_TRY(ctx, hipMemcpyAsync(ctg_off.data(), d_ctg_off, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));             // the one host round trip: candidates per contig

@@ -58,6 +58,9 @@ constexpr int kStageIt = kChunk / (kCandPerBlock * 4);   // 16-byte index loads 
 constexpr int kSmallK = 64;
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB)
+constexpr uint32_t kLongCnt = 16;                   // ... when they hold more entries than this
+constexpr uint32_t kLongTiles = 256;                // ef_seed_sort: tiles whose entries are copied by the whole workgroup
+constexpr uint32_t kMaxRuns = 32;                  // ef_seed_sort merges up to this many ascending runs by rank
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
 constexpr uint32_t kC2Quota = 32;                 // group-summary slots per classify block
 constexpr int kC2Groups = 2;                      // voter groups kept per summary (first two seen)
@@ -143,6 +146,7 @@ struct Params {
     uint32_t *out_ps;
     uint32_t n_small;                 // K when K <= kSmallK: the contig offsets then also ride in the kernel arguments
     uint32_t ctg_small[kSmallK + 1];  //   (scalar loads instead of a dependent HBM round trip)
+    const uint32_t *dyn_c;            // device-planned runs (DYN kernels): the candidate count lives on the device, C is an upper bound
     uint32_t dbg;                     // diagnostic ablation bits (0 in production)
     unsigned long long *stamps;       // diagnostic build only: [kernel][block][8] wall-clock stamps
 };
@@ -363,7 +367,7 @@ __device__ __forceinline__ void stage_store(uint64_t *s_tag, const uint64_t (&t)
 // round trips of tile i+1 / i+2 under the LDS walk of tile i was measured at 2e7 marks and was NOT faster --
 // 80 us vs 72 us: with four workgroups per CU in different phases the staging latency is already hidden and
 // the kernel is bound by the sum of VALU issue (consume + fp64 decision) and memory time; see DESIGN.md.)
-template <bool VEC>
+template <bool VEC, bool DYN = false>
 __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
 {
     __shared__ uint64_t s_tag[kChunk];
@@ -373,7 +377,9 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
     const uint32_t tid = threadIdx.x;
     STAMP(0, 0);
     const uint32_t c0 = blockIdx.x * kCandPerBlock;
-    const uint32_t nc = min((uint32_t)kCandPerBlock, p.C - c0);
+    const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
+    if (DYN && c0 >= n_cands) return;                          // the grid was sized for the upper bound
+    const uint32_t nc = min((uint32_t)kCandPerBlock, n_cands - c0);
     for (uint32_t i = tid; i <= nc; i += kCandPerBlock) s_off[i] = p.cand_off[c0 + i];
     if (tid == 0) sh.c2n = 0;
 
@@ -531,11 +537,23 @@ __device__ uint32_t unique_copy(const uint32_t *src, uint32_t n, uint32_t *dst, 
     return total;
 }
 
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t key)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
 {
     __shared__ uint32_t s_key[kSortLds];
     __shared__ uint32_t s_part[kSortThreads / 64 + 1];
     __shared__ uint32_t s_unsorted;
+    __shared__ uint32_t s_nruns, s_run[kMaxRuns + 1];
+    __shared__ uint32_t s_nlong, s_long[kLongTiles][2];
     const uint32_t k = blockIdx.x, tid = threadIdx.x;
     STAMP(1, 0);
     const uint32_t c_lo = p.n_small ? p.ctg_small[k] : p.ctg_off[k];
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         if (tid == 0) { p.n_one[k] = 0; region[0] = 0; }
         return;
     }
-    if (tid == 0) s_unsorted = 0;
+    if (tid == 0) { s_unsorted = 0; s_nruns = 0; s_nlong = 0; }
     // Seed entries of the classify tiles that overlap this contig, in candidate order: thread t owns
     // a contiguous run of tiles, counts the entries it will keep, and an exclusive scan gives its
     // output position -- so a position-sorted VCF yields an (almost always) already ascending list.
@@ -571,18 +589,80 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         const uint64_t pe = entry(my_lo - 1, (uint32_t)recp.x - 1, recp);
         if ((uint32_t)(pe >> 32) >= c_lo) prev0 = (uint32_t)pe;
     }
+    // A tile's entries are already free of repeats among themselves (seeds_tile), so for a tile that lies wholly inside
+    // the contig only its first entry can fall to the neighbour rule: its count needs no loop, and its entries beyond
+    // the three inline ones are copied by the whole workgroup afterwards (a tile of sparse candidates can hold 256 of
+    // them: one thread walking those through HBM twice cost 47 us).  Tiles on the contig's edges take the loop.
+    const uint32_t n_total = p.dyn_c ? *p.dyn_c : p.C;
+    auto interior = [&](uint32_t b) {
+        return b * kCandPerBlock >= c_lo && ((b + 1) * kCandPerBlock <= c_hi || c_hi == n_total);
+    };
+    // A tile on the contig's edge holds entries of two contigs: its owner walks it -- unless it is long, then the
+    // workgroup filters it together (one scan), in front of / behind the tiles in between.
+    const uint32_t cnt_lo = (uint32_t)recs[b_lo].x, cnt_hi = (uint32_t)recs[b_hi].x;
+    const bool lo_coop = !interior(b_lo) && cnt_lo > kLongCnt;
+    const bool hi_coop = b_hi != b_lo && !interior(b_hi) && cnt_hi > kLongCnt;
+    auto edge_tile = [&](uint32_t b, uint32_t cnt, uint32_t base) -> uint32_t {
+        const ulonglong4 rec = recs[b];
+        bool keep = false;
+        uint32_t ps = 0;
+        if (tid < cnt) {
+            const uint64_t e = entry(b, tid, rec);
+            const uint32_t c = (uint32_t)(e >> 32);
+            ps = (uint32_t)e;
+            keep = c >= c_lo && c < c_hi;
+        }
+        uint32_t total;
+        const uint32_t at = base + block_exscan(keep ? 1u : 0u, tid, s_part, kSortThreads, &total);
+        if (keep) {
+            if (at < kSortLds) s_key[at] = ps;
+            glist[at] = ps;
+        }
+        return total;
+    };
+    const uint32_t n_lo = lo_coop ? edge_tile(b_lo, cnt_lo, 0) : 0u;
+    uint32_t mid_total = 0;
     uint32_t mine = 0;
     for (int pass = 0; pass < 2; ++pass) {
         uint32_t at = 0;
         if (pass == 1) {
             uint32_t total;
-            at = block_exscan(mine, tid, s_part, kSortThreads, &total);
-            if (tid == 0) s_part[kSortThreads / 64] = total;
+            at = n_lo + block_exscan(mine, tid, s_part, kSortThreads, &total);
+            mid_total = total;
         }
         uint32_t prev_ps = prev0;
         for (uint32_t b = my_lo; b < my_hi; ++b) {
             const ulonglong4 rec = b == my_lo ? rec0 : recs[b];
             const uint32_t cnt = (uint32_t)rec.x;
+            if (cnt == 0 || (b == b_lo && lo_coop) || (b == b_hi && hi_coop)) continue;
+            if (interior(b)) {
+                const uint32_t skip = (uint32_t)rec.y == prev_ps ? 1u : 0u;
+                if (pass == 0) {
+                    mine += cnt - skip;
+                } else {
+                    for (uint32_t j = skip; j < cnt && j < 3; ++j) {
+                        const uint32_t ps = (uint32_t)entry(b, j, rec);
+                        if (at + j - skip < kSortLds) s_key[at + j - skip] = ps;
+                        glist[at + j - skip] = ps;
+                    }
+                    if (cnt > 3) {
+                        const uint32_t w = cnt > kLongCnt ? atomicAdd(&s_nlong, 1u) : kLongTiles;
+                        if (w < kLongTiles) {
+                            s_long[w][0] = b;
+                            s_long[w][1] = at + 3 - skip;
+                        } else {                               // a few more entries (or a full work list): copy them here
+                            for (uint32_t j = 3; j < cnt; ++j) {
+                                const uint32_t ps = (uint32_t)p.seed_ent[(size_t)b * kCandPerBlock + j];
+                                if (at + j - skip < kSortLds) s_key[at + j - skip] = ps;
+                                glist[at + j - skip] = ps;
+                            }
+                        }
+                    }
+                    at += cnt - skip;
+                }
+                if (b + 1 < my_hi) prev_ps = (uint32_t)entry(b, cnt - 1, rec);
+                continue;
+            }
             for (uint32_t j = 0; j < cnt; ++j) {
                 const uint64_t e = entry(b, j, rec);
                 const uint32_t c = (uint32_t)(e >> 32), ps = (uint32_t)e;
@@ -600,8 +680,23 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         }
     }
     __syncthreads();
+    {
+        const uint32_t nl = min(s_nlong, kLongTiles);
+        for (uint32_t w = 0; w < nl; ++w) {
+            const uint32_t b = s_long[w][0], at = s_long[w][1];
+            const uint32_t cnt = (uint32_t)recs[b].x;
+            for (uint32_t j = 3 + tid; j < cnt; j += kSortThreads) {
+                const uint32_t ps = (uint32_t)p.seed_ent[(size_t)b * kCandPerBlock + j];
+                if (at + j - 3 < kSortLds) s_key[at + j - 3] = ps;
+                glist[at + j - 3] = ps;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_hi = hi_coop ? edge_tile(b_hi, cnt_hi, n_lo + mid_total) : 0u;
+    __syncthreads();
     STAMP(1, 1);
-    const uint32_t n = s_part[kSortThreads / 64];
+    const uint32_t n = n_lo + mid_total + n_hi;
     {
         const uint32_t *lst = n <= kSortLds ? s_key : glist;
         for (uint32_t i = tid + 1; i < n; i += kSortThreads)
@@ -613,8 +708,63 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     if (n == 0) {
         n_one = 0;
     } else if (n <= kSortLds) {
-        if (unsorted && !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 6))
+        // local disorder (neighbouring candidates that straddle a phase-set boundary) goes in a few odd-even rounds
+        bool todo = unsorted && !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 6);
+        if (todo) {
+            // what is left are long ascending runs: find where they start
+            for (uint32_t i = tid + 1; i < n; i += kSortThreads)
+                if (s_key[i] < s_key[i - 1]) {
+                    const uint32_t r = atomicAdd(&s_nruns, 1u);
+                    if (r < kMaxRuns) s_run[r] = i;
+                }
+            __syncthreads();
+        }
+        if (todo && s_nruns < kMaxRuns) {
+            // A few ascending runs (candidates ordered by type, then position -- stage A0's order -- give one run per
+            // type): merge them by rank.  An element's final place is its index in its own run plus, for every other
+            // run, the number of elements that go before it (<= for earlier runs, < for later ones: distinct places).
+            const uint32_t R = s_nruns + 1;
+            if (tid == 0) {
+                for (uint32_t a = 1; a < R - 1; ++a) {          // the descents were appended in any order
+                    const uint32_t v = s_run[a];
+                    uint32_t b = a;
+                    while (b > 0 && s_run[b - 1] > v) { s_run[b] = s_run[b - 1]; --b; }
+                    s_run[b] = v;
+                }
+                for (uint32_t a = R - 1; a > 0; --a) s_run[a] = s_run[a - 1];
+                s_run[0] = 0;
+                s_run[R] = n;
+            }
+            __syncthreads();
+            constexpr uint32_t kPer = (kSortLds + kSortThreads - 1) / kSortThreads;
+            uint32_t val[kPer], dst[kPer];
+#pragma unroll
+            for (uint32_t t = 0; t < kPer; ++t) {
+                const uint32_t i = tid + t * kSortThreads;
+                dst[t] = kEmpty;
+                if (i < n) {
+                    const uint32_t x = s_key[i];
+                    uint32_t mine = 0;
+                    while (s_run[mine + 1] <= i) ++mine;
+                    uint32_t at = i - s_run[mine];
+                    for (uint32_t q = 0; q < R; ++q) {
+                        if (q == mine) continue;
+                        const uint32_t *a = s_key + s_run[q];
+                        const uint32_t len = s_run[q + 1] - s_run[q];
+                        at += lower_bound_u32(a, len, q < mine ? x + 1u : x);       // PS <= 2^32 - 2: x + 1 cannot wrap
+                    }
+                    val[t] = x;
+                    dst[t] = at;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t t = 0; t < kPer; ++t)
+                if (dst[t] != kEmpty) s_key[dst[t]] = val[t];
+            __syncthreads();
+        } else if (todo) {
             bitonic_sort(s_key, n, tid, kSortThreads);
+        }
         STAMP(1, 2);
         n_one = unique_copy(s_key, n, glist, tid, kSortThreads, s_part);
     } else {
@@ -633,16 +783,6 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
 // ---------------------------------------------------------------------------------------------
 // kernel 3: contig drop, nearest PS, multi-PS vote + decision
 // ---------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t key)
-{
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 
 __device__ __forceinline__ bool is_member(const uint32_t *a, uint32_t n, uint32_t key)
 {
@@ -705,6 +845,7 @@ __device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *o
     }
 }
 
+template <bool DYN = false>
 __global__ __launch_bounds__(256) void ef_finalize(const Params p)
 {
     __shared__ uint32_t s_one[kOneLds];
@@ -713,11 +854,13 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
     STAMP(2, 0);
     const uint32_t c0 = blockIdx.x * 256u;
     const uint32_t c = c0 + tid;
-    const bool live = c < p.C;
+    const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
+    if (DYN && c0 >= n_cands) return;
+    const bool live = c < n_cands;
     const uint8_t code = live ? p.out_pred[c] : 0;
     const uint32_t ps_in = live ? p.out_ps[c] : 0;
     if (tid == 0) {
-        const uint32_t last = min(c0 + 255u, p.C - 1);
+        const uint32_t last = min(c0 + 255u, n_cands - 1);
         const uint32_t k0 = p.blk_ctg[blockIdx.x];
         uint32_t k1 = k0;
         while (last >= p.ctg_off[k1 + 1]) ++k1;
@@ -804,6 +947,20 @@ __global__ void plan_mark_starts(const uint32_t *ctg_off, uint32_t K, uint8_t *c
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K && ctg_off[k] < ctg_off[k + 1]) ctg_start[ctg_off[k]] = 1;
+}
+
+// device-planned runs: contig of the first candidate of every 256-candidate block, by binary search
+__global__ void plan_blk_ctg(const uint32_t *ctg_off, uint32_t K, uint32_t B, uint32_t *blk_ctg)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t c = b * kCandPerBlock;
+    uint32_t lo = 0, hi = K;                                   // the last k with ctg_off[k] <= c
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ctg_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    blk_ctg[b] = lo;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1058,11 +1215,83 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     else
         hipExtLaunchKernelGGL(ef_classify<false>, dim3(blocks), dim3(kCandPerBlock), 0, stream, ev[0], ev[1], 0, p);
     hipExtLaunchKernelGGL(ef_seed_sort, dim3(pr->n_contigs), dim3(kSortThreads), 0, stream, ev[2], ev[3], 0, p);
-    hipExtLaunchKernelGGL(ef_finalize, dim3((pr->n_cands + 255) / 256), dim3(256), 0, stream, ev[4], ev[5], 0, p);
+    hipExtLaunchKernelGGL(ef_finalize<false>, dim3((pr->n_cands + 255) / 256), dim3(256), 0, stream, ev[4], ev[5], 0, p);
     HIP_TRY(ctx, hipGetLastError());
     ctx->pending_check = true;
     return DUET_OK;
 }
+
+}  // extern "C"
+
+// Device-planned run (used by duet_svim_phase_device): the candidate count and the contig offsets exist only on the
+// device (d_n_cands, d_ctg_off[K+1]); every buffer and grid is sized for c_max candidates and the kernels read the real
+// count.  Nothing here waits for the device.
+int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
+                                  const uint32_t *d_ctg_off, uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream)
+{
+    const uint32_t K = pr->n_contigs, C = c_max;
+    if (K == 0 || C == 0) return DUET_OK;
+    const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
+    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
+    const size_t want[6] = {small_words * 4, C, (size_t)B * kCandPerBlock * 8, ((size_t)C + K + 1) * 4, ((size_t)C + K + 1) * 4,
+                            (size_t)B * kC2Quota * kC2Words * 4};
+    DevBuf *bufs[6] = {&ctx->ws_small, &ctx->ws_start, &ctx->ws_ent, &ctx->ws_one, &ctx->ws_tmp, &ctx->ws_c2};
+    bool grow = ctx->plan_stream != stream;
+    for (int i = 0; i < 6; ++i) grow = grow || want[i] > bufs[i]->cap;
+    int rc;
+    if (grow) {
+        HIP_TRY(ctx, hipDeviceSynchronize());                  // buffers of the previous plan may still be in use
+        for (int i = 0; i < 6; ++i)
+            if ((rc = reserve(ctx, *bufs[i], want[i]))) return rc;
+    }
+    uint32_t *w = (uint32_t *)ctx->ws_small.ptr;
+    ctx->d_ctg_off = w;            w += K + 1;
+    ctx->d_n_one = w;              w += K;
+    ctx->d_status = w;             w += 8;
+    ctx->d_blk_ctg = w;            w += B;
+    w += ((uintptr_t)w & 31) ? (32 - ((uintptr_t)w & 31)) / 4 : 0;
+    ctx->d_blk_cnt = w;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctg_off, d_ctg_off, sizeof(uint32_t) * (K + 1), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_n_one, 0, sizeof(uint32_t) * ((size_t)K + 8), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ws_start.ptr, 0, C, stream));
+    hipLaunchKernelGGL(plan_blk_ctg, dim3((B + 255) / 256), dim3(256), 0, stream, (const uint32_t *)ctx->d_ctg_off, K, B,
+                       ctx->d_blk_ctg);
+    hipLaunchKernelGGL(plan_mark_starts, dim3((K + 255) / 256), dim3(256), 0, stream, ctx->d_ctg_off, K,
+                       (uint8_t *)ctx->ws_start.ptr);
+    ctx->plan_off.clear();                                     // the cached host-side plan no longer describes the workspace
+    ctx->plan_C = 0;
+    ctx->plan_stream = stream;
+
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.K = K; p.C = C; p.M = pr->n_marks;
+    p.dyn_c = d_n_cands;
+    p.read_tag = pr->n_reads ? pr->read_tag : (const uint64_t *)ctx->d_n_one;
+    p.cand_pos = pr->cand_pos; p.cand_svlen = pr->cand_svlen; p.cand_svread = pr->cand_svread;
+    p.cand_refread = pr->cand_refread; p.cand_gt_ok = pr->cand_gt_ok;
+    p.cand_off = pr->cand_off; p.mark_read = pr->mark_read;
+    p.svlen_thres = pr->svlen_thres; p.suppread_thres = pr->suppread_thres;
+    p.ctg_off = ctx->d_ctg_off; p.ctg_start = (const uint8_t *)ctx->ws_start.ptr; p.blk_ctg = ctx->d_blk_ctg;
+    p.blk_rec = (uint64_t *)ctx->d_blk_cnt; p.seed_ent = (uint64_t *)ctx->ws_ent.ptr;
+    p.one_cap = C + K;
+    p.n_small = 0;
+    p.onebuf = (uint32_t *)ctx->ws_one.ptr; p.tmpbuf = (uint32_t *)ctx->ws_tmp.ptr;
+    p.n_one = ctx->d_n_one; p.c2rec = (uint32_t *)ctx->ws_c2.ptr; p.status = ctx->d_status;
+    p.out_pred = out_pred; p.out_ps = out_ps;
+    p.dbg = ctx->dbg;
+    p.stamps = ctx->d_stamps;
+    if (((uintptr_t)pr->mark_read & 15) == 0)
+        hipLaunchKernelGGL((ef_classify<true, true>), dim3(B), dim3(kCandPerBlock), 0, stream, p);
+    else
+        hipLaunchKernelGGL((ef_classify<false, true>), dim3(B), dim3(kCandPerBlock), 0, stream, p);
+    hipLaunchKernelGGL(ef_seed_sort, dim3(K), dim3(kSortThreads), 0, stream, p);
+    hipLaunchKernelGGL(ef_finalize<true>, dim3((C + 255) / 256), dim3(256), 0, stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->pending_check = true;
+    return DUET_OK;
+}
+
+extern "C" {
 
 int duet_ef_check(duet_ctx *ctx, void *stream_)
 {

@@ -65,6 +65,10 @@ inline int duet_fail(duet_ctx *ctx, int code, const std::string &msg)
                              std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
 
+// device-planned E/F run (duet_ef.hip), for the fused pipeline in duet_cluster.hip
+int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
+                                  const uint32_t *d_ctg_off, uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream);
+
 inline int duet_reserve(duet_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return DUET_OK;

@@ -173,21 +173,25 @@ class DeviceSvim(DeviceCluster):
         self.out_ps = torch.zeros(self.M + 16, dtype=torch.int32, device=self.device)
         self.n_found = 0
 
-    def run_fused(self, ctx, stream=None):
+    def run_fused(self, ctx, stream=None, wait=True):
+        """wait=True: the call learns the candidate count (one host round trip inside).  wait=False: fully
+        asynchronous; fetch() reads the count from the device."""
         if stream is None:
             stream = self.torch.cuda.current_stream(self.device).cuda_stream
         ct = self._ct
         n = ct.c_uint32(0)
         rc = ctx.lib.duet_svim_phase_device(ctx.handle, ct.byref(self.sv_problem), ct.byref(self.result),
                                             ct.c_void_p(self.out_pred.data_ptr()), ct.c_void_p(self.out_ps.data_ptr()),
-                                            ct.byref(n), ct.c_void_p(stream))
+                                            ct.byref(n) if wait else None, ct.c_void_p(stream))
         if rc:
             ctx._raise(rc)
-        self.n_found = n.value
+        self.n_found = n.value if wait else None
         return stream
 
     def fetch(self):
         """-> dict of the cluster arrays + pred/ps, trimmed to the candidate count (synchronises)."""
+        if self.n_found is None:
+            self.n_found = self.n_cands()
         N, M = self.n_found, self.M
         g = lambda key, dt, n: self.keep['out_' + key][:n * np.dtype(dt).itemsize].cpu().numpy().view(dt)
         return dict(order=g('order', np.uint32, M), cand_off=g('cand_off', np.uint32, N + 1),

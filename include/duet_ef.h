@@ -213,8 +213,10 @@ typedef struct duet_svim_problem {
     uint32_t reserved;
 } duet_svim_problem;
 
-/* res: device arrays as for duet_cluster_run_device (n_cands a device word); out_pred[M], out_ps[M] device;
- * *n_cands_host receives the candidate count. */
+/* res: device arrays as for duet_cluster_run_device (n_cands a device word); out_pred[M], out_ps[M] device.
+ * n_cands_host != NULL: the call waits once for the clustering to learn the candidate count, stores it there and
+ * plans E/F on the host.  n_cands_host == NULL: nothing waits -- E/F is planned on the device for the upper bound of M
+ * candidates and reads the count from res->n_cands; the caller gets the count from there after synchronising. */
 int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *prob, const duet_cluster_result *res,
                            uint8_t *out_pred, uint32_t *out_ps, uint32_t *n_cands_host, void *stream);
 

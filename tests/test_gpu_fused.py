@@ -39,8 +39,8 @@ def test_fused_pipeline_matches_oracle_composition(kind, seed):
     want_cl, want_pred, want_ps = oracle_fused(marks, soa.read_tag, depth, depth_off, 1000, 50, 2, len(contigs))
     ctx = _lib.Context(0)
     ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
-    for _ in range(2):                                   # twice: the second run reuses every workspace
-        ds.run_fused(ctx)
+    for wait in (True, False, True, False):              # with / without the host round trip; reruns reuse every workspace
+        ds.run_fused(ctx, wait=wait)
         got = ds.fetch()
         assert ds.n_found == len(want_cl['cand_pos'])
         for f in ('order', 'cand_off', 'cand_contig', 'cand_type', 'cand_pos', 'cand_span'):

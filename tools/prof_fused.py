@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""GPU-side diagnostic: the fused SVIM-mode pipeline a few times (for rocprofv3 --kernel-trace)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from duet_amd import _lib, engine, synth
+from duet_amd.devmem import DeviceSvim
+wait = len(sys.argv) > 1 and sys.argv[1] == 'wait'
+ctx = _lib.Context(0)
+contigs = [synth.bench_contig('1', 200000, 100000, 1)]
+soa = engine.soa_from_synth(contigs)
+marks = synth.raw_marks(contigs, 1, reads_of=soa)
+depth, depth_off = synth.depth_bins(contigs, 1000, 1)
+ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
+for _ in range(3):
+    ds.run_fused(ctx, wait=wait)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    ds.run_fused(ctx, wait=wait)
+torch.cuda.synchronize()
+print('fused ms/run', (time.perf_counter() - t0) / 10 * 1e3, 'wait' if wait else 'async')

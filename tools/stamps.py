@@ -13,8 +13,24 @@ ctx = _lib.Context(0)
 lib = _lib.load()
 lib.duet_dbg_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 which = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
-soa = engine.soa_from_synth([synth.bench_contig('1', 200000, 100000, 1)]) if which == 'cfg2' else \
-    engine.soa_from_synth(synth.bench_genome(20000000, 3))
+if which == 'fused':
+    # the E/F problem that stage A0 hands over in the fused pipeline (candidates ordered by type, then centre)
+    from oracle import c_oracle
+    contigs = [synth.bench_contig('1', 200000, 100000, 1)]
+    base = engine.soa_from_synth(contigs)
+    marks = synth.raw_marks(contigs, 1, reads_of=base)
+    depth, depth_off = synth.depth_bins(contigs, 1000, 1)
+    cl = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'])
+    N = len(cl['cand_pos'])
+    support = np.diff(cl['cand_off'].astype(np.int64))
+    k = cl['cand_contig'].astype(np.int64)
+    d = depth[depth_off[k] + np.minimum(cl['cand_pos'].astype(np.int64) // 1000, np.diff(depth_off)[k] - 1)].astype(np.int64)
+    soa = engine.EfSoA(cand_ctg_off=np.searchsorted(k, np.arange(2)), read_tag=base.read_tag, cand_pos=cl['cand_pos'],
+                       cand_svlen=cl['cand_span'], cand_svread=support, cand_refread=np.maximum(d - support, 0),
+                       cand_gt_ok=np.ones(N, dtype=np.uint8), cand_off=cl['cand_off'], mark_read=marks['read'][cl['order']])
+else:
+    soa = engine.soa_from_synth([synth.bench_contig('1', 200000, 100000, 1)]) if which == 'cfg2' else \
+        engine.soa_from_synth(synth.bench_genome(20000000, 3))
 dp = DeviceProblem(soa, 50, 2)
 stream = torch.cuda.current_stream().cuda_stream
 for _ in range(5):
