@@ -95,3 +95,47 @@ def test_python_int_forms_accepted(tmp_path):
     tab, soa = F.generate_callinfo(home + '/sv_calling/variants.vcf', F.read_hap_bam(home + '/snp_phasing/', 1, False), False)
     assert int(soa.cand_pos[0]) == 100 and int(soa.cand_svread[0]) == 5
     ing.close()
+
+
+def rows_from_pool(ing, rows, pred, ps):
+    """The data rows rebuilt in Python from what duet_ingest_get_rows hands to the device (text pool, CHROM ranks,
+    sign flags): the same ordering rule and layout as duet_rows_run_device, so the arrays are checked without a GPU."""
+    soa = ing.soa
+    pool = rows['pool'].tobytes()
+    off = rows['str_off']
+    keep = np.nonzero(pred)[0]
+    ctg = np.searchsorted(soa.cand_ctg_off, keep, side='right') - 1
+    cls = []
+    for c in keep:
+        m = soa.mark_read[soa.cand_off[c]:soa.cand_off[c + 1]]
+        m = m[m != 0xFFFFFFFF]
+        cls.append(min(len(set((soa.read_tag[m] & 0xFFFFFFFF).tolist())), 2))
+    order = sorted(range(len(keep)), key=lambda i: (int(rows['chrom_rank'][keep[i]]), int(soa.cand_pos[keep[i]]), int(ctg[i]),
+                                                    cls[i], int(keep[i])))
+    hp = {1: '1|0', 2: '0|1', 3: '1|1'}
+    out = []
+    for n, i in enumerate(order):
+        c = int(keep[i])
+        t = [pool[off[4 * c + f]:off[4 * c + f + 1]].decode() for f in range(4)]
+        mag = int(soa.cand_svlen[c])
+        signed = mag if (rows['plus'][c] or mag == 0) else -mag
+        out.append('%s\t%d\tDuet.%d\t%s\t%s\t.\tPASS\tSVLEN=%d;SVTYPE=<%s>\tHP:PS\t%s:%d\n' % (
+            t[0], int(soa.cand_pos[c]), n + 1, t[1], t[2], signed, t[3], hp[int(pred[c])], int(ps[c])))
+    return ''.join(out)
+
+
+@pytest.mark.parametrize('name,src,params', H.full_cases()[:4], ids=[c[0] for c in H.full_cases()[:4]])
+def test_rows_pool_and_header(name, src, params, tmp_path):
+    home = str(tmp_path / name)
+    shutil.copytree(src, home)
+    materialise_bams(home)
+    with open(os.path.join(src, 'phased_sv.vcf')) as f:
+        want = f.read()
+    ing = native.NativeIngest.load(home + '/sv_calling/variants.vcf', home + '/snp_phasing/', init_chrom_list(False, home), 2)
+    assert ing is not None and ing.handle is not None
+    rc, pred, ps = c_oracle.ef(ing.soa, params['svlen_thres'], params['suppread_thres'])
+    assert rc == 0
+    rows = ing.rows()
+    assert rows is not None and rows['n_chrom_texts'] >= 1
+    assert ing.header(False).decode() + rows_from_pool(ing, rows, pred, ps) == want
+    ing.close()
