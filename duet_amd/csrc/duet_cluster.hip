@@ -254,7 +254,7 @@ struct ExactSmem {
     uint8_t row[SUBS][NMAX];
 };
 
-template <int GROUP, int R>
+template <int GROUP, int R, bool WHOLE = false>
 __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
 {
     constexpr int NMAX = GROUP * R;
@@ -268,10 +268,12 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
     {
         const uint32_t li = base + sub;
         const bool has = li < L;
-        const uint32_t part = has ? list[2 * (size_t)li] : 0u, item = has ? list[2 * (size_t)li + 1] : 0u;
+        // WHOLE: the list holds partitions (one word each) and the item is the whole partition
+        const uint32_t part = has ? (WHOLE ? list[li] : list[2 * (size_t)li]) : 0u;
+        const uint32_t item = has && !WHOLE ? list[2 * (size_t)li + 1] : 0u;
         const uint32_t s = has ? p.part_start[part] : 0u;
         const uint32_t np = has ? p.part_start[part + 1] - s : 0u;       // rows of the partition
-        const uint32_t root = item & 0xFFu, n = has ? item >> 8 : 0u;    // n = rows of the component
+        const uint32_t root = item & 0xFFu, n = WHOLE ? np : (has ? item >> 8 : 0u);     // n = rows of the component
         __syncthreads();
         // gather the component's rows, in row order
         uint32_t filled = 0;
@@ -280,7 +282,7 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
         for (int d = 32; d > 0; d >>= 1) np_max = max(np_max, (uint32_t)__shfl_xor((int)np_max, d, 64));
         for (uint32_t k0 = 0; k0 < np_max; k0 += GROUP) {
             const uint32_t row = k0 + sl;
-            const bool mem = row < np && p.comp8[s + row] == root;
+            const bool mem = row < np && (WHOLE || p.comp8[s + row] == root);
             const unsigned long long bal = (__ballot(mem) >> (sub * GROUP)) & gm;
             if (mem) {
                 const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
@@ -411,8 +413,9 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
     }
 }
 
-// components of up to 64 rows, every size class in one launch (largest first); the rare larger ones have a launch
-// of their own (their distance matrix takes most of a CU's LDS)
+// components of up to 64 rows, every size class in one launch (largest first).  Partitions of more than 64 marks do not
+// go through the fast pass at all: one wavefront would spend ~100 us on one of them there, as long as the exact
+// agglomeration takes, so cl_exact_big takes them whole, on a side stream, while the fast pass handles the rest
 __global__ __launch_bounds__(64) void cl_exact_small(const ClParams p, const uint32_t *lists, const uint32_t *cnts)
 {
     __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 1>)];
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint3
 {
     __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 2>)];
     const uint32_t L = *count;
-    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2>(p, list, L, vb, smem);
+    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2, true>(p, list, L, vb, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -937,9 +940,8 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
 
 // every size class in one launch, largest partitions first (they are the longest chains): a virtual block is one
 // wave's worth of partitions of one class
-constexpr size_t kFastSmemBytes = sizeof(FastSmem<64, 2, 16>) > sizeof(FastSmem<8, 1, 4>) ? sizeof(FastSmem<64, 2, 16>) : sizeof(FastSmem<8, 1, 4>);
-static_assert(kFastSmemBytes >= sizeof(FastSmem<64, 1, 8>) && kFastSmemBytes >= sizeof(FastSmem<32, 1, 4>) &&
-              kFastSmemBytes >= sizeof(FastSmem<16, 1, 4>), "shared scratch too small");
+constexpr size_t kFastSmemBytes = sizeof(FastSmem<64, 1, 8>) > sizeof(FastSmem<8, 1, 4>) ? sizeof(FastSmem<64, 1, 8>) : sizeof(FastSmem<8, 1, 4>);
+static_assert(kFastSmemBytes >= sizeof(FastSmem<32, 1, 4>) && kFastSmemBytes >= sizeof(FastSmem<16, 1, 4>), "shared scratch too small");
 
 // one size class per launch: what large inputs use (the fused kernel needs the registers of all five variants at
 // once, which halves the occupancy; with millions of partitions per class there is nothing to gain from fusing)
@@ -955,12 +957,11 @@ __global__ __launch_bounds__(64) void cl_fast_one(const ClParams p, const uint32
 __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const ClWork work)
 {
     __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
-    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3], c4 = cnts[4];
-    const uint32_t b4 = c4, b3 = b4 + c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3];
+    const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
     const size_t M = p.M;
     for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
-        if (vb < b4) fast_unit<64, 2, 16>(p, lists + 4 * M, c4, vb, work, smem);
-        else if (vb < b3) fast_unit<64, 1, 8>(p, lists + 3 * M, c3, vb - b4, work, smem);
+        if (vb < b3) fast_unit<64, 1, 8>(p, lists + 3 * M, c3, vb, work, smem);
         else if (vb < b2) fast_unit<32, 1, 4>(p, lists + 2 * M, c2, (vb - b3) * 2, work, smem);
         else if (vb < b1) fast_unit<16, 1, 4>(p, lists + 1 * M, c1, (vb - b2) * 4, work, smem);
         else fast_unit<8, 1, 4>(p, lists, c0, (vb - b1) * 8, work, smem);
@@ -1034,14 +1035,16 @@ __device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *lis
     }
 }
 
-__global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts)
+// (the partitions of more than 64 marks -- all of them went to the exact pass -- come straight from their class list)
+__global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const uint32_t *big_list,
+                                                  const uint32_t *big_count)
 {
     __shared__ __align__(16) unsigned char smem[sizeof(RankSmem<64, 2>)];
-    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3], c4 = cnts[4];
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3], c4 = *big_count;
     const uint32_t b4 = c4, b3 = b4 + c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
     const size_t M = p.M;
     for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
-        if (vb < b4) rank_unit<64, 2>(p, lists + 4 * M, c4, vb, smem);
+        if (vb < b4) rank_unit<64, 2>(p, big_list, c4, vb, smem);
         else if (vb < b3) rank_unit<64, 1>(p, lists + 3 * M, c3, vb - b4, smem);
         else if (vb < b2) rank_unit<32, 1>(p, lists + 2 * M, c2, (vb - b3) * 2, smem);
         else if (vb < b1) rank_unit<16, 1>(p, lists + 1 * M, c1, (vb - b2) * 4, smem);
@@ -1225,14 +1228,18 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.fast = (pr->max_dist >= 0 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
     hipLaunchKernelGGL(cl_classes, dim3((M + 1023) / 1024), dim3(1024), 0, st, p, lists, cnts);
-    // fast pass (every size class in one launch), the exact agglomeration of the components it declined (the few of
-    // more than 64 rows on a side stream beside the rest), then the ranks of the partitions those belong to
+    // Partitions of more than 64 marks go whole to the exact pass, on a side stream, right away; beside them the fast
+    // pass over the other size classes (one launch for small inputs), then the exact agglomeration of the components it
+    // declined; then the ranks of the partitions that had any of those
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+    hipLaunchKernelGGL(cl_exact_big, dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p,
+                       (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
     const uint32_t gridw = M < 32768u ? M : 32768u;
     if (M <= (4u << 20)) {
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
     } else {
-        hipLaunchKernelGGL((cl_fast_one<64, 2, 16>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 4 * (size_t)M),
-                           (const uint32_t *)(cnts + 4), work);
         hipLaunchKernelGGL((cl_fast_one<64, 1, 8>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
                            (const uint32_t *)(cnts + 3), work);
         hipLaunchKernelGGL((cl_fast_one<32, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
@@ -1241,16 +1248,11 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
                            (const uint32_t *)(cnts + 1), work);
         hipLaunchKernelGGL((cl_fast_one<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), work);
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-    hipLaunchKernelGGL(cl_exact_big, dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, ctx->cl_side[0], p,
-                       (const uint32_t *)(work.comp_list + 3 * (size_t)M), (const uint32_t *)(work.comp_count + 3));
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
     hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
                        (const uint32_t *)work.comp_count);
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
     hipLaunchKernelGGL(cl_rank_all, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.rank_list,
-                       (const uint32_t *)work.rank_count);
+                       (const uint32_t *)work.rank_count, (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
     // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
     launch_scan<0>(LoadPcat{tmpA, tmpB, pc}, M, spart, StorePlain{cbase}, res->n_cands, st);   // cbase[s] = first candidate of the partition at s
