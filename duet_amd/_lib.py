@@ -23,7 +23,8 @@ KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
 # every symbol include/duet_ef.h declares (checked by tests/test_abi.py)
 EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
            'duet_ctx_set_profiling', 'duet_ctx_set_debug', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
-           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_rows_run_device')
+           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_rows_run_device',
+           'duet_ef_rows_run_host')
 
 
 class EfProblem(ctypes.Structure):
@@ -117,6 +118,8 @@ def load():
     lib.duet_cluster_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ClusterProblem), ctypes.POINTER(ClusterResult)]
     lib.duet_rows_run_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(RowsProblem), ctypes.c_void_p, ctypes.c_uint64,
                                          ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
+    lib.duet_ef_rows_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfProblem), ctypes.POINTER(RowsProblem), ctypes.c_void_p,
+                                          ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     lib.duet_svim_phase_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(SvimProblem), ctypes.POINTER(ClusterResult),
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
     _lib = lib
@@ -200,6 +203,30 @@ class Context(object):
         return st
 
     # -- stage A0: span-position clustering ---------------------------------------------------------
+    def ef_rows_host(self, soa, rows, svlen_thres, suppread_thres):
+        """duet_ef_rows_run_host: host arrays in (an EfSoA and NativeIngest.rows()), the text of the data rows out.
+        -> (bytes, number of rows)"""
+        p, keep = problem_from_arrays(soa, svlen_thres, suppread_thres)
+        pool = np.ascontiguousarray(rows['pool'], dtype=np.uint8)
+        str_off = np.ascontiguousarray(rows['str_off'], dtype=np.uint32)
+        rank = np.ascontiguousarray(rows['chrom_rank'], dtype=np.uint16)
+        plus = np.ascontiguousarray(rows['plus'], dtype=np.uint8)
+        r = RowsProblem()
+        r.n_contigs, r.n_cands = soa.n_contigs, soa.n_cands
+        r.n_chrom_texts, r.max_pos = int(rows['n_chrom_texts']), int(rows['max_pos'])
+        r.pool, r.pool_bytes, r.str_off = pool.ctypes.data, int(rows['pool_bytes']), str_off.ctypes.data
+        r.cand_chrom_rank, r.cand_plus = rank.ctypes.data, plus.ctypes.data
+        cap = int(rows['pool_bytes']) + 96 * soa.n_cands + 64
+        out = np.empty(cap, dtype=np.uint8)
+        n = ctypes.c_uint64(0)
+        n_rows = ctypes.c_uint32(0)
+        rc = self.lib.duet_ef_rows_run_host(self.handle, ctypes.byref(p), ctypes.byref(r), out.ctypes.data, ctypes.c_uint64(cap),
+                                            ctypes.byref(n), ctypes.byref(n_rows))
+        del keep
+        if rc:
+            self._raise(rc)
+        return out[:n.value].tobytes(), n_rows.value
+
     def rows_device(self, prob, out_ptr, cap, stream):
         """duet_rows_run_device: -> (bytes written, rows)."""
         n = ctypes.c_uint64(0)

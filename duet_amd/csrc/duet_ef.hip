@@ -1126,6 +1126,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf &b : ctx->cl_out) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->sv_ws) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->rows_ws) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->rows_in) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (int i = 0; i < 3; ++i) {
         if (ctx->cl_side[i]) (void)hipStreamDestroy(ctx->cl_side[i]);
@@ -1353,6 +1354,38 @@ int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t 
     return (int)n;
 }
 
+}  // extern "C"
+
+// host arrays of *pr -> the context's staging buffers (asynchronous on `s`); *d = the same problem with device pointers.
+// Also reserves the result buffers h_out[0] (pred) / h_out[1] (ps).
+int duet_ef_upload(duet_ctx *ctx, const duet_ef_problem *pr, duet_ef_problem *d, hipStream_t s)
+{
+    const uint32_t C = pr->n_cands, M = pr->n_marks, R = pr->n_reads;
+    const void *src[8] = {pr->read_tag, pr->cand_pos, pr->cand_svlen, pr->cand_svread, pr->cand_refread,
+                          pr->cand_gt_ok, pr->cand_off, pr->mark_read};
+    const size_t bytes[8] = {(size_t)R * 8, (size_t)C * 4, (size_t)C * 4, (size_t)C * 4, (size_t)C * 4,
+                             (size_t)C, ((size_t)C + 1) * 4, (size_t)M * 4};
+    int rc;
+    for (int i = 0; i < 8; ++i) {
+        if ((rc = reserve(ctx, ctx->h_in[i], bytes[i] ? bytes[i] : 16))) return rc;
+        if (bytes[i]) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_in[i].ptr, src[i], bytes[i], hipMemcpyHostToDevice, s));
+    }
+    if ((rc = reserve(ctx, ctx->h_out[0], C ? C : 16))) return rc;
+    if ((rc = reserve(ctx, ctx->h_out[1], C ? (size_t)C * 4 : 16))) return rc;
+    *d = *pr;
+    d->read_tag = (const uint64_t *)ctx->h_in[0].ptr;
+    d->cand_pos = (const uint32_t *)ctx->h_in[1].ptr;
+    d->cand_svlen = (const uint32_t *)ctx->h_in[2].ptr;
+    d->cand_svread = (const uint32_t *)ctx->h_in[3].ptr;
+    d->cand_refread = (const uint32_t *)ctx->h_in[4].ptr;
+    d->cand_gt_ok = (const uint8_t *)ctx->h_in[5].ptr;
+    d->cand_off = (const uint32_t *)ctx->h_in[6].ptr;
+    d->mark_read = (const uint32_t *)ctx->h_in[7].ptr;
+    return DUET_OK;
+}
+
+extern "C" {
+
 int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pred, uint32_t *out_ps, duet_ef_stats *stats)
 {
     int rc = validate(ctx, pr, out_pred, out_ps);
@@ -1362,28 +1395,11 @@ int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pred
         memset(stats, 0, sizeof(*stats));
         stats->algorithmic_bytes = 12ull * pr->n_marks + 27ull * pr->n_cands + 8ull * pr->n_reads;
     }
-    const uint32_t C = pr->n_cands, M = pr->n_marks, R = pr->n_reads;
+    const uint32_t C = pr->n_cands;
     if (C == 0) return DUET_OK;
-    const void *src[9] = {pr->read_tag, pr->cand_pos, pr->cand_svlen, pr->cand_svread, pr->cand_refread,
-                          pr->cand_gt_ok, pr->cand_off, pr->mark_read, nullptr};
-    const size_t bytes[9] = {(size_t)R * 8, (size_t)C * 4, (size_t)C * 4, (size_t)C * 4, (size_t)C * 4,
-                             (size_t)C, ((size_t)C + 1) * 4, (size_t)M * 4, 0};
     hipStream_t s = ctx->own_stream;
-    for (int i = 0; i < 8; ++i) {
-        if ((rc = reserve(ctx, ctx->h_in[i], bytes[i] ? bytes[i] : 16))) return rc;
-        if (bytes[i]) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_in[i].ptr, src[i], bytes[i], hipMemcpyHostToDevice, s));
-    }
-    if ((rc = reserve(ctx, ctx->h_out[0], C))) return rc;
-    if ((rc = reserve(ctx, ctx->h_out[1], (size_t)C * 4))) return rc;
-    duet_ef_problem d = *pr;
-    d.read_tag = (const uint64_t *)ctx->h_in[0].ptr;
-    d.cand_pos = (const uint32_t *)ctx->h_in[1].ptr;
-    d.cand_svlen = (const uint32_t *)ctx->h_in[2].ptr;
-    d.cand_svread = (const uint32_t *)ctx->h_in[3].ptr;
-    d.cand_refread = (const uint32_t *)ctx->h_in[4].ptr;
-    d.cand_gt_ok = (const uint8_t *)ctx->h_in[5].ptr;
-    d.cand_off = (const uint32_t *)ctx->h_in[6].ptr;
-    d.mark_read = (const uint32_t *)ctx->h_in[7].ptr;
+    duet_ef_problem d;
+    if ((rc = duet_ef_upload(ctx, pr, &d, s))) return rc;
     if ((rc = duet_ef_run_device(ctx, &d, (uint8_t *)ctx->h_out[0].ptr, (uint32_t *)ctx->h_out[1].ptr, s))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_pred, ctx->h_out[0].ptr, C, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(out_ps, ctx->h_out[1].ptr, (size_t)C * 4, hipMemcpyDeviceToHost, s));

@@ -1003,11 +1003,14 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
         }
         g->str_off[4 * C] = (uint32_t)at;
         g->max_pos = mp;
-        // rank of each CHROM text among the distinct ones, in byte order (what Python's string compare does at :229)
+        // rank of each CHROM text among the distinct ones, in byte order (what Python's string compare does at :229).
+        // Neighbouring candidates nearly always share the text: compare with the previous one before hashing.
+        auto same = [](const Span &x, const Span &y) { return x.n == y.n && memcmp(x.p, y.p, x.n) == 0; };
         std::vector<std::string> texts;
         {
             std::unordered_map<std::string, int> seen;
             for (size_t c = 0; c < C; ++c) {
+                if (c && same(g->c_chrom[c], g->c_chrom[c - 1])) continue;
                 std::string t(g->c_chrom[c].p, g->c_chrom[c].n);
                 if (seen.emplace(t, 1).second) texts.push_back(std::move(t));
             }
@@ -1020,7 +1023,9 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
         std::unordered_map<std::string, uint16_t> rank;
         for (size_t i = 0; i < texts.size(); ++i) rank.emplace(texts[i], (uint16_t)i);
         g->chrom_rank.resize(C);
-        for (size_t c = 0; c < C; ++c) g->chrom_rank[c] = rank[std::string(g->c_chrom[c].p, g->c_chrom[c].n)];
+        for (size_t c = 0; c < C; ++c)
+            g->chrom_rank[c] = (c && same(g->c_chrom[c], g->c_chrom[c - 1])) ? g->chrom_rank[c - 1]
+                                                                             : rank[std::string(g->c_chrom[c].p, g->c_chrom[c].n)];
         g->n_chrom_texts = (uint32_t)texts.size();
         g->rows_ready = true;
     }

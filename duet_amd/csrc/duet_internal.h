@@ -39,6 +39,7 @@ struct duet_ctx {
     // clustering (A0) workspace and host-run staging
     DevBuf cl_ws[14], cl_in[4], cl_out[6];
     DevBuf rows_ws[8];                     // device-side row emission
+    DevBuf rows_in[5];                     // host-array entry: uploaded text pool, offsets, ranks, sign flags; the rows
     DevBuf sv_ws[5];                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};
@@ -68,6 +69,9 @@ inline int duet_fail(duet_ctx *ctx, int code, const std::string &msg)
 // device-planned E/F run (duet_ef.hip), for the fused pipeline in duet_cluster.hip
 int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
                                   const uint32_t *d_ctg_off, uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream);
+
+// host arrays of an E/F problem -> the context's staging buffers (duet_ef.hip)
+int duet_ef_upload(duet_ctx *ctx, const duet_ef_problem *pr, duet_ef_problem *d, hipStream_t s);
 
 inline int duet_reserve(duet_ctx *ctx, DevBuf &b, size_t bytes)
 {

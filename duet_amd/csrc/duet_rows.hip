@@ -271,4 +271,50 @@ int duet_rows_run_device(duet_ctx *ctx, const duet_rows_problem *pr, char *out_t
     return DUET_OK;
 }
 
+int duet_ef_rows_run_host(duet_ctx *ctx, const duet_ef_problem *pr, const duet_rows_problem *rows, char *out_text, uint64_t out_cap,
+                          uint64_t *out_len, uint32_t *n_rows)
+{
+    if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
+    if (!pr || !rows || !out_len || !n_rows) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
+    *out_len = 0;
+    *n_rows = 0;
+    const uint32_t C = pr->n_cands;
+    if (C == 0) return DUET_OK;
+    if (rows->n_cands != C || !rows->cand_plus || !rows->cand_chrom_rank || !rows->pool || !rows->str_off || !out_text)
+        return duet_fail(ctx, DUET_ERR_INVALID, "rows description does not match the problem");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->own_stream;
+    int rc;
+    duet_ef_problem d;
+    if ((rc = duet_ef_upload(ctx, pr, &d, s))) return rc;
+    uint8_t *d_pred = (uint8_t *)ctx->h_out[0].ptr;
+    uint32_t *d_ps = (uint32_t *)ctx->h_out[1].ptr;
+    if ((rc = duet_ef_run_device(ctx, &d, d_pred, d_ps, s))) return rc;
+    const uint64_t cap = rows->pool_bytes + 96ull * C + 64;
+    const void *src[4] = {rows->pool, rows->str_off, rows->cand_chrom_rank, rows->cand_plus};
+    const size_t bytes[4] = {(size_t)rows->pool_bytes, ((size_t)4 * C + 1) * 4, (size_t)C * 2, (size_t)C};
+    for (int i = 0; i < 4; ++i) {
+        if ((rc = duet_reserve(ctx, ctx->rows_in[i], bytes[i] ? bytes[i] : 16))) return rc;
+        if (bytes[i]) HIP_TRY(ctx, hipMemcpyAsync(ctx->rows_in[i].ptr, src[i], bytes[i], hipMemcpyHostToDevice, s));
+    }
+    if ((rc = duet_reserve(ctx, ctx->rows_in[4], cap))) return rc;
+    if ((rc = duet_ef_check(ctx, s))) return rc;                  // division by zero etc. surfaces here, before any row
+    duet_rows_problem r = *rows;
+    r.n_contigs = pr->n_contigs;
+    r.cand_ctg_off = pr->cand_ctg_off;
+    r.pred = d_pred; r.ps = d_ps;
+    r.cand_pos = d.cand_pos; r.cand_svlen = d.cand_svlen;
+    r.pool = (const char *)ctx->rows_in[0].ptr;
+    r.str_off = (const uint32_t *)ctx->rows_in[1].ptr;
+    r.cand_chrom_rank = (const uint16_t *)ctx->rows_in[2].ptr;
+    r.cand_plus = (const uint8_t *)ctx->rows_in[3].ptr;
+    r.cand_off = d.cand_off; r.mark_read = d.mark_read; r.read_tag = d.read_tag;
+    uint64_t len = 0;
+    if ((rc = duet_rows_run_device(ctx, &r, (char *)ctx->rows_in[4].ptr, cap, &len, n_rows, s))) return rc;
+    if (len > out_cap) return duet_fail(ctx, DUET_ERR_INVALID, "output buffer too small for the rows");
+    if (len) HIP_TRY(ctx, hipMemcpy(out_text, ctx->rows_in[4].ptr, len, hipMemcpyDeviceToHost));
+    *out_len = len;
+    return DUET_OK;
+}
+
 }  // extern "C"

@@ -42,14 +42,10 @@ def _native(home, svlen_thres, suppread_thres, thread, include_all_ctgs, caller_
         logging.info('predict SV haplotypes in the callset')
         rows = None if os.environ.get('DUET_DEVICE_ROWS') == '0' else ing.rows()
         if rows is not None and ing.soa.n_cands:
-            # (pred, ps) stay on the device; it also orders and formats the rows (duet_rows_run_device)
-            from duet_amd.devmem import DeviceProblem, device_rows
-            ctx = engine.default_context()
-            dp = DeviceProblem(ing.soa, svlen_thres, suppread_thres)
-            stream = dp.run(ctx)
-            ctx.check(stream)
+            # (pred, ps) stay on the device; it also orders and formats the rows (duet_ef_rows_run_host)
+            body = engine.default_context().ef_rows_host(ing.soa, rows, svlen_thres, suppread_thres)[0]
             logging.info('write phased callset into .vcf file')
-            text = ing.header(include_all_ctgs) + device_rows(ctx, dp, rows, stream=stream)[0]
+            text = ing.header(include_all_ctgs) + body
         else:
             pred, ps = engine.run_ef(ing.soa, svlen_thres, suppread_thres)
             logging.info('write phased callset into .vcf file')

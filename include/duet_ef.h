@@ -252,6 +252,13 @@ typedef struct duet_rows_problem {
 int duet_rows_run_device(duet_ctx *ctx, const duet_rows_problem *prob, char *out_text, uint64_t out_cap, uint64_t *out_len,
                          uint32_t *n_rows, void *stream);
 
+/* Host-array convenience of the two together: *prob as for duet_ef_run_host, *rows with HOST arrays cand_plus,
+ * cand_chrom_rank, pool, str_off (+ n_cands, n_chrom_texts, max_pos, pool_bytes; the other fields are filled in here);
+ * uploads, runs E/F and the row emission on the device and copies the rows' text to out_text (host, out_cap bytes).
+ * Returns what duet_ef_run_host would (e.g. DUET_ERR_DIV_ZERO) before writing any row. */
+int duet_ef_rows_run_host(duet_ctx *ctx, const duet_ef_problem *prob, const duet_rows_problem *rows, char *out_text,
+                          uint64_t out_cap, uint64_t *out_len, uint32_t *n_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,8 @@ def test_device_rows_equal_host_rows_and_oracle(kind, seed, dialect):
         body, n_rows = device_rows(ctx, dp, rows, stream=stream)
         assert n_rows == int((pred != 0).sum())
         assert header + body == host
+        body2, n_rows2 = ctx.ef_rows_host(ing.soa, rows, 50, 2)           # the host-array entry: same bytes
+        assert (body2, n_rows2) == (body, n_rows)
         assert (header + body).decode() == want_text
         assert n_rows > 0
         ing.close()
@@ -74,11 +76,11 @@ def test_device_rows_equal_host_rows_and_oracle(kind, seed, dialect):
 
 def test_sv_phasing_uses_the_device_rows(monkeypatch):
     """The stage driver's default path formats the rows on the device."""
-    import duet_amd.devmem as devmem
+    from duet_amd import _lib
     from duet_amd.sv_phasing import sv_phasing
     calls = []
-    real = devmem.device_rows
-    monkeypatch.setattr(devmem, 'device_rows', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    real = _lib.Context.ef_rows_host
+    monkeypatch.setattr(_lib.Context, 'ef_rows_host', lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
     home = tempfile.mkdtemp(prefix='duet_rows_')
     try:
         H.build_case(home, 'chr21', 9, 'cutesv')
