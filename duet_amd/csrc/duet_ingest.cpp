@@ -204,6 +204,7 @@ struct duet_ingest {
     std::vector<uint16_t> chrom_rank;
     uint32_t n_chrom_texts = 0, max_pos = 0;
     bool rows_ready = false;
+    int threads = 4;                               // what parse_vcf was given
     // SVIM-mode signature extraction (optional, set before add_bam): CIGAR indels -> raw SV marks, binned depth
     bool extract = false;
     uint32_t min_sv_size = 40, min_mapq = 20, depth_bin = 1000;
@@ -603,6 +604,7 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
         fprintf(stderr, "[duet_ingest] %-14s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    g->threads = threads > 0 ? threads : 1;
     if (g->alias) return unsupported(g, "contig list names a contig twice");
     if (!read_file(path, g->vcf)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
     const char *d = g->vcf.data();
@@ -996,10 +998,25 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
             const Span *f[4] = {&g->c_chrom[c], &g->c_ref[c], &g->c_alt[c], &g->c_type[c]};
             for (int i = 0; i < 4; ++i) {
                 g->str_off[4 * c + i] = (uint32_t)at;
-                if (f[i]->n) memcpy(&g->pool[at], f[i]->p, f[i]->n);
                 at += f[i]->n;
             }
             mp = std::max(mp, g->cand_pos[c]);
+        }
+        {
+            // the copies, in parallel
+            const int T = (int)std::min<size_t>((size_t)std::max(1, g->threads), std::max<size_t>(1, C / 4096));
+            auto work = [&](int t) {
+                const size_t lo = C * (size_t)t / T, hi = C * (size_t)(t + 1) / T;
+                for (size_t c = lo; c < hi; ++c) {
+                    const Span *f[4] = {&g->c_chrom[c], &g->c_ref[c], &g->c_alt[c], &g->c_type[c]};
+                    for (int i = 0; i < 4; ++i)
+                        if (f[i]->n) memcpy(&g->pool[g->str_off[4 * c + i]], f[i]->p, f[i]->n);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto &th : pool) th.join();
         }
         g->str_off[4 * C] = (uint32_t)at;
         g->max_pos = mp;
