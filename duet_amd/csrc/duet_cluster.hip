@@ -413,9 +413,11 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
     }
 }
 
-// components of up to 64 rows, every size class in one launch (largest first).  Partitions of more than 64 marks do not
-// go through the fast pass at all: one wavefront would spend ~100 us on one of them there, as long as the exact
-// agglomeration takes, so cl_exact_big takes them whole, on a side stream, while the fast pass handles the rest
+// components of up to 64 rows, every size class in one launch (largest first).  For small inputs the partitions of more
+// than 64 marks do not go through the fast pass at all: one wavefront would spend ~100 us on one of them there, as long
+// as the exact agglomeration takes, so cl_exact_big<true> takes them whole, on a side stream, while the fast pass handles
+// the rest.  For large inputs there can be very many of them and throughput counts: the fast pass (20 waves per CU
+// instead of 2) settles what it can first, cl_exact_big<false> gets the components it leaves.
 __global__ __launch_bounds__(64) void cl_exact_small(const ClParams p, const uint32_t *lists, const uint32_t *cnts)
 {
     __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 1>)];
@@ -430,11 +432,12 @@ __global__ __launch_bounds__(64) void cl_exact_small(const ClParams p, const uin
     }
 }
 
+template <bool WHOLE>
 __global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint32_t *list, const uint32_t *count)
 {
     __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 2>)];
     const uint32_t L = *count;
-    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2, true>(p, list, L, vb, smem);
+    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2, WHOLE>(p, list, L, vb, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1228,18 +1231,26 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.fast = (pr->max_dist >= 0 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
     hipLaunchKernelGGL(cl_classes, dim3((M + 1023) / 1024), dim3(1024), 0, st, p, lists, cnts);
-    // Partitions of more than 64 marks go whole to the exact pass, on a side stream, right away; beside them the fast
-    // pass over the other size classes (one launch for small inputs), then the exact agglomeration of the components it
-    // declined; then the ranks of the partitions that had any of those
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-    hipLaunchKernelGGL(cl_exact_big, dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p,
-                       (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
     const uint32_t gridw = M < 32768u ? M : 32768u;
-    if (M <= (4u << 20)) {
+    const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+    if (small) {
+        // partitions of more than 64 marks go whole to the exact pass, on a side stream, right away; beside them the fast
+        // pass over the other size classes in one launch
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+        hipLaunchKernelGGL(cl_exact_big<true>, dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p,
+                           (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
     } else {
+        // one launch per size class (largest first), then the components of more than 64 rows on the side stream
+        hipLaunchKernelGGL((cl_fast_one<64, 2, 16>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 4 * (size_t)M),
+                           (const uint32_t *)(cnts + 4), work);
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+        hipLaunchKernelGGL(cl_exact_big<false>, dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p,
+                           (const uint32_t *)(work.comp_list + 3 * (size_t)M), (const uint32_t *)(work.comp_count + 3));
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
         hipLaunchKernelGGL((cl_fast_one<64, 1, 8>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
                            (const uint32_t *)(cnts + 3), work);
         hipLaunchKernelGGL((cl_fast_one<32, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
@@ -1251,8 +1262,12 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
                        (const uint32_t *)work.comp_count);
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
+    // ranks: the partitions of more than 64 marks come from their class list (small: all of them) or from the fast pass's
+    // list of unsettled ones
     hipLaunchKernelGGL(cl_rank_all, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.rank_list,
-                       (const uint32_t *)work.rank_count, (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
+                       (const uint32_t *)work.rank_count,
+                       (const uint32_t *)(small ? lists + 4 * (size_t)M : work.rank_list + 4 * (size_t)M),
+                       (const uint32_t *)(small ? cnts + 4 : work.rank_count + 4));
     // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
     // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
     launch_scan<0>(LoadPcat{tmpA, tmpB, pc}, M, spart, StorePlain{cbase}, res->n_cands, st);   // cbase[s] = first candidate of the partition at s
