@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU-side diagnostic: time the three kernels under ablation flags (duet_ctx_set_debug) at two sizes."""
-import ctypes, json, os, sys, time
+import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from duet_amd import _lib, engine, synth
