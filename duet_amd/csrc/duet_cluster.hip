@@ -82,6 +82,31 @@ __device__ __forceinline__ uint64_t centre_of(uint32_t pos, uint32_t span) { ret
 // keys + radix sort
 // ---------------------------------------------------------------------------------------------
 
+// without the caller's hints: the largest contig, type and centre, so that the sort key uses only the bits it needs
+__global__ __launch_bounds__(256) void cl_maxima(const ClParams p, uint32_t *out /* [0] contig, [1] type, [2..3] centre (u64) */)
+{
+    uint32_t mc = 0, mt = 0;
+    uint64_t mx = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.M; i += gridDim.x * blockDim.x) {
+        mc = max(mc, (uint32_t)p.contig[i]);
+        mt = max(mt, (uint32_t)p.type[i]);
+        const uint64_t c = centre_of(p.pos[i], p.span[i]);
+        mx = c > mx ? c : mx;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mc = max(mc, (uint32_t)__shfl_xor((int)mc, d, 64));
+        mt = max(mt, (uint32_t)__shfl_xor((int)mt, d, 64));
+        const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(mx >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)mx, d, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicMax(&out[0], mc);
+        atomicMax(&out[1], mt);
+        atomicMax((unsigned long long *)(out + 2), (unsigned long long)mx);
+    }
+}
+
 __global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1182,14 +1207,26 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     memset(&p, 0, sizeof(p));
     p.M = M; p.part_gap = pr->part_gap; p.part_max = pr->part_max;
     p.max_dist = pr->max_dist; p.normalizer = pr->normalizer;
-    const uint64_t max_centre = pr->max_pos_hint ? (uint64_t)pr->max_pos_hint + (pr->max_span_hint ? pr->max_span_hint : 0xFFFFFFFFull) / 2
-                                                 : 0x17FFFFFFFull;
-    p.centre_bits = bits_for(max_centre);
-    p.type_bits = bits_for(pr->n_types_hint ? pr->n_types_hint - 1 : 255);
-    const uint32_t contig_bits = bits_for(pr->n_contigs_hint ? pr->n_contigs_hint - 1 : 65535);
+    p.contig = pr->mark_contig; p.type = pr->mark_type; p.pos = pr->mark_pos; p.span = pr->mark_span;
+    uint32_t contig_bits;
+    if (pr->max_pos_hint && pr->max_span_hint && pr->n_types_hint && pr->n_contigs_hint) {
+        p.centre_bits = bits_for((uint64_t)pr->max_pos_hint + pr->max_span_hint / 2);
+        p.type_bits = bits_for(pr->n_types_hint - 1);
+        contig_bits = bits_for(pr->n_contigs_hint - 1);
+    } else {
+        // no (or partial) hints: measure -- one small kernel and one host round trip, instead of sorting 58-bit keys
+        uint32_t *d_max = scal + 28;
+        uint32_t h_max[4] = {0, 0, 0, 0};
+        HIP_TRY(ctx, hipMemsetAsync(d_max, 0, 16, st));
+        hipLaunchKernelGGL(cl_maxima, dim3((M + 2047) / 2048 < 1024u ? (M + 2047) / 2048 : 1024u), dim3(256), 0, st, p, d_max);
+        HIP_TRY(ctx, hipMemcpyAsync(h_max, d_max, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        p.centre_bits = bits_for(((uint64_t)h_max[3] << 32) | h_max[2]);
+        p.type_bits = bits_for(h_max[1]);
+        contig_bits = bits_for(h_max[0]);
+    }
     const uint32_t key_bits = p.centre_bits + p.type_bits + contig_bits;
     if (key_bits > 64) return duet_fail(ctx, DUET_ERR_INVALID, "sort key does not fit 64 bits");
-    p.contig = pr->mark_contig; p.type = pr->mark_type; p.pos = pr->mark_pos; p.span = pr->mark_span;
 
     const dim3 g256((M + 255) / 256), b256(256);
     uint2 *ps = (uint2 *)((uint32_t *)ctx->cl_ws[13].ptr + 2 * ((size_t)M + 1));

@@ -156,7 +156,8 @@ typedef struct duet_cluster_problem {
     uint32_t n_marks;               /* M */
     uint32_t part_gap;              /* 1000 */
     uint32_t part_max;              /* 100 (1..128) */
-    uint32_t n_contigs_hint;        /* 0 = unknown; only narrows the sort key */
+    uint32_t n_contigs_hint;        /* the four hints only narrow the sort key; when any is 0 the library measures the
+                                     * maxima itself (one small kernel + one host round trip) */
     uint32_t n_types_hint;          /* 0 = unknown */
     uint32_t max_pos_hint;          /* 0 = unknown */
     uint32_t max_span_hint;         /* 0 = unknown */
