@@ -93,36 +93,54 @@ def python_baseline(contigs, n_cands=4000):
             'sample': 'oracle/ef_oracle.py (pure Python, text VCF+SAM -> phased_sv.vcf text) on %d marks' % marks}
 
 
+GATHER_GROUP = 8          # jobs per all-gather at N > 1 (two groups rotate, so a group's collective overlaps the next group's kernels)
+
+
 def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
-    """W warm-up + K timed steps.  With world > 1 a step also all-gathers the per-candidate records; the
-    collective of job i is issued asynchronously (its own RCCL stream) into a rotating result block so that it
-    overlaps the kernels of job i+1 -- every job still gathers completely before the clock stops."""
-    from duet_amd import dist
+    """W warm-up + K timed steps.  With world > 1 every job's per-candidate records are all-gathered; the results of
+    GATHER_GROUP consecutive jobs sit side by side in one buffer and go out in ONE asynchronous collective (its own
+    RCCL stream) that overlaps the kernels of the following jobs -- a 0.5 MB-per-rank all-gather per 24 us job would be
+    bound by the collective's latency, not by the work.  Every job is gathered completely before the clock stops."""
     stream = torch.cuda.current_stream().cuda_stream
     n_slots = len(dp.out_blocks)
-    pending = [None] * n_slots
-    gathered = [None] * n_slots
+    rb = dp.out_blocks[0].numel()
+    G = GATHER_GROUP if world > 1 else 1
+    n_groups = max(1, n_slots // G)
+    pending = [None] * n_groups                  # collective in flight over a group's buffer
+    gathered = [None] * n_groups                 # [world, G, rb] (the first `filled` jobs of dim 1 are meaningful)
+    state = {'filled': 0, 'group': 0, 'last': None, 'slot': 0}
 
-    def one(i):
-        slot = i % n_slots
-        if pending[slot] is not None:
-            pending[slot].wait()                    # the block is about to be overwritten
-            pending[slot] = None
-        dp.run(ctx, stream, slot)
-        if world > 1:
-            if gathered[slot] is None:
-                gathered[slot] = torch.empty(world * dp.out_blocks[slot].numel(), dtype=torch.uint8,
-                                             device=dp.out_blocks[slot].device)
-            pending[slot] = dist_mod.all_gather_into_tensor(gathered[slot], dp.out_blocks[slot], async_op=True)
+    def flush():
+        g, k = state['group'], state['filled']
+        if world > 1 and k:
+            if gathered[g] is None:
+                gathered[g] = torch.empty(world * G * rb, dtype=torch.uint8, device=dp.out_storage.device)
+            src = dp.out_storage[g * G * rb:(g * G + k) * rb]
+            pending[g] = dist_mod.all_gather_into_tensor(gathered[g][:world * k * rb], src, async_op=True)
+            state['last'] = (g, k)
+        state['filled'] = 0
+        state['group'] = (g + 1) % n_groups
+
+    def one():
+        g = state['group']
+        if state['filled'] == 0 and pending[g] is not None:
+            pending[g].wait()                      # the group's buffer is about to be overwritten
+            pending[g] = None
+        state['slot'] = g * G + state['filled']
+        dp.run(ctx, stream, state['slot'])
+        state['filled'] += 1
+        if state['filled'] == G:
+            flush()
 
     def drain():
-        for s in range(n_slots):
-            if pending[s] is not None:
-                pending[s].wait()
-                pending[s] = None
+        flush()
+        for g in range(n_groups):
+            if pending[g] is not None:
+                pending[g].wait()
+                pending[g] = None
 
-    for i in range(warmup):
-        one(i)
+    for _ in range(warmup):
+        one()
     drain()
     ctx.check(stream)
     ctx.set_profiling(3)                 # HIP start/stop events on ef_classify's own dispatch, every 8th step
@@ -131,8 +149,8 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
         dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        one(i)
+    for _ in range(steps):
+        one()
     drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -142,14 +160,19 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
     # after the timed region: every kernel bracketed by its own dispatch events (serialises the stream, so it
     # is kept out of `value`); these are the durations rocprofv3 --kernel-trace reports
     ctx.set_profiling(2)
+    keep_slot = state['slot']
+    spare = (keep_slot + 1) % n_slots if n_slots > 1 else 0
     for _ in range(min(steps, 50)):
-        dp.run(ctx, stream, 0)
+        dp.run(ctx, stream, spare)
     torch.cuda.synchronize()
     iso = ctx.profile_collect()
     ctx.set_profiling(0)
     ctx.check(stream)
-    last = gathered[(steps - 1) % n_slots] if world > 1 else None
-    return dt, prof, iso, last
+    last = None
+    if world > 1 and state['last'] is not None:
+        g, k = state['last']
+        last = gathered[g][:world * k * rb].view(world, k, rb)[:, k - 1, :]       # every rank's block of the last job
+    return dt, prof, iso, last, keep_slot
 
 
 def main():
@@ -197,19 +220,19 @@ def main():
     contig = synth.bench_contig('1', 200000, 100000, 1 + rank, spelled='chr' + label)
     soa = engine.soa_from_synth([contig])
     n_max = soa.n_cands                      # every rank has exactly 100000 candidates
-    dp = DeviceProblem(soa, 50, 2, device='cuda:%d' % local_rank, n_cands_max=n_max, n_out=2 if world > 1 else 1)
+    dp = DeviceProblem(soa, 50, 2, device='cuda:%d' % local_rank, n_cands_max=n_max, n_out=2 * GATHER_GROUP if world > 1 else 2)
 
     with torch.cuda.stream(torch.cuda.Stream()):             # a stream of its own, not the legacy default stream
-        dt, prof, iso, gathered = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod)
+        dt, prof, iso, gathered, last_slot = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod)
 
     # correctness of what was timed (rank-local, against the C oracle) -- outside the timed region
-    pred, ps = dp.results((args.steps - 1) % len(dp.out_blocks))
+    pred, ps = dp.results(last_slot)
     from oracle import c_oracle
     rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
     parity = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
     if world > 1:
         # this rank's slice of the gathered block must be what it computed
-        mine = gathered.view(world, -1)[rank].cpu().numpy()
+        mine = gathered[rank].cpu().numpy()
         gp, gs = dist.unpack_block(mine, n_max, soa.n_cands)
         parity = parity and bool(np.array_equal(gp, want_pred) and np.array_equal(gs, want_ps))
 
@@ -241,7 +264,7 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: synthetic 1 contig per GPU, %d SV marks / %d candidates / '
                                    '%d tagged reads per contig, resident in HBM; step = classify+seed_sort+finalize%s'
                                    % (soa.n_marks, soa.n_cands, soa.n_reads,
-                                      ' + one all_gather_into_tensor of 5 B/candidate records (async, overlapping the next job)' if world > 1 else ''),
+                                      ' + all_gather_into_tensor of the 5 B/candidate records, %d jobs per collective (async, overlapping the next jobs)' % GATHER_GROUP if world > 1 else ''),
                        'marks_per_gpu': soa.n_marks, 'candidates_per_gpu': soa.n_cands, 'reads_per_gpu': soa.n_reads,
                        'parallelism': 'contig-sharded x%d' % world, 'svlen_thres': 50, 'suppread_thres': 2},
             'parity_vs_oracle': parity,

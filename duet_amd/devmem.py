@@ -34,8 +34,10 @@ class DeviceProblem(object):
         from duet_amd.dist import record_bytes
         self.n_max = max(int(n_cands_max or soa.n_cands), soa.n_cands, 1)
         # n_out > 1: rotating result blocks, so that the all-gather of one job can run beside the kernels of the next
-        self.out_blocks = [torch.zeros(record_bytes(self.n_max), dtype=torch.uint8, device=self.device)
-                           for _ in range(max(1, n_out))]
+        # (the blocks are slices of ONE allocation, so that several jobs' results can go into one collective)
+        rb = record_bytes(self.n_max)
+        self.out_storage = torch.zeros(rb * max(1, n_out), dtype=torch.uint8, device=self.device)
+        self.out_blocks = [self.out_storage[i * rb:(i + 1) * rb] for i in range(max(1, n_out))]
         self.out_block = self.out_blocks[0]
         self.problem = _lib.problem_from_device(soa, ptrs, svlen_thres, suppread_thres)
 
