@@ -101,43 +101,16 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
     GATHER_GROUP consecutive jobs sit side by side in one buffer and go out in ONE asynchronous collective (its own
     RCCL stream) that overlaps the kernels of the following jobs -- a 0.5 MB-per-rank all-gather per 24 us job would be
     bound by the collective's latency, not by the work.  Every job is gathered completely before the clock stops."""
+    from duet_amd.dist import GroupedGather
     stream = torch.cuda.current_stream().cuda_stream
     n_slots = len(dp.out_blocks)
-    rb = dp.out_blocks[0].numel()
-    G = GATHER_GROUP if world > 1 else 1
-    n_groups = max(1, n_slots // G)
-    pending = [None] * n_groups                  # collective in flight over a group's buffer
-    gathered = [None] * n_groups                 # [world, G, rb] (the first `filled` jobs of dim 1 are meaningful)
-    state = {'filled': 0, 'group': 0, 'last': None, 'slot': 0}
-
-    def flush():
-        g, k = state['group'], state['filled']
-        if world > 1 and k:
-            if gathered[g] is None:
-                gathered[g] = torch.empty(world * G * rb, dtype=torch.uint8, device=dp.out_storage.device)
-            src = dp.out_storage[g * G * rb:(g * G + k) * rb]
-            pending[g] = dist_mod.all_gather_into_tensor(gathered[g][:world * k * rb], src, async_op=True)
-            state['last'] = (g, k)
-        state['filled'] = 0
-        state['group'] = (g + 1) % n_groups
+    gg = GroupedGather(dp.out_storage, dp.out_blocks[0].numel(), world, GATHER_GROUP, dist_mod)
 
     def one():
-        g = state['group']
-        if state['filled'] == 0 and pending[g] is not None:
-            pending[g].wait()                      # the group's buffer is about to be overwritten
-            pending[g] = None
-        state['slot'] = g * G + state['filled']
-        dp.run(ctx, stream, state['slot'])
-        state['filled'] += 1
-        if state['filled'] == G:
-            flush()
+        dp.run(ctx, stream, gg.next_slot())
+        gg.job_enqueued()
 
-    def drain():
-        flush()
-        for g in range(n_groups):
-            if pending[g] is not None:
-                pending[g].wait()
-                pending[g] = None
+    drain = gg.drain
 
     for _ in range(warmup):
         one()
@@ -160,7 +133,7 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
     # after the timed region: every kernel bracketed by its own dispatch events (serialises the stream, so it
     # is kept out of `value`); these are the durations rocprofv3 --kernel-trace reports
     ctx.set_profiling(2)
-    keep_slot = state['slot']
+    keep_slot = gg.slot
     spare = (keep_slot + 1) % n_slots if n_slots > 1 else 0
     for _ in range(min(steps, 50)):
         dp.run(ctx, stream, spare)
@@ -168,10 +141,7 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
     iso = ctx.profile_collect()
     ctx.set_profiling(0)
     ctx.check(stream)
-    last = None
-    if world > 1 and state['last'] is not None:
-        g, k = state['last']
-        last = gathered[g][:world * k * rb].view(world, k, rb)[:, k - 1, :]       # every rank's block of the last job
+    last = gg.last_job_blocks()
     return dt, prof, iso, last, keep_slot
 
 

@@ -83,6 +83,64 @@ def allgather_records(local_block, world_size, group=None):
     return out.view(world_size, local_block.numel())
 
 
+class GroupedGather(object):
+    """The all-gather of many jobs' record blocks, `group` jobs per collective.
+
+    `storage` is one uint8 tensor of n_groups * group blocks of `rb` bytes (a job's results go into the block
+    next_slot() returns); when a group is full its blocks go out in ONE asynchronous all_gather_into_tensor, which
+    overlaps the jobs of the next group(s); a group's buffer is reused only after its collective has completed.
+    With world == 1 nothing is communicated and the slots simply rotate."""
+
+    def __init__(self, storage, rb, world, group, dist_mod=None):
+        self.storage, self.rb, self.world, self.dist = storage, int(rb), int(world), dist_mod
+        self.G = int(group) if world > 1 else 1
+        self.n_groups = max(1, storage.numel() // (self.rb * self.G))
+        self.pending = [None] * self.n_groups
+        self.gathered = [None] * self.n_groups
+        self.filled, self.group, self.last, self.slot = 0, 0, None, 0
+
+    def next_slot(self):
+        """Slot (block index in `storage`) for the next job; waits for the group's previous collective first."""
+        g = self.group
+        if self.filled == 0 and self.pending[g] is not None:
+            self.pending[g].wait()
+            self.pending[g] = None
+        self.slot = g * self.G + self.filled
+        return self.slot
+
+    def job_enqueued(self):
+        """The job writing into the slot of the last next_slot() has been enqueued on the current stream."""
+        self.filled += 1
+        if self.filled == self.G:
+            self.flush()
+
+    def flush(self):
+        g, k = self.group, self.filled
+        if self.world > 1 and k:
+            import torch
+            if self.gathered[g] is None:
+                self.gathered[g] = torch.empty(self.world * self.G * self.rb, dtype=torch.uint8, device=self.storage.device)
+            src = self.storage[g * self.G * self.rb:(g * self.G + k) * self.rb]
+            self.pending[g] = self.dist.all_gather_into_tensor(self.gathered[g][:self.world * k * self.rb], src, async_op=True)
+            self.last = (g, k)
+        self.filled = 0
+        self.group = (g + 1) % self.n_groups
+
+    def drain(self):
+        self.flush()
+        for g in range(self.n_groups):
+            if self.pending[g] is not None:
+                self.pending[g].wait()
+                self.pending[g] = None
+
+    def last_job_blocks(self):
+        """After drain(): uint8 [world, rb], every rank's block of the most recent job (None when world == 1)."""
+        if self.world == 1 or self.last is None:
+            return None
+        g, k = self.last
+        return self.gathered[g][:self.world * k * self.rb].view(self.world, k, self.rb)[:, k - 1, :]
+
+
 def unpack_block(block_u8, n_cands_max, n_cands):
     """numpy uint8 block -> (pred u8[n_cands], ps u32[n_cands])"""
     ps = block_u8[:4 * n_cands_max].view(np.uint32)[:n_cands]

@@ -80,3 +80,60 @@ def test_two_ranks_gloo(tmp_path, seed):
     for r in range(2):
         with open(str(tmp_path / ('rank%d' % r))) as f:
             assert f.read() == 'ok'
+
+
+def _grouped_worker(rank, world, port, n_jobs, out_dir):
+    """bench.py's N > 1 exchange: jobs write fixed-size record blocks, `group` of them per asynchronous all-gather,
+    two groups rotating.  Every job's block must arrive on every rank, also for a last, partly filled group."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        rb, G = 48, 4
+        storage = torch.zeros(2 * G * rb, dtype=torch.uint8)
+        gg = D.GroupedGather(storage, rb, world, G, dist)
+        ok = True
+        seen = 0
+        for job in range(n_jobs):
+            slot = gg.next_slot()
+            storage[slot * rb:(slot + 1) * rb] = (7 * job + 31 * rank + torch.arange(rb)) % 251      # the "results" of this job
+            gg.job_enqueued()
+            if gg.filled == 0 and gg.last is not None:                      # a collective was just issued
+                g, k = gg.last
+                gg.pending[g].wait()
+                got = gg.gathered[g][:world * k * rb].view(world, k, rb)
+                for r in range(world):
+                    for i in range(k):
+                        want = (7 * (job - k + 1 + i) + 31 * r + torch.arange(rb)) % 251
+                        ok = ok and bool(torch.equal(got[r, i].to(torch.int64), want))
+                seen += k
+        gg.drain()
+        last = gg.last_job_blocks()
+        for r in range(world):
+            want = (7 * (n_jobs - 1) + 31 * r + torch.arange(rb)) % 251
+            ok = ok and bool(torch.equal(last[r].to(torch.int64), want))
+        ok = ok and seen == (n_jobs // G) * G
+        with open(os.path.join(out_dir, 'rank%d' % rank), 'w') as f:
+            f.write('ok' if ok else 'mismatch')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_jobs', [3, 8, 21])
+def test_grouped_gather_two_ranks_gloo(tmp_path, n_jobs):
+    port = _free_port()
+    mp.spawn(_grouped_worker, args=(2, port, n_jobs, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        with open(str(tmp_path / ('rank%d' % r))) as f:
+            assert f.read() == 'ok'
+
+
+def test_grouped_gather_single_rank_rotates_slots():
+    storage = torch.zeros(2 * 16, dtype=torch.uint8)
+    gg = D.GroupedGather(storage, 16, 1, 8, None)
+    slots = []
+    for _ in range(5):
+        slots.append(gg.next_slot())
+        gg.job_enqueued()
+    gg.drain()
+    assert slots == [0, 1, 0, 1, 0] and gg.last_job_blocks() is None
