@@ -271,19 +271,22 @@ __device__ __forceinline__ double sp_distance(uint32_t pi, uint32_t spi, uint32_
 
 // Work item: one connected component of a partition's threshold graph (list entry = partition, then
 // root row | rows << 8), gathered in row order from the partition through comp8; writes label8 for its rows.
-template <int GROUP, int R>
+// NCAP = the most rows a unit can have (<= GROUP * R): with the default part_max of 100 the triangle of a >64-row unit
+// takes 39.6 KB instead of 65 KB, i.e. four wavefronts per CU -- one per SIMD -- instead of two.
+template <int GROUP, int R, int NCAP = GROUP * R>
 struct ExactSmem {
-    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R;
+    static constexpr int SUBS = 64 / GROUP, NMAX = NCAP;
     double d[SUBS][NMAX * (NMAX - 1) / 2];                   // upper triangle, row by row
-    uint32_t pos[SUBS][NMAX], span[SUBS][NMAX], size[SUBS][NMAX];
-    uint8_t row[SUBS][NMAX];
+    uint32_t pos[SUBS][NMAX], span[SUBS][NMAX];
+    uint8_t size[SUBS][NMAX], row[SUBS][NMAX];
 };
 
-template <int GROUP, int R, bool WHOLE = false>
+template <int GROUP, int R, bool WHOLE = false, int NCAP = GROUP * R>
 __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
 {
-    constexpr int NMAX = GROUP * R;
-    ExactSmem<GROUP, R> &X = *reinterpret_cast<ExactSmem<GROUP, R> *>(smem);
+    static_assert(NCAP <= GROUP * R && NCAP <= 128, "");
+    constexpr int NMAX = NCAP;
+    ExactSmem<GROUP, R, NCAP> &X = *reinterpret_cast<ExactSmem<GROUP, R, NCAP> *>(smem);
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     double *D = X.d[sub];
@@ -425,7 +428,7 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
                     if (do_merge && k == a) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; }
                     if (do_merge && k == b) alive[r] = false;
                 }
-                if (do_merge && sl == 0) X.size[sub][a] = za + zb;
+                if (do_merge && sl == 0) X.size[sub][a] = (uint8_t)(za + zb);
             }
             __syncthreads();
         }
@@ -457,12 +460,13 @@ __global__ __launch_bounds__(64) void cl_exact_small(const ClParams p, const uin
     }
 }
 
-template <bool WHOLE>
+template <bool WHOLE, int NCAP>
 __global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint32_t *list, const uint32_t *count)
 {
-    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 2>)];
+    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 2, NCAP>)];
+    static_assert(sizeof(ExactSmem<64, 2, 100>) <= 40960, "four units per CU");
     const uint32_t L = *count;
-    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2, WHOLE>(p, list, L, vb, smem);
+    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2, WHOLE, NCAP>(p, list, L, vb, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1271,22 +1275,25 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t gridw = M < 32768u ? M : 32768u;
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+    const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
     if (small) {
         // partitions of more than 64 marks go whole to the exact pass, on a side stream, right away; beside them the fast
         // pass over the other size classes in one launch
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-        hipLaunchKernelGGL(cl_exact_big<true>, dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p,
-                           (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cap100 ? cl_exact_big<true, 100> : cl_exact_big<true, 128>), dim3(grid < 4096u ? grid : 4096u),
+                           dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
         HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
     } else {
-        // one launch per size class (largest first), then the components of more than 64 rows on the side stream
-        hipLaunchKernelGGL((cl_fast_one<64, 2, 16>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 4 * (size_t)M),
-                           (const uint32_t *)(cnts + 4), work);
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+        // the side stream takes the partitions of more than 64 marks (few, long chains: a launch of their own would leave most
+        // of the chip idle) and then the components of more than 64 rows they leave; beside them one launch per size class
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-        hipLaunchKernelGGL(cl_exact_big<false>, dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p,
-                           (const uint32_t *)(work.comp_list + 3 * (size_t)M), (const uint32_t *)(work.comp_count + 3));
+        hipLaunchKernelGGL((cl_fast_one<64, 2, 16>), dim3(grid), dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(lists + 4 * (size_t)M),
+                           (const uint32_t *)(cnts + 4), work);
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], ctx->cl_side[0]));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cap100 ? cl_exact_big<false, 100> : cl_exact_big<false, 128>), dim3(grid < 4096u ? grid : 4096u),
+                           dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(work.comp_list + 3 * (size_t)M),
+                           (const uint32_t *)(work.comp_count + 3));
         HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
         hipLaunchKernelGGL((cl_fast_one<64, 1, 8>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
                            (const uint32_t *)(cnts + 3), work);
@@ -1295,6 +1302,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         hipLaunchKernelGGL((cl_fast_one<16, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
                            (const uint32_t *)(cnts + 1), work);
         hipLaunchKernelGGL((cl_fast_one<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), work);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[1], 0));        // cl_exact_small also takes what the >64 class left
     }
     hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
                        (const uint32_t *)work.comp_count);
