@@ -69,7 +69,7 @@ struct ClParams {
     uint8_t *comp8;                                   // [M] rows left to the exact pass: smallest row of their component; else 0xFF
     uint32_t *e_info, *e_pos, *e_span;                // [M] per sorted position: rank | end << 8 | cluster << 16 | head << 24; head means
     uint32_t *pc;                                     // [P] clusters per partition
-    const uint32_t *cbase;                            // [M] at a partition's start position: its first candidate
+    const uint32_t *cbase;                            // [P] first candidate of each partition
     // outputs
     uint32_t *order, *cand_off, *cand_pos, *cand_span;
     uint16_t *cand_contig;
@@ -134,10 +134,16 @@ struct LoadHead {
         return cut ? i : 0u;
     }
 };
-// clusters of the partition that starts at sorted position i, 0 elsewhere
-struct LoadPcat {
-    const uint32_t *flag, *pid, *pc;
-    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return flag[i] ? pc[pid[i]] : 0u; }
+// clusters of partition i.  The partition count lives on the device: the scan is launched over the M positions (an upper
+// bound) and the elements past the count neither load nor store anything
+struct LoadPc {
+    const uint32_t *pc, *n_parts;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return i < *n_parts ? pc[i] : 0u; }
+};
+struct StorePc {
+    uint32_t *out;
+    const uint32_t *n_parts;
+    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { if (i < *n_parts) out[i] = v; }
 };
 // v = start of i's natural partition (inclusive max of LoadHead): a partition starts there and every part_max marks after
 struct StoreFlag {
@@ -1096,7 +1102,7 @@ __global__ void cl_emit(const ClParams p, const uint32_t *flag, const uint32_t *
     p.order[s + (info & 0xFFu)] = a;
     if (p.sv_mark_out) p.sv_mark_out[s + (info & 0xFFu)] = p.sv_mark_in[a];
     if (info >> 24) {
-        const uint32_t cand = p.cbase[s] + ((info >> 16) & 0xFFu);
+        const uint32_t cand = p.cbase[part] + ((info >> 16) & 0xFFu);
         p.cand_off[cand + 1] = s + ((info >> 8) & 0xFFu);
         const uint64_t hi = p.skeys[i] >> p.centre_bits;                    // contig | type, straight from the sorted key
         const uint32_t k = (uint32_t)(hi >> p.type_bits), pos = p.e_pos[i];
@@ -1313,9 +1319,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
                        (const uint32_t *)work.rank_count,
                        (const uint32_t *)(small ? lists + 4 * (size_t)M : work.rank_list + 4 * (size_t)M),
                        (const uint32_t *)(small ? cnts + 4 : work.rank_count + 4));
-    // clusters per partition -> candidate bases.  The partition count lives on the device, so the counts are
-    // spread to the partitions' start positions (zero elsewhere) and scanned over the M sorted positions.
-    launch_scan<0>(LoadPcat{tmpA, tmpB, pc}, M, spart, StorePlain{cbase}, res->n_cands, st);   // cbase[s] = first candidate of the partition at s
+    // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
+    launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st);       // cbase[part] = its first candidate
     p.cbase = cbase;
     if (sv) {
         p.sv_mark_in = sv->mark_in; p.sv_depth = sv->depth; p.sv_depth_off = sv->depth_off; p.sv_depth_bin = sv->depth_bin;
