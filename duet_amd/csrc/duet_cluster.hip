@@ -50,6 +50,8 @@ struct ClParams {
     uint32_t part_gap, part_max;
     double max_dist, normalizer;
     uint32_t centre_bits, type_bits;                  // key = ((contig << type_bits | type) << centre_bits) | centre
+    uint32_t key_bits, idx_packed;                    // idx_packed: the mark index rides in the key's spare bits above key_bits (the
+                                                      // sort moves keys only); otherwise it is the sort's value array `sorted`
     const uint16_t *contig;
     const uint8_t *type;
     const uint32_t *pos, *span;
@@ -77,6 +79,7 @@ struct ClParams {
 };
 
 __device__ __forceinline__ uint64_t centre_of(uint32_t pos, uint32_t span) { return (uint64_t)pos + (span >> 1); }
+__host__ __device__ __forceinline__ uint64_t key_mask(uint32_t key_bits) { return key_bits >= 64u ? ~0ull : (1ull << key_bits) - 1ull; }
 
 // ---------------------------------------------------------------------------------------------
 // keys + radix sort
@@ -113,9 +116,10 @@ __global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 
     if (i >= p.M) return;
     const uint64_t hi = ((uint64_t)p.contig[i] << p.type_bits) | (uint64_t)p.type[i];
     const uint32_t ps_ = p.pos[i], sp_ = p.span[i];
-    keys[i] = (hi << p.centre_bits) | centre_of(ps_, sp_);
+    const uint64_t key = (hi << p.centre_bits) | centre_of(ps_, sp_);
     ps[i] = make_uint2(ps_, sp_);
-    vals[i] = i;
+    if (p.idx_packed) keys[i] = key | ((uint64_t)i << p.key_bits);
+    else { keys[i] = key; vals[i] = i; }
 }
 
 // element sources / sinks of the scans: what used to be separate elementwise kernels rides on the scan's own
@@ -125,10 +129,11 @@ __global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 
 struct LoadHead {
     const uint64_t *keys;
     uint32_t centre_bits, part_gap;
+    uint64_t km;                                            // the key proper (a packed mark index sits above it)
     __device__ __forceinline__ uint32_t operator()(uint32_t i) const
     {
         if (i == 0) return 0u;
-        const uint64_t a = keys[i - 1], b = keys[i];
+        const uint64_t a = keys[i - 1] & km, b = keys[i] & km;
         const uint64_t cm = (1ull << centre_bits) - 1ull;
         const bool cut = (a >> centre_bits) != (b >> centre_bits) || (b & cm) - (a & cm) > (uint64_t)part_gap;
         return cut ? i : 0u;
@@ -275,6 +280,12 @@ __device__ __forceinline__ double sp_distance(uint32_t pi, uint32_t spi, uint32_
     return dp + ds;
 }
 
+// index (into the caller's arrays) of the mark at sorted position i
+__device__ __forceinline__ uint32_t mark_at(const ClParams &p, uint32_t i)
+{
+    return p.idx_packed ? (uint32_t)(p.skeys[i] >> p.key_bits) : p.sorted[i];
+}
+
 // Work item: one connected component of a partition's threshold graph (list entry = partition, then
 // root row | rows << 8), gathered in row order from the partition through comp8; writes label8 for its rows.
 // NCAP = the most rows a unit can have (<= GROUP * R): with the default part_max of 100 the triangle of a >64-row unit
@@ -320,7 +331,7 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
             const unsigned long long bal = (__ballot(mem) >> (sub * GROUP)) & gm;
             if (mem) {
                 const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
-                const uint32_t a = p.sorted[s + row];
+                const uint32_t a = mark_at(p, s + row);
                 const uint2 q = p.ps[a];
                 X.pos[sub][ci] = q.x;
                 X.span[sub][ci] = q.y;
@@ -691,7 +702,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
             const uint32_t k = sl + r * GROUP;
             pk[r] = spk[r] = 0;
             if (k < n) {
-                const uint32_t a = p.sorted[s + k];
+                const uint32_t a = mark_at(p, s + k);
                 const uint2 q = p.ps[a];
                 pk[r] = q.x;
                 spk[r] = q.y;
@@ -1036,7 +1047,7 @@ __device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *lis
             const uint32_t k = sl + r * GROUP;
             lab[r] = 0xFFFFu;
             if (k < n) {
-                const uint32_t a = p.sorted[s + k];
+                const uint32_t a = mark_at(p, s + k);
                 S.ps[sub][k] = p.ps[a];
                 lab[r] = p.label8[s + k];
             }
@@ -1098,13 +1109,13 @@ __global__ void cl_emit(const ClParams p, const uint32_t *flag, const uint32_t *
     const uint32_t info = p.e_info[i];
     const uint32_t part = pid[i] - (flag[i] ? 0u : 1u);
     const uint32_t s = p.part_start[part];
-    const uint32_t a = p.sorted[i];
+    const uint32_t a = mark_at(p, i);
     p.order[s + (info & 0xFFu)] = a;
     if (p.sv_mark_out) p.sv_mark_out[s + (info & 0xFFu)] = p.sv_mark_in[a];
     if (info >> 24) {
         const uint32_t cand = p.cbase[part] + ((info >> 16) & 0xFFu);
         p.cand_off[cand + 1] = s + ((info >> 8) & 0xFFu);
-        const uint64_t hi = p.skeys[i] >> p.centre_bits;                    // contig | type, straight from the sorted key
+        const uint64_t hi = (p.skeys[i] & key_mask(p.key_bits)) >> p.centre_bits;                    // contig | type, straight from the sorted key
         const uint32_t k = (uint32_t)(hi >> p.type_bits), pos = p.e_pos[i];
         p.cand_contig[cand] = (uint16_t)k;
         p.cand_type[cand] = (uint8_t)(hi & ((1ull << p.type_bits) - 1ull));
@@ -1237,6 +1248,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     }
     const uint32_t key_bits = p.centre_bits + p.type_bits + contig_bits;
     if (key_bits > 64) return duet_fail(ctx, DUET_ERR_INVALID, "sort key does not fit 64 bits");
+    p.key_bits = key_bits;
+    p.idx_packed = key_bits + bits_for(M - 1) <= 64 && !(ctx->dbg & DUET_DBG_CLUSTER_PAIRS);
 
     const dim3 g256((M + 255) / 256), b256(256);
     uint2 *ps = (uint2 *)((uint32_t *)ctx->cl_ws[13].ptr + 2 * ((size_t)M + 1));
@@ -1244,12 +1257,13 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.ps = ps;
     uint64_t *kin = nullptr, *kout = nullptr;
     uint32_t *vin = nullptr;
-    radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, st, &kin, &vin, &kout);
+    if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, st, &kin, nullptr, &kout);
+    else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, st, &kin, &vin, &kout);
     p.sorted = vin;
     p.skeys = kin;
     // partitions: natural starts by a max-scan straight off the sorted keys (stores the start flags), then a sum-scan
     // of the flags that stores each position's partition id and the partition start list
-    launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap}, M, spart, StoreFlag{tmpA, p.part_max}, nullptr, st);
+    launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)}, M, spart, StoreFlag{tmpA, p.part_max}, nullptr, st);
     launch_scan<0>(LoadPlain{tmpA}, M, spart, StoreParts{tmpB, part_start, M}, scal, st, scal + 2);   // scal[0] = #partitions
     p.part_start = part_start; p.n_parts = scal; p.pc = pc;
     p.e_info = e_info;

@@ -11,7 +11,7 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
-__global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t nb,
+__global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t dmask, uint32_t nb,
                                                       uint32_t *hist /* [256][nb] */)
 {
     __shared__ uint32_t s_h[256];
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint
 #pragma unroll
     for (int it = 0; it < kRxItems; ++it) {
         const uint32_t i = base + it * kRxThreads + tid;
-        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & dmask], 1u);
     }
     __syncthreads();
     hist[(size_t)tid * nb + blockIdx.x] = s_h[tid];
@@ -134,20 +134,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32
     }
 }
 
-// stable scatter of one 8-bit digit; hist holds the scanned (digit-major) offsets.
+// stable scatter of one digit of up to 8 bits (dmask: the last pass of a sort may take fewer, so that whatever sits above the
+// sorted bits -- a payload packed into the key -- stays out of it); hist holds the scanned (digit-major) offsets.
+// VALS = false: keys only.
 // Each wave of a block owns a contiguous quarter of the block's 4096 keys and ranks it on its own (ballot match
 // inside the wave, a running per-digit count in the wave's LDS row: no workgroup barrier inside the loop; block
 // order = wave, round, lane = input order, so the sort stays stable).  The tile is then laid out digit-sorted in
 // LDS and written from there: consecutive lanes hold consecutive keys of one digit run, so each run leaves as whole
 // cache lines in one go.  (Writing straight from the ranking loop touched every run one 8-byte key at a time; with
 // thousands of blocks in flight the partly written lines fell out of L2 and the scatter ran at half this speed.)
+template <bool VALS>
 __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in, const uint32_t *vals_in, uint32_t n,
-                                                         uint32_t shift, uint32_t nb, const uint32_t *hist,
+                                                         uint32_t shift, uint32_t dmask, uint32_t nb, const uint32_t *hist,
                                                          uint64_t *keys_out, uint32_t *vals_out)
 {
     constexpr int kWaves = kRxThreads / 64, kPerWave = kRxTile / kWaves;
     __shared__ uint64_t s_key[kRxTile];
-    __shared__ uint32_t s_val[kRxTile];
+    __shared__ uint32_t s_val[VALS ? kRxTile : 1];
     __shared__ uint32_t s_gbase[256];                      // global position of the block's first key of each digit
     __shared__ uint32_t s_start[256];                      // where each digit starts inside the tile
     __shared__ uint32_t s_wloc[kWaves][256];               // per wave: keys of each digit so far; then the wave's offset
@@ -160,17 +163,17 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
     const uint32_t base = blockIdx.x * kRxTile, wbase = base + wave * kPerWave;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint64_t key[kRxItems];
-    uint32_t val[kRxItems], lrank[kRxItems];
+    uint32_t val[VALS ? kRxItems : 1], lrank[kRxItems];
 #pragma unroll
     for (int it = 0; it < kRxItems; ++it) {
         const uint32_t i = wbase + it * 64 + lane;
         key[it] = i < n ? keys_in[i] : ~0ull;
-        val[it] = i < n ? vals_in[i] : 0u;
+        if (VALS) val[it] = i < n ? vals_in[i] : 0u;
     }
 #pragma unroll
     for (int it = 0; it < kRxItems; ++it) {
         const bool valid = wbase + it * 64 + lane < n;
-        const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & dmask;
         unsigned long long same = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -212,10 +215,10 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
 #pragma unroll
     for (int it = 0; it < kRxItems; ++it) {
         if (wbase + it * 64 + lane < n) {
-            const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
+            const uint32_t d = (uint32_t)(key[it] >> shift) & dmask;
             const uint32_t at = s_start[d] + s_wloc[wave][d] + lrank[it];
             s_key[at] = key[it];
-            s_val[at] = val[it];
+            if (VALS) s_val[at] = val[it];
         }
     }
     __syncthreads();
@@ -225,10 +228,10 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
         const uint32_t q = it * kRxThreads + tid;
         if (q < count) {
             const uint64_t k = s_key[q];
-            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t d = (uint32_t)(k >> shift) & dmask;
             const uint32_t at = s_gbase[d] + (q - s_start[d]);
             keys_out[at] = k;
-            vals_out[at] = s_val[q];
+            if (VALS) vals_out[at] = s_val[q];
         }
     }
 }
@@ -250,8 +253,9 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
     hipLaunchKernelGGL((scan_apply<OP, Load, Store>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out);
 }
 
-// stable LSD radix sort of n (key, value) pairs on the low key_bits of the keys; buffers A hold the input, the result
-// ends in whichever pair of buffers *keys_out / *vals_out point to afterwards.  hist: 256 * ceil(n / kRxTile) words,
+// stable LSD radix sort of n (key, value) pairs -- or, with null value buffers, of the keys alone -- on the low key_bits of
+// the keys (bits above them are carried along untouched); buffers A hold the input, the result ends in whichever buffers
+// *keys_out / *vals_out point to afterwards.  hist: 256 * ceil(n / kRxTile) words,
 // spart: ceil(256 * ceil(n / kRxTile) / kScanTile) + 1 words.
 inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, uint32_t n, uint32_t key_bits,
                              uint32_t *hist, uint32_t *spart, hipStream_t st, uint64_t **keys_out, uint32_t **vals_out,
@@ -261,15 +265,20 @@ inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, 
     uint64_t *kin = keysA, *kout = keysB;
     uint32_t *vin = valsA, *vout = valsB;
     for (uint32_t shift = 0; shift < key_bits; shift += 8) {
-        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, n, shift, nb_rx, hist);
+        const uint32_t dmask = key_bits - shift >= 8 ? 255u : (1u << (key_bits - shift)) - 1u;
+        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist);
         launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st);     // in place: scan_apply reads a tile before writing it
-        hipLaunchKernelGGL(rx_scatter, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, (const uint32_t *)vin, n, shift,
-                           nb_rx, (const uint32_t *)hist, kout, vout);
+        if (valsA)
+            hipLaunchKernelGGL(rx_scatter<true>, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, (const uint32_t *)vin, n,
+                               shift, dmask, nb_rx, (const uint32_t *)hist, kout, vout);
+        else
+            hipLaunchKernelGGL(rx_scatter<false>, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, (const uint32_t *)nullptr,
+                               n, shift, dmask, nb_rx, (const uint32_t *)hist, kout, (uint32_t *)nullptr);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
     }
     *keys_out = kin;
-    *vals_out = vin;
+    if (vals_out) *vals_out = vin;
     if (keys_spare) *keys_spare = kout;
 }
 

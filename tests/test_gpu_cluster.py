@@ -23,8 +23,8 @@ def ctx():
 def check(ctx, marks, **kw):
     want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
     # hints on/off (sort key width), threshold-graph fast path on/off (DUET_DBG_CLUSTER_EXACT = 0x100)
-    # ... and the launch structure of large inputs (DUET_DBG_CLUSTER_LARGE = 0x200)
-    for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200)):
+    # ... the launch structure of large inputs (DUET_DBG_CLUSTER_LARGE = 0x200), the pair sort (DUET_DBG_CLUSTER_PAIRS = 0x400)
+    for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
