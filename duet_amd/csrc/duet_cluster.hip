@@ -152,17 +152,22 @@ struct StorePc {
 };
 // v = start of i's natural partition (inclusive max of LoadHead): a partition starts there and every part_max marks after
 struct StoreFlag {
-    uint32_t *flag;
+    uint8_t *flag;
     uint32_t part_max;
-    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { flag[i] = ((i - v) % part_max) == 0 ? 1u : 0u; }
+    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { flag[i] = ((i - v) % part_max) == 0 ? 1 : 0; }
 };
-// v = partitions that start before i (exclusive sum of the flags), in = i's own flag
+struct LoadFlag {
+    const uint8_t *flag;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return flag[i]; }
+};
+// v = partitions that start before i (exclusive sum of the flags), in = i's own flag; pid[i] = i's partition (position 0
+// always starts one)
 struct StoreParts {
     uint32_t *pid, *part_start;
     uint32_t M;
     __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t in) const
     {
-        pid[i] = v;
+        pid[i] = v + in - 1u;
         if (in) part_start[v] = i;
         if (i == M - 1) part_start[v + in] = M;
     }
@@ -1102,12 +1107,12 @@ __global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32
 }
 
 // one thread per sorted position: members to their place in order[], cluster heads write the candidate
-__global__ void cl_emit(const ClParams p, const uint32_t *flag, const uint32_t *pid)
+__global__ void cl_emit(const ClParams p, const uint32_t *pid)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.M) return;
     const uint32_t info = p.e_info[i];
-    const uint32_t part = pid[i] - (flag[i] ? 0u : 1u);
+    const uint32_t part = pid[i];
     const uint32_t s = p.part_start[part];
     const uint32_t a = mark_at(p, i);
     p.order[s + (info & 0xFFu)] = a;
@@ -1263,8 +1268,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.skeys = kin;
     // partitions: natural starts by a max-scan straight off the sorted keys (stores the start flags), then a sum-scan
     // of the flags that stores each position's partition id and the partition start list
-    launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)}, M, spart, StoreFlag{tmpA, p.part_max}, nullptr, st);
-    launch_scan<0>(LoadPlain{tmpA}, M, spart, StoreParts{tmpB, part_start, M}, scal, st, scal + 2);   // scal[0] = #partitions
+    launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)}, M, spart, StoreFlag{(uint8_t *)tmpA, p.part_max}, nullptr, st);
+    launch_scan<0>(LoadFlag{(const uint8_t *)tmpA}, M, spart, StoreParts{tmpB, part_start, M}, scal, st, scal + 2);   // scal[0] = #partitions
     p.part_start = part_start; p.n_parts = scal; p.pc = pc;
     p.e_info = e_info;
     p.e_pos = (uint32_t *)kout;                                   // the spare key buffer: 2 x M words
@@ -1342,7 +1347,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     }
     p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
     p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
-    hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpA, (const uint32_t *)tmpB);
+    hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpB);
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
         uint32_t h[32];

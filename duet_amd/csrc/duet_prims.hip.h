@@ -19,10 +19,17 @@ __global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint
     s_h[tid] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kRxTile;
+    // two keys per 16-byte load (the tile base is a multiple of kRxTile keys, the buffers are hipMalloc-aligned)
 #pragma unroll
-    for (int it = 0; it < kRxItems; ++it) {
-        const uint32_t i = base + it * kRxThreads + tid;
-        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & dmask], 1u);
+    for (int it = 0; it < kRxItems / 2; ++it) {
+        const uint32_t i = base + (it * kRxThreads + tid) * 2u;
+        if (i + 1 < n) {
+            const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(keys + i);
+            atomicAdd(&s_h[(uint32_t)(k2.x >> shift) & dmask], 1u);
+            atomicAdd(&s_h[(uint32_t)(k2.y >> shift) & dmask], 1u);
+        } else if (i < n) {
+            atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & dmask], 1u);
+        }
     }
     __syncthreads();
     hist[(size_t)tid * nb + blockIdx.x] = s_h[tid];
