@@ -545,7 +545,13 @@ struct BitSet {
     __device__ __forceinline__ bool equals(const BitSet &o) const { bool e = true; for (int i = 0; i < NW; ++i) e = e && w[i] == o.w[i]; return e; }
 };
 
-__device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b) { return __usad(a, b, 0u); }      // v_sad_u32
+// |a - b| in ONE instruction (__usad compiles to min, max, sub)
+__device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 // What cl_emit needs, per mark: its place in the partition's output, and at each cluster's smallest member the
 // cluster's rank, end and floor means.  F[r] = the cluster (bit set over the partition's rows) of this lane's row
