@@ -33,6 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "duet_ef.h"
@@ -556,9 +557,9 @@ __device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b)
 // What cl_emit needs, per mark: its place in the partition's output, and at each cluster's smallest member the
 // cluster's rank, end and floor means.  F[r] = the cluster (bit set over the partition's rows) of this lane's row
 // sl + r * GROUP; groups with go == false only keep the collective operations company.  Uses s_mask as scratch.
-template <int GROUP, int R, int NW, int NMAX>
+template <int GROUP, int R, int NW, int NMAX, class PsT>
 __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t part, uint32_t s, uint32_t n, uint32_t sub,
-                                          uint32_t sl, const BitSet<NW> (&F)[R], uint64_t (*s_mask)[NW], const uint2 *s_ps,
+                                          uint32_t sl, const BitSet<NW> (&F)[R], uint64_t (*s_mask)[NW], const PsT *s_ps,
                                           unsigned long long (*s_sum)[2])
 {
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
@@ -580,7 +581,7 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
     for (int r = 0; r < R; ++r) {
         const uint32_t k = sl + r * GROUP;
         if (go && k < n) {
-            const uint2 q = s_ps[k];
+            const PsT q = s_ps[k];
             atomicAdd(&s_sum[rt[r]][0], (unsigned long long)q.x);
             atomicAdd(&s_sum[rt[r]][1], (unsigned long long)q.y);
         }
@@ -679,7 +680,7 @@ __device__ __forceinline__ bool atoms_linkage(uint32_t m, double *D, double *sz,
 template <int GROUP, int R, int KA>
 struct FastSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
-    uint2 ps[SUBS][NMAX];                                    // (pos, span)
+    uint4 ps[SUBS][NMAX];                                    // (pos, span, end, centre): one 16-byte broadcast read per pair
     uint64_t mask[SUBS][NMAX][NW];
     double D[SUBS][KA][KA], sz[SUBS][KA];
     uint32_t csz[SUBS][NMAX];                                // rows per component, at the component's smallest row
@@ -717,10 +718,10 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 const uint2 q = p.ps[a];
                 pk[r] = q.x;
                 spk[r] = q.y;
-                S.ps[sub][k] = make_uint2(pk[r], spk[r]);
             }
             ek[r] = pk[r] + spk[r];
             ck[r] = pk[r] + (spk[r] >> 1);
+            if (k < n) S.ps[sub][k] = make_uint4(pk[r], spk[r], ek[r], ck[r]);
             bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits: leave it to the exact path
         }
         __syncthreads();
@@ -736,18 +737,34 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
 #pragma unroll
             for (int r = 0; r < R; ++r) N[l][r].clear();
         }
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint2 q = S.ps[sub][j];
-            const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
+        // (32 columns at a time: the bits of one mask word are collected in one register, two instructions per pair)
+        auto level0 = [&](auto wc) {
+            constexpr uint32_t W = decltype(wc)::value;
+            const uint32_t j1 = min(n, 32u * (W + 1u));
+            uint32_t acc[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
-                const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
-                const float dp = (float)m * p.inv_norm;
-                const bool e_hi = fs <= (p.t_hi[0] - dp) * fm, e_lo = fs <= (p.t_lo[0] - dp) * fm;
-                amb0r[r] = amb0r[r] || e_hi != e_lo;
-                N[0][r].set_if(e_hi, j);
+            for (int r = 0; r < R; ++r) acc[r] = 0;
+            for (uint32_t j = 32u * W; j < j1; ++j) {
+                const uint4 q = S.ps[sub][j];
+                const uint32_t ej = q.z, cj = q.w;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
+                    const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
+                    const float dp = (float)m * p.inv_norm;
+                    const bool e_hi = fs <= (p.t_hi[0] - dp) * fm, e_lo = fs <= (p.t_lo[0] - dp) * fm;
+                    amb0r[r] = amb0r[r] || e_hi != e_lo;
+                    acc[r] |= (e_hi ? 1u : 0u) << (j - 32u * W);
+                }
             }
+#pragma unroll
+            for (int r = 0; r < R; ++r) N[0][r].w[W >> 1] |= (uint64_t)acc[r] << (32u * (W & 1u));
+        };
+        level0(std::integral_constant<uint32_t, 0>{});
+        if constexpr (NMAX > 32) level0(std::integral_constant<uint32_t, 1>{});
+        if constexpr (NMAX > 64) {
+            level0(std::integral_constant<uint32_t, 2>{});
+            level0(std::integral_constant<uint32_t, 3>{});
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -790,21 +807,40 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
             // happens (every pair inside is closer than every pair across), so what remains is average linkage over
             // the atoms, decided from binary32 estimates of their average distances when that is safe
             const uint32_t nw = want2 ? n : 0u;
-            for (uint32_t j = 0; j < nw; ++j) {
-                const uint2 q = S.ps[sub][j];
-                const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
+            auto finer = [&](auto wc) {
+                constexpr uint32_t W = decltype(wc)::value;
+                const uint32_t j1 = min(nw, 32u * (W + 1u));
+                uint32_t acc[kLevels][R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
-                    const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
-                    const float dp = (float)m * p.inv_norm;
+                for (int l = 1; l < kLevels; ++l)
 #pragma unroll
-                    for (int l = 1; l < kLevels; ++l) {
-                        const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
-                        amb[l] = amb[l] || e_hi != e_lo;
-                        N[l][r].set_if(e_hi, j);
+                    for (int r = 0; r < R; ++r) acc[l][r] = 0;
+                for (uint32_t j = 32u * W; j < j1; ++j) {
+                    const uint4 q = S.ps[sub][j];
+                    const uint32_t ej = q.z, cj = q.w;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
+                        const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
+                        const float dp = (float)m * p.inv_norm;
+#pragma unroll
+                        for (int l = 1; l < kLevels; ++l) {
+                            const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
+                            amb[l] = amb[l] || e_hi != e_lo;
+                            acc[l][r] |= (e_hi ? 1u : 0u) << (j - 32u * W);
+                        }
                     }
                 }
+#pragma unroll
+                for (int l = 1; l < kLevels; ++l)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) N[l][r].w[W >> 1] |= (uint64_t)acc[l][r] << (32u * (W & 1u));
+            };
+            finer(std::integral_constant<uint32_t, 0>{});
+            if constexpr (NMAX > 32) finer(std::integral_constant<uint32_t, 1>{});
+            if constexpr (NMAX > 64) {
+                finer(std::integral_constant<uint32_t, 2>{});
+                finer(std::integral_constant<uint32_t, 3>{});
             }
 #pragma unroll
             for (int l = 1; l < kLevels; ++l)
@@ -855,9 +891,9 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                     for (int b = 0; b < KA; ++b) acc[r][b] = 0.f;
                 const uint32_t n2 = two ? n : 0u;
                 for (uint32_t j = 0; j < n2; ++j) {
-                    const uint2 q = S.ps[sub][j];
+                    const uint4 q = S.ps[sub][j];
                     const uint32_t aj = S.atom[sub][j];
-                    const uint32_t ej = q.x + q.y, cj = q.x + (q.y >> 1);
+                    const uint32_t ej = q.z, cj = q.w;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const uint32_t mm = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
