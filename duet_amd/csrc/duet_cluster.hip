@@ -884,31 +884,37 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 for (uint32_t e = sl; e < (uint32_t)(KA * KA); e += GROUP) S.D[sub][e / KA][e % KA] = 0.0;
             __syncthreads();
             if (__ballot(two)) {
-                float acc[R][KA];
+                // Row k's distances to the columns of one atom, summed while consecutive columns stay in that atom and
+                // then added to the atom pair's total in LDS (rows are in centre order, atoms mostly contiguous runs:
+                // about one flush per atom instead of a select per atom for every column; any order is correct)
+                float cur[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int b = 0; b < KA; ++b) acc[r][b] = 0.f;
+                for (int r = 0; r < R; ++r) cur[r] = 0.f;
                 const uint32_t n2 = two ? n : 0u;
+                uint32_t prev = n2 ? (uint32_t)S.atom[sub][0] : 0u;
+                auto flush = [&](uint32_t b) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (sl + r * GROUP < n && b != ai[r]) atomicAdd(&S.D[sub][ai[r]][b], (double)cur[r]);
+                        cur[r] = 0.f;
+                    }
+                };
                 for (uint32_t j = 0; j < n2; ++j) {
                     const uint4 q = S.ps[sub][j];
                     const uint32_t aj = S.atom[sub][j];
                     const uint32_t ej = q.z, cj = q.w;
+                    if (aj != prev) {
+                        flush(prev);
+                        prev = aj;
+                    }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const uint32_t mm = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
                         const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
-                        const float d = (float)mm * p.inv_norm + fs * __builtin_amdgcn_rcpf(fm);
-#pragma unroll
-                        for (int b = 0; b < KA; ++b) acc[r][b] += aj == (uint32_t)b ? d : 0.f;
+                        cur[r] += (float)mm * p.inv_norm + fs * __builtin_amdgcn_rcpf(fm);
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (two && sl + r * GROUP < n)
-#pragma unroll
-                        for (int b = 0; b < KA; ++b)
-                            if ((uint32_t)b != ai[r] && (uint32_t)b < m) atomicAdd(&S.D[sub][ai[r]][b], (double)acc[r][b]);
+                if (n2) flush(prev);
                 __syncthreads();
                 if (two) {
                     // averages into the upper triangle (lanes share the pairs), then every lane of the group
