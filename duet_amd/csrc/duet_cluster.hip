@@ -802,6 +802,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
         const bool amb0 = group_any(amb[0]), cl0 = cliques(N[0]);       // collective: every lane takes part
         bool solved = n < 2 || (!unfit && !amb0 && cl0);
         const bool want2 = has && !solved && !unfit;
+        if (work.why && want2 && sl == 0) atomicAdd(&work.why[(GROUP == 64 ? (R == 2 ? 0 : 4) : 8) + 3], 1u);     // level 0 did not settle it
         if (__ballot(want2)) {
             // atoms: the cliques of the finest usable level -- they are complete clusters before anything else
             // happens (every pair inside is closer than every pair across), so what remains is average linkage over
@@ -1402,8 +1403,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         HIP_TRY(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u components %u %u %u %u partitions to rank %u %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
-        fprintf(stderr, "[duet_cluster] gave up (no clean level / too many atoms / decision too close): >64: %u %u %u  33..64: %u %u %u  <=32: %u %u %u\n",
-                h[16], h[17], h[18], h[20], h[21], h[22], h[24], h[25], h[26]);
+        fprintf(stderr, "[duet_cluster] gave up (no clean level / too many atoms / decision too close): >64: %u %u %u  33..64: %u %u %u  <=32: %u %u %u;  "
+                        "not settled by level 0: %u %u %u\n",
+                h[16], h[17], h[18], h[20], h[21], h[22], h[24], h[25], h[26], h[19], h[23], h[27]);
     }
     return DUET_OK;
 }
