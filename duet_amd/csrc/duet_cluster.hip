@@ -58,6 +58,8 @@ struct ClParams {
     const uint32_t *pos, *span;
     const uint32_t *sorted;                           // mark index at each sorted position
     const uint2 *ps;                                  // (pos, span) per mark, side by side: one gather instead of two
+    const uint4 *rec4;                                // fused pipeline instead: (pos, span, read index, -) -- the agglomeration's gather
+                                                      // also fetches what the output needs, cl_emit does not gather again
     const uint64_t *skeys;                            // the sorted keys (contig | type | centre)
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
@@ -111,14 +113,15 @@ __global__ __launch_bounds__(256) void cl_maxima(const ClParams p, uint32_t *out
     }
 }
 
-__global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps)
+__global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps, uint4 *rec4)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.M) return;
     const uint64_t hi = ((uint64_t)p.contig[i] << p.type_bits) | (uint64_t)p.type[i];
     const uint32_t ps_ = p.pos[i], sp_ = p.span[i];
     const uint64_t key = (hi << p.centre_bits) | centre_of(ps_, sp_);
-    ps[i] = make_uint2(ps_, sp_);
+    if (p.sv_mark_in) rec4[i] = make_uint4(ps_, sp_, p.sv_mark_in[i], 0u);
+    else ps[i] = make_uint2(ps_, sp_);
     if (p.idx_packed) keys[i] = key | ((uint64_t)i << p.key_bits);
     else { keys[i] = key; vals[i] = i; }
 }
@@ -292,6 +295,17 @@ __device__ __forceinline__ uint32_t mark_at(const ClParams &p, uint32_t i)
     return p.idx_packed ? (uint32_t)(p.skeys[i] >> p.key_bits) : p.sorted[i];
 }
 
+// (pos, span, read index) of mark a (the read index only in the fused pipeline)
+__device__ __forceinline__ uint3 load_rec(const ClParams &p, uint32_t a)
+{
+    if (p.rec4) {
+        const uint4 q = p.rec4[a];
+        return make_uint3(q.x, q.y, q.z);
+    }
+    const uint2 q = p.ps[a];
+    return make_uint3(q.x, q.y, 0u);
+}
+
 // Work item: one connected component of a partition's threshold graph (list entry = partition, then
 // root row | rows << 8), gathered in row order from the partition through comp8; writes label8 for its rows.
 // NCAP = the most rows a unit can have (<= GROUP * R): with the default part_max of 100 the triangle of a >64-row unit
@@ -338,7 +352,7 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
             if (mem) {
                 const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
                 const uint32_t a = mark_at(p, s + row);
-                const uint2 q = p.ps[a];
+                const uint3 q = load_rec(p, a);
                 X.pos[sub][ci] = q.x;
                 X.span[sub][ci] = q.y;
                 X.size[sub][ci] = 1;
@@ -560,7 +574,7 @@ __device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b)
 template <int GROUP, int R, int NW, int NMAX, class PsT>
 __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t part, uint32_t s, uint32_t n, uint32_t sub,
                                           uint32_t sl, const BitSet<NW> (&F)[R], uint64_t (*s_mask)[NW], const PsT *s_ps,
-                                          unsigned long long (*s_sum)[2])
+                                          unsigned long long (*s_sum)[2], const uint32_t (&mk)[R], const uint32_t (&rd)[R])
 {
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     __syncthreads();
@@ -614,9 +628,11 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
         const uint32_t k = sl + r * GROUP;
         if (k < n) {
             const bool head = rt[r] == k;
-            const uint32_t size = F[r].count();
-            p.e_info[s + k] = (before[r] + F[r].count_below(k)) | ((before[r] + size) << 8) |
-                              (heads.count_below(rt[r]) << 16) | (head ? 1u << 24 : 0u);
+            const uint32_t size = F[r].count(), rank = before[r] + F[r].count_below(k);
+            p.e_info[s + k] = rank | ((before[r] + size) << 8) | (heads.count_below(rt[r]) << 16) | (head ? 1u << 24 : 0u);
+            // the mark's place in the output: clusters in order of their smallest member, members in sorted order
+            p.order[s + rank] = mk[r];
+            if (p.sv_mark_out) p.sv_mark_out[s + rank] = rd[r];
             if (head) {
                 // floor means.  A sum stays below 2^40 and size <= 128, so the correctly rounded binary64 quotient
                 // lies strictly between the same two integers as the true one (or is that integer): no 64-bit division
@@ -707,17 +723,18 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
         const uint32_t s = has ? p.part_start[part] : 0u;
         const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
         __syncthreads();
-        uint32_t pk[R], spk[R], ek[R], ck[R];
+        uint32_t pk[R], spk[R], ek[R], ck[R], mk[R], rd[R];
         bool bad = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t k = sl + r * GROUP;
-            pk[r] = spk[r] = 0;
+            pk[r] = spk[r] = mk[r] = rd[r] = 0;
             if (k < n) {
-                const uint32_t a = mark_at(p, s + k);
-                const uint2 q = p.ps[a];
+                mk[r] = mark_at(p, s + k);
+                const uint3 q = load_rec(p, mk[r]);
                 pk[r] = q.x;
                 spk[r] = q.y;
+                rd[r] = q.z;
             }
             ek[r] = pk[r] + spk[r];
             ck[r] = pk[r] + (spk[r] >> 1);
@@ -1037,7 +1054,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 work.rank_list[(size_t)rc * p.M + atomicAdd(&work.rank_count[rc], 1u)] = part;
             }
         }
-        emit_prep<GROUP, R, NW, NMAX>(p, has && solved, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub]);
+        emit_prep<GROUP, R, NW, NMAX>(p, has && solved, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
     }
 }
 
@@ -1095,14 +1112,17 @@ __device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *lis
         const uint32_t s = has ? p.part_start[part] : 0u;
         const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
         __syncthreads();
-        uint32_t lab[R];
+        uint32_t lab[R], mk[R], rd[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t k = sl + r * GROUP;
             lab[r] = 0xFFFFu;
+            mk[r] = rd[r] = 0;
             if (k < n) {
-                const uint32_t a = mark_at(p, s + k);
-                S.ps[sub][k] = p.ps[a];
+                mk[r] = mark_at(p, s + k);
+                const uint3 q = load_rec(p, mk[r]);
+                S.ps[sub][k] = make_uint2(q.x, q.y);
+                rd[r] = q.z;
                 lab[r] = p.label8[s + k];
             }
         }
@@ -1134,7 +1154,7 @@ __device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *lis
             if (any)
                 for (int i = 0; i < NW; ++i) left.w[i] &= (h >> 6) == (uint32_t)i ? ~(1ull << (h & 63u)) : ~0ull;
         }
-        emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub]);
+        emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
     }
 }
 
@@ -1161,12 +1181,9 @@ __global__ void cl_emit(const ClParams p, const uint32_t *pid)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.M) return;
     const uint32_t info = p.e_info[i];
-    const uint32_t part = pid[i];
-    const uint32_t s = p.part_start[part];
-    const uint32_t a = mark_at(p, i);
-    p.order[s + (info & 0xFFu)] = a;
-    if (p.sv_mark_out) p.sv_mark_out[s + (info & 0xFFu)] = p.sv_mark_in[a];
-    if (info >> 24) {
+    if (info >> 24) {                                                            // a cluster's smallest member speaks for the candidate
+        const uint32_t part = pid[i];
+        const uint32_t s = p.part_start[part];
         const uint32_t cand = p.cbase[part] + ((info >> 16) & 0xFFu);
         p.cand_off[cand + 1] = s + ((info >> 8) & 0xFFu);
         const uint64_t hi = (p.skeys[i] & key_mask(p.key_bits)) >> p.centre_bits;                    // contig | type, straight from the sorted key
@@ -1263,7 +1280,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 128, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2 + (size_t)M * 8};
+                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 128, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8)};
     int rc;
     for (int i = 0; i < 14; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
@@ -1305,10 +1322,19 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.key_bits = key_bits;
     p.idx_packed = key_bits + bits_for(M - 1) <= 64 && !(ctx->dbg & DUET_DBG_CLUSTER_PAIRS);
 
+    // outputs (the agglomeration kernels write the marks' output order themselves)
+    if (sv) {
+        p.sv_mark_in = sv->mark_in; p.sv_depth = sv->depth; p.sv_depth_off = sv->depth_off; p.sv_depth_bin = sv->depth_bin;
+        p.sv_mark_out = sv->mark_out; p.sv_svread = sv->svread; p.sv_refread = sv->refread; p.sv_gt = sv->gt;
+    }
+    p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
+    p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
+
     const dim3 g256((M + 255) / 256), b256(256);
-    uint2 *ps = (uint2 *)((uint32_t *)ctx->cl_ws[13].ptr + 2 * ((size_t)M + 1));
-    hipLaunchKernelGGL(cl_keys, g256, b256, 0, st, p, keysA, valsA, ps);
-    p.ps = ps;
+    unsigned char *recs = (unsigned char *)ctx->cl_ws[13].ptr + ((8 * ((size_t)M + 1) + 15) & ~(size_t)15);
+    if (sv) p.rec4 = (const uint4 *)recs;
+    else p.ps = (const uint2 *)recs;
+    hipLaunchKernelGGL(cl_keys, g256, b256, 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs);
     uint64_t *kin = nullptr, *kout = nullptr;
     uint32_t *vin = nullptr;
     if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, st, &kin, nullptr, &kout);
@@ -1390,12 +1416,6 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st);       // cbase[part] = its first candidate
     p.cbase = cbase;
-    if (sv) {
-        p.sv_mark_in = sv->mark_in; p.sv_depth = sv->depth; p.sv_depth_off = sv->depth_off; p.sv_depth_bin = sv->depth_bin;
-        p.sv_mark_out = sv->mark_out; p.sv_svread = sv->svread; p.sv_refread = sv->refread; p.sv_gt = sv->gt;
-    }
-    p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
-    p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
     hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpB);
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {

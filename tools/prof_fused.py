@@ -5,9 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from duet_amd import _lib, engine, synth
 from duet_amd.devmem import DeviceSvim
-wait = len(sys.argv) > 1 and sys.argv[1] == 'wait'
+wait = 'wait' in sys.argv[1:]
+big = 'big' in sys.argv[1:]          # 2e7 marks over 24 contigs instead of config 2's 1e6
 ctx = _lib.Context(0)
-contigs = [synth.bench_contig('1', 200000, 100000, 1)]
+contigs = synth.bench_genome(20000000, 3) if big else [synth.bench_contig('1', 200000, 100000, 1)]
 soa = engine.soa_from_synth(contigs)
 marks = synth.raw_marks(contigs, 1, reads_of=soa)
 depth, depth_off = synth.depth_bins(contigs, 1000, 1)
