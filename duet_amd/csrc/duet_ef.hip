@@ -53,7 +53,9 @@ constexpr uint8_t kClass2Slow = 16;               // multi-PS candidate without 
 constexpr uint8_t kDivZero = 32;                  // kept candidate with svread + refread == 0
 
 constexpr int kCandPerBlock = 256;
-constexpr int kChunk = 4096;                      // marks staged in LDS per pass (32 KiB of tags; 2048 was measured: -7 % at 2e7 marks, +38 % at 1e6)
+constexpr int kChunk = 3072;                      // marks staged in LDS per pass: 24 KiB of tags, six workgroups per CU.  A 256-candidate tile of
+                                                  // config 2 (2560 marks on average) still fits one pass; 4096 (four per CU): ef_classify 74 us instead
+                                                  // of 61 us at 2e7 marks; 2048 (two passes per tile): -7 % at 2e7 marks but +38 % at 1e6
 constexpr int kStageIt = kChunk / (kCandPerBlock * 4);   // 16-byte index loads per thread and pass
 constexpr int kSmallK = 64;
 constexpr int kSortThreads = 1024;
