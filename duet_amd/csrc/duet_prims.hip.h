@@ -48,10 +48,11 @@ struct StorePlain {
     __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { out[i] = v; }
 };
 template <int OP, class Load>
-__global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint32_t n, uint32_t *part)
+__global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint32_t n, uint32_t *part, uint32_t *zero14)
 {
     __shared__ uint32_t s_w[kScanThreads / 64];
     const uint32_t tid = threadIdx.x;
+    if (zero14 && blockIdx.x == 0 && tid < 14) zero14[tid] = 0;     // (scans without a spine launch: see scan_spine)
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     uint32_t acc = 0;
 #pragma unroll
@@ -103,11 +104,17 @@ __global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, u
     if (tid == 0 && total) *total = s_carry;
 }
 
-// out[i] = exclusive sum (OP 0) / inclusive max (OP 1) of in[0..i] given the per-tile carries in part[]
-template <int OP, class Load, class Store>
-__global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32_t n, const uint32_t *part, const Store out)
+// out[i] = exclusive sum (OP 0) / inclusive max (OP 1) of in[0..i] given the per-tile carries in part[].
+// SELF: there was no spine launch -- part[] still holds the tiles' own totals and every block combines the ones before
+// it by itself (up to kSelfSpine of them: a few loads per thread, cheaper than one more dependent launch); the last
+// block also delivers *total.
+constexpr uint32_t kSelfSpine = 2048;
+template <int OP, class Load, class Store, bool SELF>
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32_t n, const uint32_t *part, const Store out,
+                                                           uint32_t *total)
 {
     __shared__ uint32_t s_w[kScanThreads / 64];
+    __shared__ uint32_t s_c[kScanThreads / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     uint32_t v[kScanItems];
@@ -124,8 +131,28 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32
         if ((int)lane >= d) x = scan_op<OP>(x, y);
     }
     if (lane == 63) s_w[wave] = x;
+    uint32_t carry = 0;
+    if (SELF) {
+        for (uint32_t i = tid; i < blockIdx.x; i += kScanThreads) carry = scan_op<OP>(carry, part[i]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) carry = scan_op<OP>(carry, __shfl_xor(carry, d, 64));
+        if (lane == 0) s_c[wave] = carry;
+    }
     __syncthreads();
-    uint32_t run = part[blockIdx.x];
+    if (SELF) {
+        carry = 0;
+#pragma unroll
+        for (int w = 0; w < kScanThreads / 64; ++w) carry = scan_op<OP>(carry, s_c[w]);
+        if (total && tid == 0 && blockIdx.x == gridDim.x - 1) {
+            uint32_t t = carry;
+#pragma unroll
+            for (int w = 0; w < kScanThreads / 64; ++w) t = scan_op<OP>(t, s_w[w]);
+            *total = t;
+        }
+    } else {
+        carry = part[blockIdx.x];
+    }
+    uint32_t run = carry;
     for (uint32_t w = 0; w < wave; ++w) run = scan_op<OP>(run, s_w[w]);
     const uint32_t prev = __shfl_up(x, 1, 64);
     if (lane > 0) run = scan_op<OP>(run, prev);
@@ -255,9 +282,16 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
                  uint32_t *zero14 = nullptr)
 {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part);
+    if (nb >= 1 && nb <= kSelfSpine) {
+        hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, zero14);
+        hipLaunchKernelGGL((scan_apply<OP, Load, Store, true>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out,
+                           total);
+        return;
+    }
+    hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, (uint32_t *)nullptr);
     hipLaunchKernelGGL(scan_spine<OP>, dim3(1), dim3(1024), 0, st, part, nb, total, zero14);
-    hipLaunchKernelGGL((scan_apply<OP, Load, Store>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out);
+    hipLaunchKernelGGL((scan_apply<OP, Load, Store, false>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out,
+                       (uint32_t *)nullptr);
 }
 
 // stable LSD radix sort of n (key, value) pairs -- or, with null value buffers, of the keys alone -- on the low key_bits of
