@@ -1337,8 +1337,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     hipLaunchKernelGGL(cl_keys, g256, b256, 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs);
     uint64_t *kin = nullptr, *kout = nullptr;
     uint32_t *vin = nullptr;
-    if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, st, &kin, nullptr, &kout);
-    else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, st, &kin, &vin, &kout);
+    const bool big_sort = (ctx->dbg & DUET_DBG_CLUSTER_LARGE) != 0;     // (tests: the tile-offset path of > 4 M keys)
+    if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, nullptr, &kout, big_sort);
+    else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, &vin, &kout, big_sort);
     p.sorted = vin;
     p.skeys = kin;
     // partitions: natural starts by a max-scan straight off the sorted keys (stores the start flags), then a sum-scan

@@ -1105,9 +1105,11 @@ duet_ctx *duet_ctx_create(int device_id)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cl_join[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->plan_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->rx_dtot, 256 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->rx_dtot, 0, 256 * sizeof(uint32_t));
     if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
-        duet_g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-        delete ctx;
+        duet_g_last_error = std::string("context resources: ") + hipGetErrorString(e);
+        duet_ctx_destroy(ctx);                               // releases whatever was created
         return nullptr;
     }
     return ctx;
@@ -1130,6 +1132,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf &b : ctx->rows_ws) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->rows_in) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->rx_dtot) (void)hipFree(ctx->rx_dtot);
     for (int i = 0; i < 3; ++i) {
         if (ctx->cl_side[i]) (void)hipStreamDestroy(ctx->cl_side[i]);
         if (ctx->cl_join[i]) (void)hipEventDestroy(ctx->cl_join[i]);

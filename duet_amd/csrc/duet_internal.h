@@ -23,6 +23,7 @@ struct duet_ctx {
     uint32_t dbg = 0;
     unsigned long long *d_stamps = nullptr;
     hipStream_t own_stream = nullptr;
+    uint32_t *rx_dtot = nullptr;                              // [256] digit totals of a radix pass (zero between passes)
     // E/F plan (workspace keyed by the contig layout)
     std::vector<uint32_t> plan_off;        // cached cand_ctg_off
     uint32_t plan_C = 0;

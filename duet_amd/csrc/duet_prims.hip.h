@@ -12,7 +12,7 @@ constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
 __global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t dmask, uint32_t nb,
-                                                      uint32_t *hist /* [256][nb] */)
+                                                      uint32_t *hist /* [256][nb] */, uint32_t *dtot /* [256] digit totals, zero on entry */)
 {
     __shared__ uint32_t s_h[256];
     const uint32_t tid = threadIdx.x;
@@ -32,7 +32,51 @@ __global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint
         }
     }
     __syncthreads();
-    hist[(size_t)tid * nb + blockIdx.x] = s_h[tid];
+    const uint32_t c = s_h[tid];
+    hist[(size_t)tid * nb + blockIdx.x] = c;
+    if (dtot && c) atomicAdd(&dtot[tid], c);
+}
+
+// hist[d][b] <- keys with a smaller digit + keys with digit d in the tiles before b: one workgroup per digit scans its
+// row, the digits below it come from the totals rx_hist accumulated (one launch where a generic scan takes two or three)
+__global__ __launch_bounds__(256) void rx_offsets(uint32_t *hist, uint32_t nb, const uint32_t *dtot)
+{
+    __shared__ uint32_t s_w[4], s_b[4];
+    const uint32_t d = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t b = tid < d ? dtot[tid] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+    if (lane == 0) s_b[wave] = b;
+    __syncthreads();
+    uint32_t carry = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    uint32_t *row = hist + (size_t)d * nb;
+    for (uint32_t i0 = 0; i0 < nb; i0 += 256u * 8u) {
+        uint32_t v[8], acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = i0 + tid * 8u + j;
+            v[j] = i < nb ? row[i] : 0u;
+            acc += v[j];
+        }
+        uint32_t x = acc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if ((int)lane >= o) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t run = carry + x - acc;
+        for (uint32_t w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = i0 + tid * 8u + j;
+            if (i < nb) row[i] = run;
+            run += v[j];
+        }
+        carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
 }
 
 // generic block-tiled scan: op 0 = exclusive sum, op 1 = inclusive max
@@ -180,7 +224,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32
 template <bool VALS>
 __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in, const uint32_t *vals_in, uint32_t n,
                                                          uint32_t shift, uint32_t dmask, uint32_t nb, const uint32_t *hist,
-                                                         uint64_t *keys_out, uint32_t *vals_out)
+                                                         uint64_t *keys_out, uint32_t *vals_out, uint32_t *dtot)
 {
     constexpr int kWaves = kRxThreads / 64, kPerWave = kRxTile / kWaves;
     __shared__ uint64_t s_key[kRxTile];
@@ -268,6 +312,7 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
             if (VALS) vals_out[at] = s_val[q];
         }
     }
+    if (dtot && blockIdx.x == 0) dtot[tid] = 0;            // rx_offsets is done with the totals: zero again for the next pass
 }
 
 uint32_t bits_for(uint64_t max_value)
@@ -299,22 +344,27 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
 // *keys_out / *vals_out point to afterwards.  hist: 256 * ceil(n / kRxTile) words,
 // spart: ceil(256 * ceil(n / kRxTile) / kScanTile) + 1 words.
 inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, uint32_t n, uint32_t key_bits,
-                             uint32_t *hist, uint32_t *spart, hipStream_t st, uint64_t **keys_out, uint32_t **vals_out,
-                             uint64_t **keys_spare)
+                             uint32_t *hist, uint32_t *spart, uint32_t *dtot /* [256], zero between sorts */, hipStream_t st,
+                             uint64_t **keys_out, uint32_t **vals_out, uint64_t **keys_spare, bool force_scan = false)
 {
     const uint32_t nb_rx = (n + kRxTile - 1) / kRxTile, nh = 256 * nb_rx;
+    // up to 1024 tiles (4 M keys) the tile offsets take ONE launch: rx_hist also accumulates the digit totals (atomics, a
+    // few hundred per address) and rx_offsets scans one digit row per workgroup; beyond, the atomics would cost more
+    // than the launch they save (2e7 keys: +40 us per pass) and the generic scan does it
+    if (nb_rx > 1024 || force_scan) dtot = nullptr;
     uint64_t *kin = keysA, *kout = keysB;
     uint32_t *vin = valsA, *vout = valsB;
     for (uint32_t shift = 0; shift < key_bits; shift += 8) {
         const uint32_t dmask = key_bits - shift >= 8 ? 255u : (1u << (key_bits - shift)) - 1u;
-        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist);
-        launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st);     // in place: scan_apply reads a tile before writing it
+        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist, dtot);
+        if (dtot) hipLaunchKernelGGL(rx_offsets, dim3(256), dim3(256), 0, st, hist, nb_rx, (const uint32_t *)dtot);
+        else launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st);   // in place: scan_apply reads a tile before writing it
         if (valsA)
             hipLaunchKernelGGL(rx_scatter<true>, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, (const uint32_t *)vin, n,
-                               shift, dmask, nb_rx, (const uint32_t *)hist, kout, vout);
+                               shift, dmask, nb_rx, (const uint32_t *)hist, kout, vout, dtot);
         else
             hipLaunchKernelGGL(rx_scatter<false>, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, (const uint32_t *)nullptr,
-                               n, shift, dmask, nb_rx, (const uint32_t *)hist, kout, (uint32_t *)nullptr);
+                               n, shift, dmask, nb_rx, (const uint32_t *)hist, kout, (uint32_t *)nullptr, dtot);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
     }

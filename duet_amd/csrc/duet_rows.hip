@@ -253,7 +253,7 @@ int duet_rows_run_device(duet_ctx *ctx, const duet_rows_problem *pr, char *out_t
     hipLaunchKernelGGL(rows_keys, dim3((N + 255) / 256), dim3(256), 0, st, p, (const uint32_t *)idx, keysA, valsA);
     uint64_t *kin = nullptr;
     uint32_t *vin = nullptr;
-    radix_sort_pairs(keysA, keysB, valsA, valsB, N, key_bits, hist, spart, st, &kin, &vin, nullptr);
+    radix_sort_pairs(keysA, keysB, valsA, valsB, N, key_bits, hist, spart, ctx->rx_dtot, st, &kin, &vin, nullptr);
     p.sorted = vin;
     // row offsets (idx is free again) and the total
     uint32_t *row_off = idx;
