@@ -6,9 +6,10 @@
 // statement of the published SVIM 1.4.2 scheme, normative text in oracle/cluster_oracle.c / DESIGN.md section 9.
 //
 // Pipeline:
-//   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, val = mark index
-//   radix sort     stable LSD, 8-bit digits: rx_hist -> scan -> rx_scatter per pass (ballot-ranked, no atomics
-//                  on the data path, so the order is deterministic)
+//   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, the mark index in the spare
+//                  bits above them when it fits (else a separate value array)
+//   radix sort     stable LSD, 8-bit digits: rx_hist -> tile offsets -> rx_scatter per pass (ballot-ranked, no atomics
+//                  on the data path, so the order is deterministic); keys only when the index rides in the key
 //   partitions     two scans straight off the sorted keys: a max-scan finds each position's natural partition start
 //                  (contig/type change or centre gap > part_gap) and stores the start flags (natural start, then
 //                  every part_max marks); a sum-scan of the flags stores partition ids and the partition start list
@@ -18,9 +19,9 @@
 //                  goes, component by component, on work lists
 //   exact pass     binary64 average linkage for the listed components (nearest-neighbour cache per row)
 //   rank pass      finishes the partitions that had listed components
-//                  fast and rank passes write, per mark, its place in the partition's output and, per cluster head,
-//                  rank/end/means
-//   scan + cl_emit clusters per partition -> candidate bases; one thread per mark writes order[] and cand_*[]
+//                  fast and rank passes write each mark to its place in the partition's output (order[], and in the
+//                  fused pipeline its read index) and leave, per cluster head, rank/end/means
+//   scan + cl_emit clusters per partition -> candidate bases; the cluster heads write cand_*[]
 //
 // Bit-exactness vs the oracle: what is emitted depends only on the final clusters; the exact pass evaluates the same
 // binary64 expressions in the same order as the oracle (-ffp-contract=off; ties to the smallest (first, second)
