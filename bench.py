@@ -54,9 +54,19 @@ def pmc_traffic(soa):
     return None
 
 
-def cpu_baseline(soa, budget_s=10.0):
+def cpu_leg():
+    """The CPU leg of this script -- with python_baseline() below (the pure-Python restatement, timed only) the ONLY
+    place where bench.py touches oracle/.  The C restatement is timed as
+    `cpu_baseline` and supplies the expected results every parity flag compares the GPU output with; it is the checker
+    beside the measured path, never on it (the GPU path is libduet_ef.so through duet_amd/_lib.py and fails loudly
+    without it)."""
     from oracle import c_oracle
     c_oracle.load()
+    return c_oracle
+
+
+def cpu_baseline(soa, budget_s=10.0):
+    c_oracle = cpu_leg()
     t0 = time.perf_counter()
     c_oracle.ef(soa, 50, 2)
     one = time.perf_counter() - t0
@@ -197,7 +207,7 @@ def main():
 
     # correctness of what was timed (rank-local, against the C oracle) -- outside the timed region
     pred, ps = dp.results(last_slot)
-    from oracle import c_oracle
+    c_oracle = cpu_leg()
     rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
     parity = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
     if world > 1:
@@ -284,7 +294,7 @@ def concurrent_jobs(torch, _lib, DeviceProblem, soa, steps, n_streams=4):
         dps[k].run(ctxs[k], streams[k].cuda_stream)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    from oracle import c_oracle
+    c_oracle = cpu_leg()
     rc, wp, ws = c_oracle.ef(soa, 50, 2)
     ok = True
     for k in range(n_streams):
@@ -357,7 +367,7 @@ def cluster_point(ctx, torch, synth, contigs):
     (pos, span) per support read, shuffled; sort + partition + average linkage + emit, resident in HBM.
     Reported beside the E/F number, not inside `value`: the reference computes A0 in an external binary."""
     from duet_amd.devmem import DeviceCluster
-    from oracle import c_oracle
+    c_oracle = cpu_leg()
     marks = synth.raw_marks(contigs, 1)
     dc = DeviceCluster(marks)
     for _ in range(3):
@@ -383,7 +393,7 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20):
     """The metric read literally -- marks clustered AND phased: duet_svim_phase_device on raw shuffled marks
     (A0 sort + linkage + emit, adapter, E/F) resident in HBM, checked against the two C oracles composed."""
     from duet_amd.devmem import DeviceSvim
-    from oracle import c_oracle
+    c_oracle = cpu_leg()
     soa = engine.soa_from_synth(contigs)
     marks = synth.raw_marks(contigs, 1, reads_of=soa)
     depth, depth_off = synth.depth_bins(contigs, 1000, 1)
@@ -453,7 +463,7 @@ def extra_points(ctx, torch, engine, synth, DeviceProblem, large):
         dt = (time.perf_counter() - t0) / n
         prof = ctx.profile_collect()
         ctx.set_profiling(0)
-        from oracle import c_oracle
+        c_oracle = cpu_leg()
         pred, ps = dp.results()
         rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
         ok = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
