@@ -386,7 +386,7 @@ def cluster_point(ctx, torch, synth, contigs):
     return {'marks': M, 'candidates_found': dc.n_cands(), 'candidates_oracle': int(len(want['cand_off']) - 1),
             'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'algorithmic_bytes_18_per_mark': 18 * M,
             'GBs_vs_B_A0': 18 * M / dt / 1e9, 'cpu_oracle_ms_1core': cpu * 1e3,
-            'note': 'latency-bound at this size: ~45 small launches; the few 65..100-mark partitions are the critical path'}
+            'note': 'latency-bound at this size: ~30 small launches; the few 65..100-mark partitions are on the critical path'}
 
 
 def fused_point(ctx, torch, engine, synth, contigs, runs=20):
