@@ -1345,8 +1345,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.skeys = kin;
     // partitions: natural starts by a max-scan straight off the sorted keys (stores the start flags), then a sum-scan
     // of the flags that stores each position's partition id and the partition start list
-    launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)}, M, spart, StoreFlag{(uint8_t *)tmpA, p.part_max}, nullptr, st);
-    launch_scan<0>(LoadFlag{(const uint8_t *)tmpA}, M, spart, StoreParts{tmpB, part_start, M}, scal, st, scal + 2);   // scal[0] = #partitions
+    launch_scan<1>(LoadHead{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)}, M, spart, StoreFlag{(uint8_t *)tmpA, p.part_max}, nullptr, st, nullptr, big_sort);
+    launch_scan<0>(LoadFlag{(const uint8_t *)tmpA}, M, spart, StoreParts{tmpB, part_start, M}, scal, st, scal + 2, big_sort);   // scal[0] = #partitions
     p.part_start = part_start; p.n_parts = scal; p.pc = pc;
     p.e_info = e_info;
     p.e_pos = (uint32_t *)kout;                                   // the spare key buffer: 2 x M words
@@ -1416,7 +1416,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
                        (const uint32_t *)(small ? lists + 4 * (size_t)M : work.rank_list + 4 * (size_t)M),
                        (const uint32_t *)(small ? cnts + 4 : work.rank_count + 4));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
-    launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st);       // cbase[part] = its first candidate
+    launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort);       // cbase[part] = its first candidate
     p.cbase = cbase;
     hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpB);
     HIP_TRY(ctx, hipGetLastError());

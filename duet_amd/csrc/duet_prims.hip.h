@@ -324,10 +324,10 @@ uint32_t bits_for(uint64_t max_value)
 
 template <int OP, class Load, class Store>
 void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uint32_t *total, hipStream_t st,
-                 uint32_t *zero14 = nullptr)
+                 uint32_t *zero14 = nullptr, bool force_spine = false /* tests: the path of more than kSelfSpine tiles */)
 {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
-    if (nb >= 1 && nb <= kSelfSpine) {
+    if (nb >= 1 && nb <= kSelfSpine && !force_spine) {
         hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, zero14);
         hipLaunchKernelGGL((scan_apply<OP, Load, Store, true>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out,
                            total);
@@ -358,7 +358,7 @@ inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, 
         const uint32_t dmask = key_bits - shift >= 8 ? 255u : (1u << (key_bits - shift)) - 1u;
         hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist, dtot);
         if (dtot) hipLaunchKernelGGL(rx_offsets, dim3(256), dim3(256), 0, st, hist, nb_rx, (const uint32_t *)dtot);
-        else launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st);   // in place: scan_apply reads a tile before writing it
+        else launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st, nullptr, force_scan);   // in place: scan_apply reads a tile before writing it
         if (valsA)
             hipLaunchKernelGGL(rx_scatter<true>, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, (const uint32_t *)vin, n,
                                shift, dmask, nb_rx, (const uint32_t *)hist, kout, vout, dtot);

@@ -134,7 +134,8 @@ int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
  * partition through the exact binary64 agglomeration instead of the threshold-graph fast path (the outputs are
  * identical; tests use it to exercise both).  0 in production. */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
-#define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks) whatever the size */
+#define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
+                                           generic tile-offset scan in the sort, scans with a spine launch) whatever the size */
 #define DUET_DBG_CLUSTER_PAIRS 0x400u   /* A0: sort (key, mark index) pairs even when the index fits the key's spare bits */
 int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags);
 
