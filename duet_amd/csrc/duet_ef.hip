@@ -392,7 +392,15 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         svread = p.cand_svread[c0 + tid];
         refread = p.cand_refread[c0 + tid];
         gt_ok = p.cand_gt_ok[c0 + tid];
-        is_start = p.ctg_start[c0 + tid];
+        if (DYN) {
+            // device-planned runs have no start flags: the contig of this candidate, from the contig of the tile's first one
+            const uint32_t c = c0 + tid;
+            uint32_t k = p.blk_ctg[blockIdx.x];
+            while (c >= p.ctg_off[k + 1]) ++k;
+            is_start = c == p.ctg_off[k] ? 1u : 0u;
+        } else {
+            is_start = p.ctg_start[c0 + tid];
+        }
     }
     const bool kept = tid < nc && svlen >= p.svlen_thres && svread >= p.suppread_thres && gt_ok != 0;     // :189-190
     const bool divzero = kept && ((uint64_t)svread + (uint64_t)refread == 0);
@@ -951,10 +959,14 @@ __global__ void plan_mark_starts(const uint32_t *ctg_off, uint32_t K, uint8_t *c
     if (k < K && ctg_off[k] < ctg_off[k + 1]) ctg_start[ctg_off[k]] = 1;
 }
 
-// device-planned runs: contig of the first candidate of every 256-candidate block, by binary search
-__global__ void plan_blk_ctg(const uint32_t *ctg_off, uint32_t K, uint32_t B, uint32_t *blk_ctg)
+// device-planned runs, everything the plan needs in ONE launch: the workspace's copy of the contig offsets, the per-contig
+// seed counts and the status words zeroed, and the contig of the first candidate of every 256-candidate block (binary search)
+__global__ void plan_device(const uint32_t *ctg_off, uint32_t K, uint32_t B, uint32_t *ctg_off_copy, uint32_t *n_one_and_status,
+                            uint32_t *blk_ctg)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= K) ctg_off_copy[b] = ctg_off[b];
+    if (b < K + 8) n_one_and_status[b] = 0;
     if (b >= B) return;
     const uint32_t c = b * kCandPerBlock;
     uint32_t lo = 0, hi = K;                                   // the last k with ctg_off[k] <= c
@@ -1257,13 +1269,11 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     ctx->d_blk_ctg = w;            w += B;
     w += ((uintptr_t)w & 31) ? (32 - ((uintptr_t)w & 31)) / 4 : 0;
     ctx->d_blk_cnt = w;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctg_off, d_ctg_off, sizeof(uint32_t) * (K + 1), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_n_one, 0, sizeof(uint32_t) * ((size_t)K + 8), stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ws_start.ptr, 0, C, stream));
-    hipLaunchKernelGGL(plan_blk_ctg, dim3((B + 255) / 256), dim3(256), 0, stream, (const uint32_t *)ctx->d_ctg_off, K, B,
-                       ctx->d_blk_ctg);
-    hipLaunchKernelGGL(plan_mark_starts, dim3((K + 255) / 256), dim3(256), 0, stream, ctx->d_ctg_off, K,
-                       (uint8_t *)ctx->ws_start.ptr);
+    {
+        const uint32_t nthr = B > K + 8 ? B : K + 8;
+        hipLaunchKernelGGL(plan_device, dim3((nthr + 255) / 256), dim3(256), 0, stream, d_ctg_off, K, B, ctx->d_ctg_off, ctx->d_n_one,
+                           ctx->d_blk_ctg);
+    }
     ctx->plan_off.clear();                                     // the cached host-side plan no longer describes the workspace
     ctx->plan_C = 0;
     ctx->plan_stream = stream;
