@@ -11,30 +11,39 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
-__global__ __launch_bounds__(kRxThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t dmask, uint32_t nb,
-                                                      uint32_t *hist /* [256][nb] */, uint32_t *dtot /* [256] digit totals, zero on entry */)
+// 1024 threads per 4096-key tile (the tile of rx_scatter): four keys per thread, so that a small input -- one tile per CU at
+// 1 M keys -- still has 16 wavefronts per CU loading
+constexpr int kRxHistThreads = 1024;
+constexpr int kDtotCopies = 8;                        // the digit totals are kept in 8 copies (by tile index): 8x fewer atomics per address
+__global__ __launch_bounds__(kRxHistThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t dmask, uint32_t nb,
+                                                          uint32_t *hist /* [256][nb] */, uint32_t *dtot /* [256] digit totals, zero on entry */)
 {
     __shared__ uint32_t s_h[256];
     const uint32_t tid = threadIdx.x;
-    s_h[tid] = 0;
+    if (tid < 256) s_h[tid] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kRxTile;
     // two keys per 16-byte load (the tile base is a multiple of kRxTile keys, the buffers are hipMalloc-aligned)
+    static_assert(kRxTile == kRxHistThreads * 4, "two 16-byte loads per thread");
+    ulonglong2 k2[2];
+    uint32_t have[2];
 #pragma unroll
-    for (int it = 0; it < kRxItems / 2; ++it) {
-        const uint32_t i = base + (it * kRxThreads + tid) * 2u;
-        if (i + 1 < n) {
-            const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(keys + i);
-            atomicAdd(&s_h[(uint32_t)(k2.x >> shift) & dmask], 1u);
-            atomicAdd(&s_h[(uint32_t)(k2.y >> shift) & dmask], 1u);
-        } else if (i < n) {
-            atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & dmask], 1u);
-        }
+    for (int it = 0; it < 2; ++it) {
+        const uint32_t i = base + (it * kRxHistThreads + tid) * 2u;
+        have[it] = i + 1 < n ? 2u : (i < n ? 1u : 0u);
+        k2[it] = have[it] == 2u ? *reinterpret_cast<const ulonglong2 *>(keys + i) : make_ulonglong2(have[it] ? keys[i] : 0ull, 0ull);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (have[it] >= 1u) atomicAdd(&s_h[(uint32_t)(k2[it].x >> shift) & dmask], 1u);
+        if (have[it] == 2u) atomicAdd(&s_h[(uint32_t)(k2[it].y >> shift) & dmask], 1u);
     }
     __syncthreads();
-    const uint32_t c = s_h[tid];
-    hist[(size_t)tid * nb + blockIdx.x] = c;
-    if (dtot && c) atomicAdd(&dtot[tid], c);
+    if (tid < 256) {
+        const uint32_t c = s_h[tid];
+        hist[(size_t)tid * nb + blockIdx.x] = c;
+        if (dtot && c) atomicAdd(&dtot[(blockIdx.x % kDtotCopies) * 256u + tid], c);
+    }
 }
 
 // hist[d][b] <- keys with a smaller digit + keys with digit d in the tiles before b: one workgroup per digit scans its
@@ -43,7 +52,11 @@ __global__ __launch_bounds__(256) void rx_offsets(uint32_t *hist, uint32_t nb, c
 {
     __shared__ uint32_t s_w[4], s_b[4];
     const uint32_t d = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t b = tid < d ? dtot[tid] : 0u;
+    uint32_t b = 0;
+    if (tid < d) {
+#pragma unroll
+        for (int c = 0; c < kDtotCopies; ++c) b += dtot[c * 256 + tid];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
     if (lane == 0) s_b[wave] = b;
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(kRxThreads) void rx_scatter(const uint64_t *keys_in
             if (VALS) vals_out[at] = s_val[q];
         }
     }
-    if (dtot && blockIdx.x == 0) dtot[tid] = 0;            // rx_offsets is done with the totals: zero again for the next pass
+    if (dtot && blockIdx.x < kDtotCopies) dtot[blockIdx.x * 256u + tid] = 0;   // rx_offsets is done with the totals: zero again for the next pass
 }
 
 uint32_t bits_for(uint64_t max_value)
@@ -344,7 +357,7 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
 // *keys_out / *vals_out point to afterwards.  hist: 256 * ceil(n / kRxTile) words,
 // spart: ceil(256 * ceil(n / kRxTile) / kScanTile) + 1 words.
 inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, uint32_t n, uint32_t key_bits,
-                             uint32_t *hist, uint32_t *spart, uint32_t *dtot /* [256], zero between sorts */, hipStream_t st,
+                             uint32_t *hist, uint32_t *spart, uint32_t *dtot /* [kDtotCopies][256], zero between sorts */, hipStream_t st,
                              uint64_t **keys_out, uint32_t **vals_out, uint64_t **keys_spare, bool force_scan = false)
 {
     const uint32_t nb_rx = (n + kRxTile - 1) / kRxTile, nh = 256 * nb_rx;
@@ -356,7 +369,7 @@ inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, 
     uint32_t *vin = valsA, *vout = valsB;
     for (uint32_t shift = 0; shift < key_bits; shift += 8) {
         const uint32_t dmask = key_bits - shift >= 8 ? 255u : (1u << (key_bits - shift)) - 1u;
-        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist, dtot);
+        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxHistThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist, dtot);
         if (dtot) hipLaunchKernelGGL(rx_offsets, dim3(256), dim3(256), 0, st, hist, nb_rx, (const uint32_t *)dtot);
         else launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st, nullptr, force_scan);   // in place: scan_apply reads a tile before writing it
         if (valsA)
