@@ -96,11 +96,12 @@ def test_config2_soa_vs_oracle(ctx):
     assert 40000 < int((pred != 0).sum()) < 60000
 
 
-def test_config3_shape_soa_vs_oracle(ctx):
-    """24 contigs, 8e6 marks (config 3's shape at 40 % of its size; the full size runs in bench.py)."""
-    soa = engine.soa_from_synth(synth.bench_genome(8000000, 3))
-    assert soa.n_contigs == 24
-    check_against_c_oracle(ctx, soa)
+def test_config3_full_size_soa_vs_oracle(ctx):
+    """BASELINE configs[2] at full size on one GPU: 24 contigs, 2e7 marks, 2e6 candidates, every (pred, ps) against the C oracle."""
+    soa = engine.soa_from_synth(synth.bench_genome(20000000, 3))
+    assert soa.n_contigs == 24 and 19900000 < soa.n_marks < 20100000 and 1990000 < soa.n_cands < 2010000
+    pred, _ = check_against_c_oracle(ctx, soa)
+    assert 800000 < int((pred != 0).sum()) < 1200000
 
 
 @pytest.mark.parametrize('seed', range(12))
