@@ -32,14 +32,23 @@ def oracle_fused(marks, read_tag, depth, depth_off, depth_bin, svlen_thres, supp
 
 @pytest.mark.parametrize('kind,seed', [('chr21', 21), ('genome_small', 3), ('config2', 1)])
 def test_fused_pipeline_matches_oracle_composition(kind, seed):
-    contigs = H.case_contigs(kind, seed)
+    fused_case(H.case_contigs(kind, seed), seed, (True, False, True, False))
+
+
+def test_fused_pipeline_config3_size():
+    """2e7 raw marks over 24 contigs (BASELINE configs[2]'s size): the launch structure of large inputs, the generic
+    tile-offset scan of the sort, scans with a spine launch -- at their real size."""
+    fused_case(synth.bench_genome(20000000, 3), 3, (False, True))
+
+
+def fused_case(contigs, seed, waits):
     soa = engine.soa_from_synth(contigs)
     marks = synth.raw_marks(contigs, seed, reads_of=soa)
     depth, depth_off = synth.depth_bins(contigs, 1000, seed)
     want_cl, want_pred, want_ps = oracle_fused(marks, soa.read_tag, depth, depth_off, 1000, 50, 2, len(contigs))
     ctx = _lib.Context(0)
     ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
-    for wait in (True, False, True, False):              # with / without the host round trip; reruns reuse every workspace
+    for wait in waits:                                   # with / without the host round trip; reruns reuse every workspace
         ds.run_fused(ctx, wait=wait)
         got = ds.fetch()
         assert ds.n_found == len(want_cl['cand_pos'])
