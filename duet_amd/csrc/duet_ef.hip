@@ -80,7 +80,11 @@ __device__ __forceinline__ uint32_t tag_hap(uint64_t t) { return (uint32_t)(t >>
 // predict_hp, sv_phasing_fn.py:142-183, on the features of :112-139.  cls in {0,1,2}.
 __device__ int decide(int cls, const Vote &v, uint32_t deg, uint32_t svread, uint32_t refread)
 {
-    const double hapread_ratio = (double)v.allhap / (double)deg;                      // :112
+    // hapread_ratio = allhap / deg (:112) is only ever compared with 0.75, which binary64 represents exactly: for integers
+    // below 2^32 the rounded quotient is <= 0.75 exactly when 4 * allhap <= 3 * deg (a quotient above 0.75 exceeds it by at
+    // least 1 / (4 * deg) > 2^-34, far more than the spacing of doubles there) -- one binary64 division less per candidate.
+    // deg == 0 makes the quotient NaN, which fails both comparisons.
+    const bool hp_le = deg != 0 && 4ull * v.allhap <= 3ull * deg, hp_gt = deg != 0 && !hp_le;
     const double a1 = v.hap1 > 0 ? (double)v.t1 / (double)v.hap1 : 0.0;               // :113-114
     const double a2 = v.hap2 > 0 ? (double)v.t2 / (double)v.hap2 : 0.0;               // :115-116
     const double sv_ratio = (double)svread / (double)((uint64_t)svread + (uint64_t)refread);   // :123
@@ -98,7 +102,7 @@ __device__ int decide(int cls, const Vote &v, uint32_t deg, uint32_t svread, uin
             else { if (v.hap0 >= 6) pred = 3; }
         }
     } else {                                                                          // :156-182
-        const bool gate = (hapread_ratio <= 0.75 && diff <= 2400.0) || hapread_ratio > 0.75;
+        const bool gate = (hp_le && diff <= 2400.0) || hp_gt;
         if (onehap != 0) {
             if (sv_ratio <= 0.24) pred = 0;
             else if (sv_ratio <= 0.9) { if (gate) pred = a1 > 0 ? 1 : 2; }
