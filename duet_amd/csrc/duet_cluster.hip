@@ -1515,10 +1515,8 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     sv.mark_out = (uint32_t *)ctx->sv_ws[4].ptr; sv.svread = (uint32_t *)ctx->sv_ws[1].ptr;
     sv.refread = (uint32_t *)ctx->sv_ws[2].ptr; sv.gt = (uint8_t *)ctx->sv_ws[3].ptr;
     if ((rc = cluster_run(ctx, &pr->marks, res, st, &sv))) return rc;
-    hipLaunchKernelGGL(sv_contig_offsets, dim3((K + 1 + 255) / 256), dim3(256), 0, st, (const uint16_t *)res->cand_contig,
-                       (const uint32_t *)res->n_cands, K, d_ctg_off);
     if (!n_cands_host) {
-        // fully asynchronous: E/F is planned on the device from the contig offsets just computed; buffers and grids are
+        // fully asynchronous: E/F is planned on the device from the candidates' contig column; buffers and grids are
         // sized for the upper bound (a candidate has at least one mark) and the kernels read the real count
         duet_ef_problem ef;
         memset(&ef, 0, sizeof(ef));
@@ -1527,9 +1525,11 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
         ef.cand_pos = res->cand_pos; ef.cand_svlen = res->cand_span; ef.cand_svread = sv.svread; ef.cand_refread = sv.refread;
         ef.cand_gt_ok = sv.gt; ef.cand_off = res->cand_off; ef.mark_read = sv.mark_out;
         ef.svlen_thres = pr->svlen_thres; ef.suppread_thres = pr->suppread_thres;
-        return duet_ef_run_planned_on_device(ctx, &ef, M, (const uint32_t *)res->n_cands, (const uint32_t *)d_ctg_off, out_pred,
-                                             out_ps, st);
+        return duet_ef_run_planned_on_device(ctx, &ef, M, (const uint32_t *)res->n_cands, nullptr, (const uint16_t *)res->cand_contig,
+                                             out_pred, out_ps, st);
     }
+    hipLaunchKernelGGL(sv_contig_offsets, dim3((K + 1 + 255) / 256), dim3(256), 0, st, (const uint16_t *)res->cand_contig,
+                       (const uint32_t *)res->n_cands, K, d_ctg_off);
     std::vector<uint32_t> ctg_off(K + 1);
     HIP_TRY(ctx, hipMemcpyAsync(ctg_off.data(), d_ctg_off, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));             // the one host round trip: candidates per contig

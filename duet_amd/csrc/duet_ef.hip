@@ -981,6 +981,28 @@ __global__ void plan_device(const uint32_t *ctg_off, uint32_t K, uint32_t B, uin
     blk_ctg[b] = lo;
 }
 
+// the same from the candidates' contig column (sorted by contig): the contig offsets by binary search, the tiles' contigs
+// straight from the column
+__global__ void plan_device_contigs(const uint16_t *cand_contig, const uint32_t *n_cands, uint32_t K, uint32_t B,
+                                    uint32_t *ctg_off_copy, uint32_t *n_one_and_status, uint32_t *blk_ctg)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t N = *n_cands;
+    if (t <= K) {
+        uint32_t lo = 0, hi = N;                               // first candidate whose contig is >= t
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (cand_contig[mid] < t) lo = mid + 1; else hi = mid;
+        }
+        ctg_off_copy[t] = t == K ? N : lo;
+    }
+    if (t < K + 8) n_one_and_status[t] = 0;
+    if (t < B) {
+        const uint32_t c = t * kCandPerBlock;
+        blk_ctg[t] = c < N ? (uint32_t)cand_contig[c] : 0u;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1249,7 +1271,8 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
 // device (d_n_cands, d_ctg_off[K+1]); every buffer and grid is sized for c_max candidates and the kernels read the real
 // count.  Nothing here waits for the device.
 int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
-                                  const uint32_t *d_ctg_off, uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream)
+                                  const uint32_t *d_ctg_off, const uint16_t *d_cand_contig, uint8_t *out_pred, uint32_t *out_ps,
+                                  hipStream_t stream)
 {
     const uint32_t K = pr->n_contigs, C = c_max;
     if (K == 0 || C == 0) return DUET_OK;
@@ -1275,8 +1298,12 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     ctx->d_blk_cnt = w;
     {
         const uint32_t nthr = B > K + 8 ? B : K + 8;
-        hipLaunchKernelGGL(plan_device, dim3((nthr + 255) / 256), dim3(256), 0, stream, d_ctg_off, K, B, ctx->d_ctg_off, ctx->d_n_one,
-                           ctx->d_blk_ctg);
+        if (d_cand_contig)      // no contig offsets yet: they come out of the same launch
+            hipLaunchKernelGGL(plan_device_contigs, dim3((nthr + 255) / 256), dim3(256), 0, stream, d_cand_contig, d_n_cands, K, B,
+                               ctx->d_ctg_off, ctx->d_n_one, ctx->d_blk_ctg);
+        else
+            hipLaunchKernelGGL(plan_device, dim3((nthr + 255) / 256), dim3(256), 0, stream, d_ctg_off, K, B, ctx->d_ctg_off,
+                               ctx->d_n_one, ctx->d_blk_ctg);
     }
     ctx->plan_off.clear();                                     // the cached host-side plan no longer describes the workspace
     ctx->plan_C = 0;

@@ -69,7 +69,8 @@ inline int duet_fail(duet_ctx *ctx, int code, const std::string &msg)
 
 // device-planned E/F run (duet_ef.hip), for the fused pipeline in duet_cluster.hip
 int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
-                                  const uint32_t *d_ctg_off, uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream);
+                                  const uint32_t *d_ctg_off /* or null ... */, const uint16_t *d_cand_contig /* ... then the candidates' contig column */,
+                                  uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream);
 
 // host arrays of an E/F problem -> the context's staging buffers (duet_ef.hip)
 int duet_ef_upload(duet_ctx *ctx, const duet_ef_problem *pr, duet_ef_problem *d, hipStream_t s);
