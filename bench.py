@@ -2,20 +2,27 @@
 # coding=utf-8
 """bench.py -- throughput of Duet's step E/F hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # started plainly: spawns one process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (ef_classify -> ef_seed_sort -> ef_finalize, plus the single
-all-gather of the per-candidate records when N > 1) over one batch of synthetic input that is already
-resident in HBM.  Workload: BASELINE.json configs[1] -- one contig, ~1.0M SV support-read marks,
-200k reads, 100k candidates (duet_amd.synth.bench_contig, seed 1).  With N > 1 every rank owns one
-such contig (contig sharding, weak scaling) and the results are reassembled with one
-all_gather_into_tensor over RCCL.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM.
 
-`roofline` prices the dominant kernel (ef_classify): algorithmic bytes per launch
-(12 B/mark + 18 B/candidate in + 5 B/candidate out + 8 B/read) / mean duration from HIP
-events recorded on the launch stream during the timed region / 8 TB/s.
-`cpu_baseline` times oracle/ef_oracle.c (scalar C port, 1 core) on the same arrays, rank 0, N=1.
+N = 1   BASELINE.json configs[1]: one contig, ~1.0 M SV support-read marks, 200 k reads, 100 k candidates
+        (duet_amd.synth.bench_contig, seed 1); step = ef_classify -> ef_seed_sort -> ef_finalize.  `value` is the phasing
+        (E/F) rate; `value_clustered_and_phased` is the metric read literally: the same marks, raw and shuffled, clustered
+        (stage A0) AND phased in one device pipeline, with its own roofline block.  `roofline` prices the dominant kernel
+        of the step (ef_classify) at config 2, where it is launch-latency bound; `roofline_bandwidth_bound` is the same
+        kernel on 2e8 marks (3.2 GB), the only size that is unambiguously HBM traffic.
+N > 1   BASELINE.json configs[2]: the synthetic whole genome (24 contigs, 2e7 marks) as ONE problem, contigs assigned to
+        ranks longest-processing-time-first, each rank runs the three kernels on its shard, exactly ONE
+        all_gather_into_tensor (RCCL over xGMI) per problem reassembles the records; "scaling": "strong".  Rank 0 also
+        times the same problem on its GPU alone (`same_problem_on_1_gpu`), so the line carries its own 1-GPU reference.
+Rank 0 prints ONE JSON line.
+
+Algorithmic bytes: ef_classify 12 B/mark + 22 B/candidate + 8 B/read per launch; the whole
+E/F step B_EF = 12 M + 27 C + 8 R; stage A0 18 B/mark.  Kernel durations come from HIP events on the kernel's own
+dispatch (duet_ctx_set_profiling), recorded inside the timed region.
+`cpu_baseline` times oracle/ef_oracle.c (scalar C port, 1 core) on the same arrays, rank 0, N = 1.
 """
 
 import argparse
@@ -40,17 +47,19 @@ def classify_bytes(soa):
 
 
 def pmc_traffic(soa):
-    """HBM bytes per ef_classify launch from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE exact), or None
-    when no committed counter run matches the workload."""
-    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if '%d marks' % soa.n_marks in d.get('workload', ''):
-            return d['traffic_bytes_per_launch']
-    except (OSError, ValueError, KeyError):
-        pass
+    """HBM bytes per ef_classify launch from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json, the
+    newest round that has this workload: FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE exact), or None when
+    no committed counter run matches the workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*pmc_traffic*.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for e in (d if isinstance(d, list) else [d]):
+                if '%d marks' % soa.n_marks in e.get('workload', ''):
+                    return e['traffic_bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            pass
     return None
 
 
@@ -103,28 +112,92 @@ def python_baseline(contigs, n_cands=4000):
             'sample': 'oracle/ef_oracle.py (pure Python, text VCF+SAM -> phased_sv.vcf text) on %d marks' % marks}
 
 
-GATHER_GROUP = 8          # jobs per all-gather at N > 1 (two groups rotate, so a group's collective overlaps the next group's kernels)
+GATHER_GROUP = 8          # extra.weak_grouped only: jobs per all-gather (two groups rotate)
 
 
-def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
-    """W warm-up + K timed steps.  With world > 1 every job's per-candidate records are all-gathered; the results of
-    GATHER_GROUP consecutive jobs sit side by side in one buffer and go out in ONE asynchronous collective (its own
-    RCCL stream) that overlaps the kernels of the following jobs -- a 0.5 MB-per-rank all-gather per 24 us job would be
-    bound by the collective's latency, not by the work.  Every job is gathered completely before the clock stops."""
+def host_info():
+    """CPU model and core count of the box the CPU legs run on (north_star: 'core count stated')."""
+    model = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {'host_cpu_model': model, 'host_cores': os.cpu_count(), 'host_cores_usable': usable}
+
+
+def cpu_baseline_ncore(soa, one_core_marks_per_s, budget_s=6.0, max_threads=64):
+    """The same scalar C restatement on T host threads at once (each thread passes over the same read-only arrays
+    into its own outputs; ctypes releases the GIL) -- the N-core figure SURVEY 8d asks for beside the 1-core one."""
+    import threading
+    c_oracle = cpu_leg()
+    info = host_info()
+    T = max(1, min(int(info['host_cores_usable'] or 1), max_threads))
+    reps = max(1, int(budget_s * one_core_marks_per_s / max(soa.n_marks, 1)))
+
+    def work():
+        for _ in range(reps):
+            c_oracle.ef(soa, 50, 2)
+
+    ths = [threading.Thread(target=work) for _ in range(T)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {'value': soa.n_marks * reps * T / dt, 'unit': 'marks/s', 'cores': T, 'kind': 'port',
+            'sample': '%d threads x %d passes of oracle/ef_oracle.c over the same arrays (throughput of independent '
+                      'passes; the restatement itself is scalar)' % (T, reps)}
+
+
+def cpu_calibration():
+    """profiles/cpu_calibration.json: upstream's Python step E/F against the C restatement, both timed in the
+    development container on the config-2 inputs (tools/calibrate_cpu.py)."""
+    try:
+        with open(os.path.join(REPO, 'profiles', 'cpu_calibration.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def step_kernels_profiled(ctx, dp, stream, torch, n=50):
+    """After a timed region: every kernel bracketed by its own dispatch events (serialises the stream, so it is kept out
+    of `value`); these are the durations rocprofv3 --kernel-trace reports."""
+    ctx.set_profiling(2)
+    spare = len(dp.out_blocks) - 1
+    for _ in range(n):
+        dp.run(ctx, stream, spare)
+    torch.cuda.synchronize()
+    iso = ctx.profile_collect()
+    ctx.set_profiling(0)
+    ctx.check(stream)
+    return iso
+
+
+def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, group):
+    """W warm-up + K timed steps of (ef_classify -> ef_seed_sort -> ef_finalize [-> all-gather]).  With world > 1 the
+    record blocks of `group` consecutive jobs go out in ONE asynchronous all_gather_into_tensor on RCCL's stream, which
+    overlaps the kernels of the following job(s); group = 1 is one collective per problem (the sharded configs[2] run).
+    Every job is gathered completely before the clock stops."""
     from duet_amd.dist import GroupedGather
     stream = torch.cuda.current_stream().cuda_stream
-    n_slots = len(dp.out_blocks)
-    gg = GroupedGather(dp.out_storage, dp.out_blocks[0].numel(), world, GATHER_GROUP, dist_mod)
+    gg = GroupedGather(dp.out_storage, dp.out_blocks[0].numel(), world, group, dist_mod)
 
     def one():
         dp.run(ctx, stream, gg.next_slot())
         gg.job_enqueued()
 
-    drain = gg.drain
-
     for _ in range(warmup):
         one()
-    drain()
+    gg.drain()
     ctx.check(stream)
     ctx.set_profiling(3)                 # HIP start/stop events on ef_classify's own dispatch, every 8th step
     ctx.profile_collect()
@@ -134,25 +207,271 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod):
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
-    drain()
+    gg.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist_mod.barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_collect()
-    # after the timed region: every kernel bracketed by its own dispatch events (serialises the stream, so it
-    # is kept out of `value`); these are the durations rocprofv3 --kernel-trace reports
-    ctx.set_profiling(2)
-    keep_slot = gg.slot
-    spare = (keep_slot + 1) % n_slots if n_slots > 1 else 0
-    for _ in range(min(steps, 50)):
-        dp.run(ctx, stream, spare)
-    torch.cuda.synchronize()
-    iso = ctx.profile_collect()
     ctx.set_profiling(0)
     ctx.check(stream)
-    last = gg.last_job_blocks()
-    return dt, prof, iso, last, keep_slot
+    return dt, prof, gg
+
+
+def reduce_max_sum(torch, dist_mod, values):
+    t = torch.tensor(values, dtype=torch.float64, device='cuda')
+    tmax, tsum = t.clone(), t.clone()
+    dist_mod.all_reduce(tmax, op=dist_mod.ReduceOp.MAX)
+    dist_mod.all_reduce(tsum, op=dist_mod.ReduceOp.SUM)
+    return [float(x) for x in tmax], [float(x) for x in tsum]
+
+
+def topology(torch, dist_mod, rank, world, local_rank, one_gpu):
+    """What proves N ranks on N devices: per rank its device index, name, PCI bus id and the XCD/CU count; the
+    collective backend and RCCL's version."""
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = {'rank': rank, 'device': local_rank, 'name': props.name, 'cus': props.multi_processor_count,
+            'hbm_GiB': round(props.total_memory / 2 ** 30, 1),
+            'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pid': os.getpid()}
+    allr = [None] * world
+    dist_mod.all_gather_object(allr, mine)
+    ver = None
+    try:
+        ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return {'backend': dist_mod.get_backend(), 'world_size': dist_mod.get_world_size(), 'rccl_version': ver,
+            'one_gpu_plumbing_mode': one_gpu, 'ranks': allr,
+            'distinct_devices': len(set((r['device'], r['pci_bus_id']) for r in allr))}
+
+
+def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
+    """N > 1: BASELINE configs[2] -- the synthetic whole genome (24 contigs, 2e7 marks) as ONE problem, contigs assigned
+    to ranks longest-processing-time-first on mark counts (duet_amd/dist.py), each rank runs the three kernels on its
+    shard, exactly ONE all_gather_into_tensor per problem reassembles the (pred, ps) records on every rank.  Strong
+    scaling: the problem is the same at every N."""
+    from duet_amd import dist, engine, synth
+    from duet_amd.devmem import DeviceProblem
+    contigs = synth.bench_genome(args.genome_marks, 3)
+    soa = engine.soa_from_synth(contigs)
+    del contigs
+    weights = dist.contig_mark_counts(soa)
+    owned = dist.lpt_assign(weights, world)
+    sizes = dist.shard_sizes(soa, owned)
+    n_max = max(max(sizes), 1)
+    sub = dist.shard_soa(soa, owned[rank])
+    dev = 'cuda:%d' % local_rank
+    dp = DeviceProblem(sub, 50, 2, device=dev, n_cands_max=n_max, n_out=4)
+    stream_obj = torch.cuda.Stream()
+    with torch.cuda.stream(stream_obj):
+        stream = torch.cuda.current_stream().cuda_stream
+        dt, prof, gg = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod, 1)
+        gathered = gg.last_job_blocks()
+        # --- outside the timed region: the pieces on their own ---------------------------------------------------
+        iso = step_kernels_profiled(ctx, dp, stream, torch, n=min(args.steps, 50))
+        n = max(10, min(args.steps, 50))
+        dist_mod.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            dp.run(ctx, stream, 3)
+        torch.cuda.synchronize()
+        t_kern = (time.perf_counter() - t0) / n
+        src = dp.out_blocks[3]
+        dst = torch.empty(world * src.numel(), dtype=torch.uint8, device=src.device)
+        for _ in range(3):
+            dist_mod.all_gather_into_tensor(dst, src)
+        torch.cuda.synchronize()
+        dist_mod.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            dist_mod.all_gather_into_tensor(dst, src)
+        torch.cuda.synchronize()
+        t_gather = (time.perf_counter() - t0) / n
+    kms = float(prof.kernel_ms[0])
+    ab = classify_bytes(sub)
+    mine = {'rank': rank, 'contigs': [int(k) for k in owned[rank]], 'marks': sub.n_marks, 'candidates': sub.n_cands,
+            'reads': sub.n_reads, 'ef_classify_ms': kms, 'ef_classify_launches_timed': int(prof.n_profiled_runs),
+            'ef_classify_algorithmic_bytes': ab,
+            'ef_classify_GBs': ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+            'ef_classify_frac_of_8TBs': ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else 0.0,
+            'kernels_us_isolated': {k: round(float(iso.kernel_ms[i]) * 1e3, 2) for i, k in enumerate(('ef_classify', 'ef_seed_sort', 'ef_finalize'))},
+            'kernels_only_ms_per_step': t_kern * 1e3, 'gather_only_us': t_gather * 1e6}
+    per_rank = [None] * world
+    dist_mod.all_gather_object(per_rank, mine)
+    (dt,), _ = reduce_max_sum(torch, dist_mod, [dt])
+    topo = topology(torch, dist_mod, rank, world, local_rank, one_gpu)
+
+    out = None
+    same = None
+    if rank == 0:
+        # the merged call set of the LAST timed problem against the C oracle on the unsharded problem
+        c_oracle = cpu_leg()
+        g = gathered.cpu().numpy()
+        got = dist.merge_results(soa, owned, [dist.unpack_block(g[r], n_max, sizes[r]) for r in range(world)])
+        rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
+        parity = bool(rc == 0 and np.array_equal(got[0], want_pred) and np.array_equal(got[1], want_ps))
+        # the SAME problem on this rank's GPU alone (the other ranks wait at the barrier below): the 1-GPU point of the
+        # strong-scaling curve, measured in the same run
+        del dp
+        torch.cuda.empty_cache()
+        dpf = DeviceProblem(soa, 50, 2, device=dev)
+        with torch.cuda.stream(stream_obj):
+            for _ in range(3):
+                dpf.run(ctx, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dpf.run(ctx, stream)
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t0) / 20
+            ctx.check(stream)
+        p1, s1 = dpf.results()
+        same = {'ms_per_step': t1 * 1e3, 'marks_per_s': soa.n_marks / t1,
+                'parity_vs_oracle': bool(np.array_equal(p1, want_pred) and np.array_equal(s1, want_ps)),
+                'note': 'no collective: one GPU holds the whole call set'}
+        del dpf
+        torch.cuda.empty_cache()
+        slow = max(per_rank, key=lambda r: r['ef_classify_ms'])
+        loads = [r['marks'] for r in per_rank]
+        out = {
+            'metric': METRIC, 'value': soa.n_marks * args.steps / dt, 'unit': 'marks/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+            'plumbing_test_one_gpu': one_gpu,
+            'config': {'workload': 'BASELINE configs[2]: synthetic whole genome chr1-22,X,Y, %d SV marks / %d candidates / %d '
+                                   'tagged reads in %d contigs, resident in HBM, contigs LPT-sharded over %d GPUs; step = '
+                                   'classify+seed_sort+finalize per rank + ONE all_gather_into_tensor of the 5 B/candidate '
+                                   'records per problem (asynchronous, overlapping the next problem\'s kernels)'
+                                   % (soa.n_marks, soa.n_cands, soa.n_reads, soa.n_contigs, world),
+                       'marks': soa.n_marks, 'candidates': soa.n_cands, 'reads': soa.n_reads, 'contigs': soa.n_contigs,
+                       'parallelism': 'contig-sharded x%d (LPT on mark counts)' % world, 'svlen_thres': 50,
+                       'suppread_thres': 2},
+            'parity_vs_oracle': parity,
+            'roofline': {'kernel': 'ef_classify', 'bound': 'hbm', 'achieved': slow['ef_classify_GBs'], 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': slow['ef_classify_frac_of_8TBs'], 'traffic': None,
+                         'algorithmic_bytes_per_launch': slow['ef_classify_algorithmic_bytes'],
+                         'launch_ms': slow['ef_classify_ms'], 'launches_timed': slow['ef_classify_launches_timed'],
+                         'note': 'the rank whose ef_classify launch is longest (rank %d); every rank is in per_rank' % slow['rank']},
+            'sharding': {'lpt_imbalance_max_over_mean_marks': max(loads) / (sum(loads) / float(world)),
+                         'candidates_per_rank': sizes, 'record_bytes_per_rank': dist.record_bytes(n_max)},
+            'gather': {'collectives_per_problem': 1, 'bytes_contributed_per_rank': dist.record_bytes(n_max),
+                       'us_isolated_max_over_ranks': max(r['gather_only_us'] for r in per_rank),
+                       'kernels_only_ms_per_step_max_over_ranks': max(r['kernels_only_ms_per_step'] for r in per_rank)},
+            'per_rank': per_rank,
+            'topology': topo,
+            'same_problem_on_1_gpu': same,
+        }
+    dist_mod.barrier()
+    return out
+
+
+def weak_grouped_run(args, ctx, torch, dist_mod, rank, world, local_rank):
+    """extra (N > 1): round 1's weak-scaling variant -- one config-2 contig per rank, the record blocks of GATHER_GROUP
+    consecutive jobs in one asynchronous collective."""
+    from duet_amd import dist, engine, synth
+    from duet_amd.devmem import DeviceProblem
+    label = synth.DEFAULT_CONTIGS[rank % len(synth.DEFAULT_CONTIGS)]
+    contig = synth.bench_contig('1', 200000, 100000, 1 + rank, spelled='chr' + label)
+    soa = engine.soa_from_synth([contig])
+    n_max = soa.n_cands
+    dp = DeviceProblem(soa, 50, 2, device='cuda:%d' % local_rank, n_cands_max=n_max, n_out=2 * GATHER_GROUP)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        dt, prof, gg = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod, GATHER_GROUP)
+        gathered = gg.last_job_blocks()
+    c_oracle = cpu_leg()
+    rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
+    gp, gs = dist.unpack_block(gathered[rank].cpu().numpy(), n_max, soa.n_cands)
+    ok = float(rc == 0 and np.array_equal(gp, want_pred) and np.array_equal(gs, want_ps))
+    (dt, _, _), (_, marks, oks) = reduce_max_sum(torch, dist_mod, [dt, float(soa.n_marks), ok])
+    return {'scaling': 'weak', 'workload': 'one BASELINE configs[1] contig per rank, %d jobs per all-gather' % GATHER_GROUP,
+            'marks_per_s': marks * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3, 'parity_vs_oracle': bool(oks == world)}
+
+
+METRIC = 'SV support-read marks clustered+phased /sec; bit-exact phased_sv.vcf vs ref'
+DTYPE = 'u32/u64 integer + f64 threshold compares'
+
+
+def single_gpu_run(args, ctx, torch):
+    """N = 1: BASELINE configs[1] -- one contig, ~1.0 M marks / 100 k candidates / 200 k reads (160 k tagged)."""
+    from duet_amd import _lib, engine, synth
+    from duet_amd.devmem import DeviceProblem
+    contig = synth.bench_contig('1', 200000, 100000, 1, spelled='chr1')
+    soa = engine.soa_from_synth([contig])
+    dp = DeviceProblem(soa, 50, 2, n_out=3)
+    with torch.cuda.stream(torch.cuda.Stream()):             # a stream of its own, not the legacy default stream
+        stream = torch.cuda.current_stream().cuda_stream
+        dt, prof, gg = timed_steps(ctx, dp, args.steps, args.warmup, 1, torch, None, 1)
+        last_slot = gg.slot
+        iso = step_kernels_profiled(ctx, dp, stream, torch, n=min(args.steps, 50))
+    pred, ps = dp.results(last_slot)
+    c_oracle = cpu_leg()
+    rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
+    parity = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
+
+    kname = _lib.KERNEL_NAMES[0]
+    k_ms = float(prof.kernel_ms[0])
+    abytes = classify_bytes(soa)
+    achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    out = {
+        'metric': METRIC, 'value': soa.n_marks * args.steps / dt, 'unit': 'marks/s', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: synthetic 1 contig, %d SV marks / %d candidates / %d tagged reads, '
+                               'resident in HBM; step = classify+seed_sort+finalize (phasing, E/F); the clustered+phased '
+                               'figure for the same marks is value_clustered_and_phased'
+                               % (soa.n_marks, soa.n_cands, soa.n_reads),
+                   'marks_per_gpu': soa.n_marks, 'candidates_per_gpu': soa.n_cands, 'reads_per_gpu': soa.n_reads,
+                   'parallelism': 'contig-sharded x1', 'svlen_thres': 50, 'suppread_thres': 2,
+                   'generator_vs_SURVEY_8d': 'marks with no SAM line: 5 % (8d: 20 % of names absent); pc ~ geometric(1/2)*400 + '
+                                             'U[0,400), mean ~600, capped at 8100 + 3 % U[8101,20000] (8d: exp mean 600); '
+                                             'the reference sha256 in tests/golden/seeded.json pins exactly these inputs'},
+        'parity_vs_oracle': parity,
+        'kernels_us_isolated': {n: round(float(iso.kernel_ms[i]) * 1e3, 2) for i, n in enumerate(_lib.KERNEL_NAMES)},
+        'roofline': {'kernel': kname, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(soa),
+                     'algorithmic_bytes_per_launch': abytes, 'launch_ms': k_ms,
+                     'launches_timed': int(prof.n_profiled_runs),
+                     'note': 'config 2 is 15.5 MB per launch (~1.9 us at peak): launch-latency bound; '
+                             'roofline_bandwidth_bound below is the same kernel at 2e8 marks'},
+    }
+    if not args.no_extra:
+        # the metric read literally: raw marks clustered (A0) AND phased (E/F) in one device pipeline
+        fused = fused_point(ctx, torch, engine, synth, [contig])
+        out['value_clustered_and_phased'] = fused['marks_per_s']
+        out['ms_per_step_clustered_and_phased'] = fused['ms_per_run']
+        out['roofline_clustered_and_phased'] = fused['roofline']
+        out['parity_clustered_and_phased_vs_composed_oracles'] = fused['parity_vs_composed_oracles']
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(soa)
+        cb.update(host_info())
+        cal = cpu_calibration()
+        if cal:
+            cb['calibration'] = {'reference_python_over_port': cal['ratio_reference_over_port'],
+                                 'measured': cal['where'], 'reference_python_ef_marks_per_s_here_estimate':
+                                 cb['value'] / cal['ratio_reference_over_port'],
+                                 'note': 'BASELINE.md section 4: upstream\'s Python cannot travel to the GPU box; estimate = '
+                                         'port on this host / (reference time / port time, both measured in the dev container, '
+                                         'same inputs, same region: filter..decision, sv_phasing_fn.py:189-228)'}
+        out['cpu_baseline'] = cb
+        out['cpu_baseline_ncore'] = cpu_baseline_ncore(soa, cb['value'])
+        out['cpu_baseline_python'] = python_baseline([contig])
+    if not args.no_extra:
+        ex = extra_points(ctx, torch, engine, synth, DeviceProblem, not args.no_large)
+        out['extra'] = ex
+        big = ex.get('1gpu_2e8_marks') or ex.get('config3_1gpu_2e7_marks')
+        out['roofline_bandwidth_bound'] = big['roofline']
+        out['same_problem_as_multi_gpu_runs'] = {'workload': 'BASELINE configs[2] on one GPU (what --gpus N shards)',
+                                                 'marks_per_s': ex['config3_1gpu_2e7_marks']['marks_per_s'],
+                                                 'ms_per_step': ex['config3_1gpu_2e7_marks']['ms_per_step']}
+        ex['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
+        ex['fused_clustered_and_phased_config2'] = fused
+        ex['fused_clustered_and_phased_2e7_marks'] = fused_point(ctx, torch, engine, synth,
+                                                                  synth.bench_genome(20000000, 3), runs=5)
+        ex['three_timed_regions_config2'] = abi_and_e2e(ctx, soa, contig, float(iso.total_ms))
+        ex['concurrent_jobs_config2'] = concurrent_jobs(torch, _lib, DeviceProblem, soa, args.steps)
+    return out
 
 
 def main():
@@ -162,21 +481,31 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the larger single-GPU roofline points')
-    ap.add_argument('--large', action='store_true', help='also run the 2e8-mark single-GPU point')
+    ap.add_argument('--no-large', action='store_true', help='skip the 2e8-mark single-GPU point (about a minute of host-side generation)')
+    ap.add_argument('--large', action='store_true', help='(default now; kept for round-1 command lines)')
+    ap.add_argument('--genome-marks', type=int, default=20000000, help='N > 1: marks of the sharded whole-genome problem')
+    ap.add_argument('--launch-dry-run', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    from duet_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # started plainly: hand over to one fresh process per GPU BEFORE anything here has touched torch or HIP
+        sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
+                                    extra_env={'DUET_BENCH_PARENT_TORCH': '1' if 'torch' in sys.modules else '0'}))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                     '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d' % (args.gpus, args.gpus))
         sys.exit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+    if args.launch_dry_run:
+        if rank == 0:
+            print(json.dumps({'launch_dry_run': True, 'rank': rank, 'world': world,
+                              'torch_imported_by_parent': os.environ.get('DUET_BENCH_PARENT_TORCH') == '1'}))
+        return
 
     import torch
-    from duet_amd import _lib, dist, engine, synth
-    from duet_amd.devmem import DeviceProblem
+    from duet_amd import _lib
 
     # DUET_BENCH_ONE_GPU=1 (plumbing test on a 1-GPU box only): every rank uses device 0 and the collective
     # goes through gloo instead of RCCL; never set for a measurement.
@@ -194,79 +523,15 @@ def main():
             dist_mod.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     ctx = _lib.Context(local_rank)
-
-    # ---- workload: one config-2 contig per rank ------------------------------------------------------
-    label = synth.DEFAULT_CONTIGS[rank % len(synth.DEFAULT_CONTIGS)]
-    contig = synth.bench_contig('1', 200000, 100000, 1 + rank, spelled='chr' + label)
-    soa = engine.soa_from_synth([contig])
-    n_max = soa.n_cands                      # every rank has exactly 100000 candidates
-    dp = DeviceProblem(soa, 50, 2, device='cuda:%d' % local_rank, n_cands_max=n_max, n_out=2 * GATHER_GROUP if world > 1 else 2)
-
-    with torch.cuda.stream(torch.cuda.Stream()):             # a stream of its own, not the legacy default stream
-        dt, prof, iso, gathered, last_slot = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod)
-
-    # correctness of what was timed (rank-local, against the C oracle) -- outside the timed region
-    pred, ps = dp.results(last_slot)
-    c_oracle = cpu_leg()
-    rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
-    parity = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
-    if world > 1:
-        # this rank's slice of the gathered block must be what it computed
-        mine = gathered[rank].cpu().numpy()
-        gp, gs = dist.unpack_block(mine, n_max, soa.n_cands)
-        parity = parity and bool(np.array_equal(gp, want_pred) and np.array_equal(gs, want_ps))
-
-    marks_local = soa.n_marks
-    if world > 1:
-        t = torch.tensor([dt, float(marks_local), float(parity)], dtype=torch.float64, device='cuda')
-        tmax = t.clone()
-        dist_mod.all_reduce(tmax, op=dist_mod.ReduceOp.MAX)
-        tsum = t.clone()
-        dist_mod.all_reduce(tsum, op=dist_mod.ReduceOp.SUM)
-        dt = float(tmax[0])
-        marks_total = float(tsum[1])
-        parity = bool(tsum[2] == world)
+    if world == 1:
+        out = single_gpu_run(args, ctx, torch)
     else:
-        marks_total = float(marks_local)
-
+        out = sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu)
+        if not args.no_extra:
+            weak = weak_grouped_run(args, ctx, torch, dist_mod, rank, world, local_rank)
+            if rank == 0:
+                out['extra'] = {'weak_grouped_config2_per_rank': weak}
     if rank == 0:
-        kname = _lib.KERNEL_NAMES[0]
-        k_ms = float(prof.kernel_ms[0])
-        abytes = classify_bytes(soa)
-        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        out = {
-            'metric': 'SV support-read marks clustered+phased /sec; bit-exact phased_sv.vcf vs ref',
-            'value': marks_total * args.steps / dt, 'unit': 'marks/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32/u64 integer + f64 threshold compares',
-            'data': 'synthetic',
-            'plumbing_test_one_gpu': one_gpu,
-            'config': {'workload': 'BASELINE configs[1]: synthetic 1 contig per GPU, %d SV marks / %d candidates / '
-                                   '%d tagged reads per contig, resident in HBM; step = classify+seed_sort+finalize%s'
-                                   % (soa.n_marks, soa.n_cands, soa.n_reads,
-                                      ' + all_gather_into_tensor of the 5 B/candidate records, %d jobs per collective (async, overlapping the next jobs)' % GATHER_GROUP if world > 1 else ''),
-                       'marks_per_gpu': soa.n_marks, 'candidates_per_gpu': soa.n_cands, 'reads_per_gpu': soa.n_reads,
-                       'parallelism': 'contig-sharded x%d' % world, 'svlen_thres': 50, 'suppread_thres': 2},
-            'parity_vs_oracle': parity,
-            'kernels_us_isolated': {n: round(float(iso.kernel_ms[i]) * 1e3, 2) for i, n in enumerate(_lib.KERNEL_NAMES)},
-            'roofline': {'kernel': kname, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(soa),
-                         'algorithmic_bytes_per_launch': abytes, 'launch_ms': k_ms,
-                         'launches_timed': int(prof.n_profiled_runs),
-                         'note': 'config 2 is 14.6 MB per launch (~1.8 us at peak): launch-latency bound; '
-                                 'see extra.* for the bandwidth-bound sizes'},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(soa)
-            out['cpu_baseline_python'] = python_baseline([contig])
-        if world == 1 and not args.no_extra:
-            out['extra'] = extra_points(ctx, torch, engine, synth, DeviceProblem, args.large)
-            out['extra']['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
-            out['extra']['fused_clustered_and_phased_config2'] = fused_point(ctx, torch, engine, synth, [contig])
-            out['extra']['fused_clustered_and_phased_2e7_marks'] = fused_point(ctx, torch, engine, synth,
-                                                                               synth.bench_genome(20000000, 3), runs=5)
-            out['extra']['three_timed_regions_config2'] = abi_and_e2e(ctx, soa, contig, float(iso.total_ms))
-            out['extra']['concurrent_jobs_config2'] = concurrent_jobs(torch, _lib, DeviceProblem, soa, args.steps)
         print(json.dumps(out))
         sys.stdout.flush()
 
@@ -430,9 +695,17 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20):
               and np.array_equal(got['cand_off'], cl['cand_off']) and np.array_equal(got['order'], cl['order'])
               and np.array_equal(got_async['pred'], wp) and np.array_equal(got_async['ps'], ws))
     M = len(marks['pos'])
+    b_a0, b_ef = 18 * M, 12 * M + 27 * int(ds.n_found) + 8 * soa.n_reads
+    gbs = (b_a0 + b_ef) / dt / 1e9
     return {'marks': M, 'candidates_found': int(ds.n_found), 'phased': int((got['pred'] != 0).sum()),
             'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'ms_per_run_with_count_returned': dt_wait * 1e3,
             'parity_vs_composed_oracles': ok,
+            'roofline': {'kernels': 'duet_svim_phase_device: A0 (sort, partitions, linkage, emit) + E/F, ~30 launches',
+                         'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                         'traffic': None, 'algorithmic_bytes_per_run': b_a0 + b_ef, 'B_A0_18_per_mark': b_a0, 'B_EF': b_ef,
+                         'run_ms': dt * 1e3,
+                         'note': 'whole pipeline: (B_A0 + B_EF) / wall time per run, back-to-back runs resident in HBM; the '
+                                 'sort passes and the pair distances of the agglomeration are not credited (SURVEY 8d)'},
             'note': 'asynchronous call (E/F planned on the device); the second figure is the variant with one host round trip'}
 
 
@@ -469,7 +742,11 @@ def extra_points(ctx, torch, engine, synth, DeviceProblem, large):
         ok = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
         ab = classify_bytes(soa)
         kms = float(prof.kernel_ms[0])
+        gbs = ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         pts[name] = {'parity_vs_oracle': ok, 'marks': soa.n_marks, 'candidates': soa.n_cands, 'reads': soa.n_reads,
+                     'roofline': {'kernel': 'ef_classify', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': gbs / HBM_PEAK_GBS, 'traffic': pmc_traffic(soa), 'algorithmic_bytes_per_launch': ab,
+                                  'launch_ms': kms, 'launches_timed': int(prof.n_profiled_runs), 'workload': name},
                      'contigs': soa.n_contigs, 'ms_per_step': dt * 1e3, 'marks_per_s': soa.n_marks / dt,
                      'kernels_ms': {k: float(prof.kernel_ms[i]) for i, k in enumerate(('ef_classify', 'ef_seed_sort', 'ef_finalize'))},
                      'classify_GBs': ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,

@@ -1,6 +1,6 @@
 # coding=utf-8
-"""The `duet` command: BAM REFERENCE OUTPUT [-t -m -c -s -r -a -b] as upstream (src/duet/duet:14-28), one additive
-flag (--device).  The pipeline is a table of stages; B, C, D shell out to external tools (duet_amd/stages.py),
+"""The `duet` command: BAM REFERENCE OUTPUT [-t -m -c -s -r -a -b] as upstream (src/duet/duet:14-28), two additive
+flags (--device, --gpus).  The pipeline is a table of stages; B, C, D shell out to external tools (duet_amd/stages.py),
 the last one -- SV phasing, steps E/F -- runs on the MI355X."""
 
 import logging
@@ -21,7 +21,7 @@ def pipeline(a):
         (stages.sv_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.cluster_max_distance, a.sv_min_size, a.thread, a.sv_caller,
                              a.min_support_read)),
         (stages.snp_phasing, (a.OUTPUT, a.REFERENCE, a.BAM, a.thread)),
-        (sv_phasing, (a.OUTPUT, a.sv_min_size, a.min_support_read, a.thread, a.include_all_ctgs)),
+        (sv_phasing, (a.OUTPUT, a.sv_min_size, a.min_support_read, a.thread, a.include_all_ctgs, a.device, a.gpus)),
     )
 
 
@@ -35,7 +35,8 @@ def main(argv):
     todo = pipeline(a)
     for fn, args in todo[:-1]:
         fn(*args)
-    engine.default_context(a.device)          # fail before the last stage if there is no MI355X / no library
+    if a.gpus <= 1:
+        engine.default_context(a.device)      # fail before the last stage if there is no MI355X / no library
     fn, args = todo[-1]
     fn(*args)
     logging.info('%s DUET FINISHED IN %ss %s' % (_BAR, round(time.time() - began, 3), _BAR))

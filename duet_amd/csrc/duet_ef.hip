@@ -6,18 +6,21 @@
 //                 its slice of mark_read with 16-byte loads, gathers the 8-byte read tag of every
 //                 mark (the join of sv_phasing_fn.py:46-48) into LDS, then each thread walks ITS
 //                 candidate's marks in list order out of LDS: filter (:189-190), PS-class (:191-194),
-//                 seed PS (:199-203), class-0/1 vote (:74-84) and decision (:142-183).  Seeds go
-//                 into a per-contig open-addressing hash set in HBM (atomicCAS), deduplicated
-//                 against the neighbouring candidate first.
-//   ef_seed_sort  one workgroup per contig: collects the contig's distinct seeds, bitonic-sorts
-//                 them in LDS (global memory for > 16K seeds) -> ascending `oneps` array (:107),
-//                 and wipes the hash slots it consumed (the set is self-cleaning between runs).
+//                 seed PS (:199-203), class-0/1 vote (:74-84) and decision (:142-183); multi-PS
+//                 candidates leave a 14-word summary of their first two voter groups.  Seeds leave the
+//                 tile as compacted (candidate, PS) entries in candidate order -- repeats of the previous
+//                 seed-bearing candidate dropped with ballots -- in the tile's own slots: no atomics, no
+//                 hash set.
+//   ef_seed_sort  one workgroup per contig: gathers the contig's entries in candidate order (an
+//                 exclusive scan of per-thread counts), finishes local disorder with a few odd-even
+//                 rounds, merges a few long ascending runs by rank or falls back to a bitonic network
+//                 (LDS up to 15,360 seeds, HBM beyond), drops duplicates -> ascending `oneps` (:107).
 //   ef_finalize   per candidate: contig drop (:209-210), nearest-PS (:106-111), and the class-2
 //                 grouped vote (:85-105) + decision (:148-155) for the few multi-PS candidates.
 //
 // Everything order-dependent upstream (first qualifying mark, first-seen PS wins ties, last voter's
-// PS) is reproduced by walking marks in list order; nothing relies on atomics ordering -- the only
-// atomics build a SET, whose content does not depend on arrival order.
+// PS) is reproduced by walking marks in list order; no result depends on atomic arrival order (the
+// only LDS atomics hand out summary slots, whose numbering is not observable).
 //
 // Floating point: IEEE binary64, operations exactly as upstream, built with -ffp-contract=off.
 
@@ -42,7 +45,7 @@ namespace {
 #define STAMP(k, i) do { } while (0)
 #endif
 
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;          // empty hash slot / "no seed"
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;          // "no seed" / "no PS yet"
 constexpr uint64_t kUntagged = ~0ull;             // LDS tag word of an absent mark
 constexpr uint32_t kPcMax = DUET_PC_MAX;
 
@@ -229,10 +232,12 @@ __device__ __forceinline__ uint32_t decide_store(const Params &p, TileShared &sh
     const bool c2_fast = c2 && !st.more && deg < 500000u;
     const uint32_t rank = c2_fast ? atomicAdd(&sh.c2n, 1u) : kC2Quota;
     if (live) {
+        // the seed sets are built from every kept class-1 candidate BEFORE any decision is taken (:195-203), so a candidate
+        // whose decision would divide by zero (:123) still contributes its seed -- and raises only if its contig then has one
+        want_seed = (active || divzero) && (n_ps == 1) && st.seed() != kEmpty;                     // :198-203
         if (divzero) {
             code = kDivZero;
         } else if (active) {
-            want_seed = (n_ps == 1) && st.seed() != kEmpty;                                        // :198-203
             if (c2) {
                 if (rank < kC2Quota) {
                     const uint32_t slot = tile * kC2Quota + rank;
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         // ---- consume: each thread walks its candidate's part of this chunk ----------------------
         uint32_t lo = max(my_b, cs);
         const uint32_t hi = min(my_e, cs + (uint32_t)kChunk);
-        if (!active || (p.dbg & 4)) lo = hi;
+        if (!kept || (p.dbg & 4)) lo = hi;
         consume_range(st, s_tag, lo, hi, cs);
         STAMP(0, 3);
         __syncthreads();
@@ -1192,7 +1197,7 @@ int duet_ctx_set_profiling(duet_ctx *ctx, int enabled)
 }
 
 #ifdef DUET_STAMPS
-int duet_dbg_stamps(duet_ctx *ctx, int enable, unsigned long long *host_out)
+DUET_API int duet_dbg_stamps(duet_ctx *ctx, int enable, unsigned long long *host_out)
 {
     const size_t bytes = (size_t)3 * 65536 * 8 * 8;
     if (enable && !ctx->d_stamps) { if (hipMalloc((void **)&ctx->d_stamps, bytes) != hipSuccess) return -1; }

@@ -189,6 +189,7 @@ struct duet_ingest {
     bool alias = false;
     std::vector<NameTable> tables;
     std::vector<std::vector<uint64_t>> tags;
+    std::vector<uint8_t> bam_has_aln;             // per contig: its BAM printed at least one alignment line (:30-33)
     std::string err;
     // VCF
     std::vector<char> vcf;
@@ -402,6 +403,7 @@ duet_ingest *duet_ingest_create(int n_contigs, const char *const *contig_names)
     }
     g->tables.resize(n_contigs);
     g->tags.resize(n_contigs);
+    g->bam_has_aln.assign(n_contigs, 0);
     return g;
 }
 
@@ -438,6 +440,7 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     while (p + 4 <= n) {
         const size_t bs = u32(p), end = p + 4 + bs;
         if (end > n || bs < 32) return unsupported(g, "truncated BAM record");
+        g->bam_has_aln[contig] = 1;
         const unsigned l_name = b[p + 12];
         const unsigned n_cig = b[p + 16] | (b[p + 17] << 8);
         const size_t l_seq = u32(p + 20);
@@ -674,6 +677,8 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
             auto it = g->owner.find(key);
             if (it != g->owner.end()) {
                 if (nt < 10) { o.why = "record with fewer than 10 columns"; return; }
+                // an 11th token shifts upstream's appended columns (read_file.py:37): TypeError in generate_callinfo
+                if (nt > 10) { o.why = "record with more than 10 columns"; return; }
                 o.per[it->second].push_back(r);
             }
         }
@@ -894,7 +899,7 @@ int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, in
     if (C && (!pred || !ps)) return DUET_INGEST_INVALID;
     std::string out;
     out.reserve(4096 + C * 48);
-    {
+    if (include_all_ctgs >= 0) {
         const int hrc = build_header(g, include_all_ctgs, out);
         if (hrc) return hrc;
     }
@@ -1055,6 +1060,12 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
     o->max_pos = g->max_pos;
     o->cand_plus = g->cand_plus.data();
     return DUET_INGEST_OK;
+}
+
+int duet_ingest_bam_has_alignments(const duet_ingest *g, int contig)
+{
+    if (!g || contig < 0 || contig >= (int)g->contigs.size()) return DUET_INGEST_INVALID;
+    return g->bam_has_aln[contig];
 }
 
 int duet_ingest_set_extraction(duet_ingest *g, int enable, uint32_t min_sv_size, uint32_t min_mapq, uint32_t depth_bin)

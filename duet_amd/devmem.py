@@ -14,7 +14,7 @@ class DeviceProblem(object):
     """An EfSoA uploaded once to HBM, plus output buffers, ready for repeated duet_ef_run_device."""
 
     def __init__(self, soa, svlen_thres, suppread_thres, device='cuda:0', misalign_marks=0, n_cands_max=None,
-                 n_out=1):
+                 n_out=1, trailer=0):
         import torch
         self.torch = torch
         self.soa = soa
@@ -35,7 +35,7 @@ class DeviceProblem(object):
         self.n_max = max(int(n_cands_max or soa.n_cands), soa.n_cands, 1)
         # n_out > 1: rotating result blocks, so that the all-gather of one job can run beside the kernels of the next
         # (the blocks are slices of ONE allocation, so that several jobs' results can go into one collective)
-        rb = record_bytes(self.n_max)
+        rb = record_bytes(self.n_max) + int(trailer)       # trailer: caller-defined bytes behind the records (status word)
         self.out_storage = torch.zeros(rb * max(1, n_out), dtype=torch.uint8, device=self.device)
         self.out_blocks = [self.out_storage[i * rb:(i + 1) * rb] for i in range(max(1, n_out))]
         self.out_block = self.out_blocks[0]
@@ -47,6 +47,15 @@ class DeviceProblem(object):
         blk = self.out_blocks[slot]
         ctx.run_device(self.problem, blk.data_ptr() + 4 * self.n_max, blk.data_ptr(), stream)
         return stream
+
+    def load_results(self, pred, ps, slot=0):
+        """Put host (pred, ps) -- e.g. the merged records of a multi-GPU run -- into result block `slot`, so that the
+        device-side row emission can read them."""
+        torch = self.torch
+        blk, C = self.out_blocks[slot], self.soa.n_cands
+        if C:
+            blk[:4 * C] = torch.from_numpy(np.ascontiguousarray(ps, dtype=np.uint32).view(np.uint8)).to(self.device)
+            blk[4 * self.n_max:4 * self.n_max + C] = torch.from_numpy(np.ascontiguousarray(pred, dtype=np.uint8)).to(self.device)
 
     def results(self, slot=0):
         """-> (pred u8[C], ps u32[C]) on the host (synchronises)."""

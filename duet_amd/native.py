@@ -18,7 +18,7 @@ OK, UNSUPPORTED = 0, 1
 
 EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam',
            'duet_ingest_parse_vcf', 'duet_ingest_get_arrays', 'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
-           'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks')
+           'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks', 'duet_ingest_bam_has_alignments')
 
 
 class IngestArrays(ctypes.Structure):
@@ -68,6 +68,7 @@ def load():
         lib.duet_ingest_get_marks.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestMarks)]
         lib.duet_ingest_free.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_free.restype = None
+        lib.duet_ingest_bam_has_alignments.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _lib = lib
     return _lib
 
@@ -82,8 +83,19 @@ def _view(ptr, n, dtype):
 class NativeIngest(object):
     """One ingest: tag dicts per contig + caller VCF -> EfSoA (arrays stay owned by the native object)."""
 
-    def __init__(self, handle, lib, soa, why=None):
+    def __init__(self, handle, lib, soa, why=None, bam_contigs=()):
         self.handle, self.lib, self.soa, self.why = handle, lib, soa, why
+        self.bam_contigs = tuple(bam_contigs)          # contig indices for which a BAM file was found (:19-24)
+
+    def log_lines(self, chrom_list):
+        """The per-contig lines upstream logs while it reads the BAMs (sv_phasing_fn.py:30-33: only contigs that have a
+        BAM file) and while it joins the VCF (:41-45: every contig) -> (snp_lines, sv_lines)."""
+        yes, no = '  signatures extracted from ', '  no signature from '
+        snp = [(yes if self.lib.duet_ingest_bam_has_alignments(self.handle, k) == 1 else no) + chrom_list[k]
+               for k in self.bam_contigs]
+        off = self.soa.cand_ctg_off
+        sv = [(yes if off[k + 1] > off[k] else no) + c for k, c in enumerate(chrom_list)]
+        return snp, sv
 
     @classmethod
     def load(cls, vcf_path, sam_home, chrom_list, thread=4):
@@ -102,11 +114,13 @@ class NativeIngest(object):
             lib.duet_ingest_destroy(h)
             return cls(None, lib, None, why)
 
+        with_bam = []
         for k, c in enumerate(chrom_list):
             for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
                 if os.path.exists(cand):
                     if lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) != OK:
                         return decline()
+                    with_bam.append(k)
                     break
         if lib.duet_ingest_parse_vcf(h, vcf_path.encode(), int(thread)) != OK:
             return decline()
@@ -119,7 +133,7 @@ class NativeIngest(object):
                            cand_svlen=_view(a.cand_svlen, C, np.uint32), cand_svread=_view(a.cand_svread, C, np.uint32),
                            cand_refread=_view(a.cand_refread, C, np.uint32), cand_gt_ok=_view(a.cand_gt_ok, C, np.uint8),
                            cand_off=_view(a.cand_off, C + 1, np.uint32), mark_read=_view(a.mark_read, M, np.uint32))
-        return cls(h, lib, soa)
+        return cls(h, lib, soa, bam_contigs=with_bam)
 
     @classmethod
     def extract(cls, sam_home, chrom_list, thread=4, min_sv_size=40, min_mapq=20, depth_bin=1000):
@@ -166,7 +180,8 @@ class NativeIngest(object):
         ps = np.ascontiguousarray(ps, dtype=np.uint32)
         text = ctypes.c_void_p()
         n = ctypes.c_uint64()
-        rc = self.lib.duet_ingest_emit(self.handle, pred.ctypes.data, ps.ctypes.data, 1 if include_all_ctgs else 0,
+        mode = -1 if include_all_ctgs == -1 else (1 if include_all_ctgs else 0)
+        rc = self.lib.duet_ingest_emit(self.handle, pred.ctypes.data, ps.ctypes.data, mode,
                                        ctypes.byref(text), ctypes.byref(n))
         if rc != OK:
             raise RuntimeError('duet_ingest_emit: ' + self.lib.duet_ingest_error(self.handle).decode('utf-8', 'replace'))
@@ -174,6 +189,10 @@ class NativeIngest(object):
             return ctypes.string_at(text.value, n.value)
         finally:
             self.lib.duet_ingest_free(text)
+
+    def emit_rows(self, pred, ps):
+        """The data rows alone (no header) as bytes."""
+        return self.emit(pred, ps, -1)
 
     def header(self, include_all_ctgs):
         """The header lines of phased_sv.vcf as bytes."""

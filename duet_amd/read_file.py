@@ -66,53 +66,66 @@ def _int_or_zero(txt):
 
 
 def _contig_columns(recs):
-    """Derived columns of one contig's records (read_file.py:33-76). The layout switches are taken
-    from recs[0]; later records are parsed with that layout and raise like upstream if they lack it."""
+    """Derived columns of one contig's records (read_file.py:33-76), computed column by column over ALL records
+    like upstream, so that a malformed record raises what upstream raises first.  The layout switches are taken from
+    recs[0]; later records are parsed with that layout and raise like upstream if they lack it."""
     infos = [r[7].split(';') for r in recs]
-    svlen, svtype, svread, names, gt, refread = [], [], [], [], [], []
 
-    first_supp = _first_with(infos[0], 'SUPPORT=', 'SR=', 'RE=')
-    first_rn = _first_with(infos[0], 'RNAMES=', 'READS=')
-    first_fmt = recs[0][9].split(':')
-    if first_supp is None or first_rn is None or len(first_fmt) < 3:
+    def lacks():
         # upstream silently drops the column and then fails on shifted indices (TypeError/IndexError)
-        raise ValueError('first record of contig %s lacks a support count, a read-name list or a '
-                         '>=3-field sample column; the reference cannot process this layout' % recs[0][0])
+        return ValueError('first record of contig %s lacks a support count, a read-name list or a '
+                          '>=3-field sample column; the reference cannot process this layout' % recs[0][0])
+
+    svlen = []
+    for items in infos:                                            # :34-36
+        it = _first_with(items, 'SVLEN=')
+        if it is None or it == 'SVLEN=.':
+            it = 'SVLEN=0'
+        svlen.append(int(it[7:]) if '>' in it else int(it[6:]))
+    svtype = []
+    for items in infos:                                            # :38
+        it = _first_with(items, 'SVTYPE=')
+        if it is None:
+            raise IndexError('list index out of range')            # upstream: [][0]
+        svtype.append(it[7:])
+    first_supp = _first_with(infos[0], 'SUPPORT=', 'SR=', 'RE=')
+    if first_supp is None:
+        raise lacks()
     supp_cut = 8 if 'SUPPORT=' in first_supp else 3
+    svread = []
+    for items in infos:                                            # :40-47
+        it = _first_with(items, 'SUPPORT=', 'SR=', 'RE=')
+        if it is None:
+            raise IndexError('list index out of range')
+        svread.append(int(it[supp_cut:]))
+    first_rn = _first_with(infos[0], 'RNAMES=', 'READS=')
+    if first_rn is None:
+        raise lacks()
     rn_cut = 7 if 'RNAMES=' in first_rn else 6
+    names = []
+    for items in infos:                                            # :48-55
+        it = _first_with(items, 'RNAMES=', 'READS=')
+        if it is None:
+            raise IndexError('list index out of range')
+        names.append(it[rn_cut:].split(','))
+    subs = [r[9].split(':') for r in recs]                          # :56
+    first_fmt = subs[0]
+    if len(first_fmt) < 3:
+        raise lacks()
     if len(first_fmt) > 4:
         fmt_kind = 0                    # cuteSV   GT:DR:DV:PL:GQ -> DR
     elif first_fmt[-1].find(',') == -1:
         fmt_kind = 1                    # Sniffles GT:GQ:DR:DV    -> GQ (sic)
     else:
         fmt_kind = 2                    # SVIM     GT:DP:AD       -> AD[0]
-
-    for r, items in zip(recs, infos):
-        it = _first_with(items, 'SVLEN=')
-        if it is None or it == 'SVLEN=.':
-            it = 'SVLEN=0'
-        svlen.append(int(it[7:]) if '>' in it else int(it[6:]))
-        it = _first_with(items, 'SVTYPE=')
-        if it is None:
-            raise IndexError('list index out of range')            # upstream: [][0]
-        svtype.append(it[7:])
-        it = _first_with(items, 'SUPPORT=', 'SR=', 'RE=')
-        if it is None:
-            raise IndexError('list index out of range')
-        svread.append(int(it[supp_cut:]))
-        it = _first_with(items, 'RNAMES=', 'READS=')
-        if it is None:
-            raise IndexError('list index out of range')
-        names.append(it[rn_cut:].split(','))
-        sub = r[9].split(':')
-        gt.append(sub[0])
-        if fmt_kind == 2:
-            last = sub[-1]
-            k = last.find(',')
-            refread.append(_int_or_zero(last[:k]))
-            _int_or_zero(last[k + 1:])                              # parsed (and may raise) upstream too
-        else:
-            refread.append(_int_or_zero(sub[1]))
+    gt = [sub[0] for sub in subs]
+    if fmt_kind == 2:                                              # :70-76
+        refread = [_int_or_zero(sub[-1][:sub[-1].find(',')]) for sub in subs]
+        for sub in subs:
+            _int_or_zero(sub[-1][sub[-1].find(',') + 1:])           # parsed (and may raise) upstream too
+    else:                                                          # :58-69
+        refread = [_int_or_zero(sub[1]) for sub in subs]
+        for sub in subs:
             _int_or_zero(sub[2])
     return svlen, svtype, svread, names, gt, refread
 
@@ -152,6 +165,12 @@ def parse_vcf(vcf_file, include_all_ctgs, tokens=None):
             svread_all.extend(svread)
             refread_all.extend(refread)
         tab.ctg_off[k + 1] = len(tab.chrom)
+    for recs in per_ctg:
+        for r in recs:
+            if len(r) > 10:
+                # upstream appends its derived columns AFTER the last token (read_file.py:37), so an 11th token
+                # shifts them and generate_callinfo fails on the shifted indices (sv_phasing_fn.py:47,62)
+                raise TypeError("'int' object is not iterable")
     tab.pos = np.array(pos, dtype=np.int64)
     tab.svlen_abs = np.array(svlen_abs, dtype=np.int64)
     tab.svread = np.array(svread_all, dtype=np.int64)

@@ -299,9 +299,11 @@ _TYPES = ['INS', 'DEL', 'DUP', 'INV', 'DUP:TANDEM', 'BND', 'DUP:INT']
 _GTS = ['0/1', '1/1', './.', '0/0', '1/0', '.']
 
 
-def fuzz_case(seed, labels=None, n_contigs=3):
+def fuzz_case(seed, labels=None, n_contigs=3, bare_bias=False):
     """Small adversarial multi-contig case. Returns list[SynthContig] (some without BAM, some
-    spelled without the 'chr' prefix, plus one contig outside the default list)."""
+    spelled without the 'chr' prefix, plus one contig outside the default list).  bare_bias: spell three
+    contigs in four exactly like their list entry (the natural case with -a, where the list already holds the
+    names as the files spell them) instead of 'chr' + entry."""
     rng = SplitMix(0xF00D0000 + seed)
     pool = DEFAULT_CONTIGS if labels is None else labels
     picks = []
@@ -311,7 +313,7 @@ def fuzz_case(seed, labels=None, n_contigs=3):
             picks.append(l)
     out = []
     for ci, l in enumerate(picks):
-        spelled = ('chr' + l) if rng.one(4) else l
+        spelled = ('chr' + l) if bool(rng.one(4)) != bool(bare_bias) else l
         length = 2000000 + rng.one(3000000)
         c = SynthContig(l, spelled, length)
         R = 20 + rng.one(120)
@@ -368,6 +370,29 @@ def fuzz_case(seed, labels=None, n_contigs=3):
         c.mark_name_id = mark
         out.append(c)
     return out
+
+
+# contig names for -a / --include_all_ctgs cases: what `tabix --list-chroms` prints for a pileup VCF (read_file.py:13-15).
+# No name equals 'chr' + another one (such a list names one contig twice; the build refuses it).
+ALL_CTG_POOL = ['chr1', 'chr2', 'chr10', 'chr19', 'chrX', 'chrM', 'chrUn_gl000220', 'chr6_cox_hap2', 'GL000192.1',
+                'KI270728.1', 'MT', '21', 'HLA-A*01:01', 'chrEBV', 'scaffold_7', 'Y']
+
+
+def fuzz_case_all_ctgs(seed, n_contigs=4):
+    """A fuzz case for -a mode.  -> (contigs, listing, header_contigs): `listing` is the contig universe in the order
+    `tabix --list-chroms` would print it (a shuffled subset of ALL_CTG_POOL, NOT karyotype order); the candidates sit on
+    `n_contigs` of them; `header_contigs` are the ##contig lines of the caller VCF in a third order and include names
+    that are not in the listing (with -a every ##contig line is copied in FILE order, write_file.py:38-41)."""
+    rng = SplitMix(0xA11C0000 + seed)
+    pool = list(ALL_CTG_POOL)
+    order = np.argsort(rng.u64(len(pool)), kind='stable')
+    listing = [pool[i] for i in order[:6 + rng.one(len(pool) - 6)]]
+    contigs = fuzz_case(seed, labels=listing, n_contigs=min(n_contigs, len(listing)), bare_bias=True)
+    spelled = {c.label: c.spelled for c in contigs}
+    names = [spelled.get(l, l) for l in listing] + ['chrNotListed_1', 'decoy']
+    horder = np.argsort(rng.u64(len(names)), kind='stable')
+    header_contigs = [(names[i], 1000 + 37 * int(i)) for i in horder]
+    return contigs, listing, header_contigs
 
 
 # ------------------------------------------------------------------------------------------
@@ -540,12 +565,19 @@ def write_svim_workdir(home, contigs, seed=1, write_sam=True):
     return home
 
 
-def write_workdir(home, contigs, dialect='cutesv', seed=1, write_bam=True, write_sam=True, **vcf_kw):
+def write_workdir(home, contigs, dialect='cutesv', seed=1, write_bam=True, write_sam=True, listing=None, **vcf_kw):
     """Lay out Duet's <OUTPUT> directory for step E/F (sv_phasing.py:12-14):
     <home>/sv_calling/variants.vcf and <home>/snp_phasing/<spelled>.bam (+ .bam.sam text that a
-    `samtools view` shim can print)."""
+    `samtools view` shim can print).  `listing` (for -a mode): the contig names a
+    `tabix --list-chroms` shim prints, written to <home>/snp_calling/pileup.vcf.gz.chroms beside an empty
+    pileup.vcf.gz (read_file.py:13-15 only passes the path on)."""
     os.makedirs(os.path.join(home, 'sv_calling'), exist_ok=True)
     os.makedirs(os.path.join(home, 'snp_phasing'), exist_ok=True)
+    if listing is not None:
+        os.makedirs(os.path.join(home, 'snp_calling'), exist_ok=True)
+        open(os.path.join(home, 'snp_calling', 'pileup.vcf.gz'), 'wb').close()
+        with open(os.path.join(home, 'snp_calling', 'pileup.vcf.gz.chroms'), 'w') as f:
+            f.write(''.join(n + '\n' for n in listing))
     write_vcf(os.path.join(home, 'sv_calling', 'variants.vcf'), contigs, dialect=dialect, seed=seed, **vcf_kw)
     for c in contigs:
         if not c.has_bam:

@@ -2,7 +2,8 @@
 """Flags, logging and input checks of the `duet` command (mirror of src/duet/utils.py:8-50).
 
 Flag names, defaults, help texts and the positional order are upstream's (utils.py:19-44), so an
-existing command line works unchanged.  Two additive options select the device.
+existing command line works unchanged.  Two additive options select the device (--device) or shard the contigs
+over several GPUs (--gpus).
 """
 
 import argparse
@@ -40,6 +41,8 @@ def build_parser():
                     help='choose the base SV caller from cuteSV ("cutesv"), Sniffles (sniffles), or SVIM ("svim") '
                          '[%(default)s]')
     ap.add_argument('--device', type=int, default=0, help='HIP device index for SV phasing [%(default)s]')
+    ap.add_argument('--gpus', type=int, default=1,
+                    help='number of GPUs for SV phasing: contigs are sharded over them, one process per GPU [%(default)s]')
     for name, text in _POSITIONALS:
         ap.add_argument(name, type=str, help=text)
     return ap
@@ -55,6 +58,20 @@ def set_logging(home):
     root = logging.getLogger()
     root.setLevel(logging.INFO)
     for handler in (logging.FileHandler(home + '/run_duet.log', mode='w'), logging.StreamHandler()):
+        handler.setFormatter(fmt)
+        root.addHandler(handler)
+
+
+def add_stream_logging(home):
+    """Logging of a rank process started by duet_amd/multi.py: the same line format on stderr, appended to
+    <home>/run_duet.log when the parent logs there (DUET_RANK_LOG=1)."""
+    fmt = logging.Formatter('%(asctime)s [%(levelname)s] %(message)s', datefmt='%H:%M:%S')
+    root = logging.getLogger()
+    root.setLevel(logging.INFO)
+    handlers = [logging.StreamHandler()]
+    if os.environ.get('DUET_RANK_LOG') == '1':
+        handlers.append(logging.FileHandler(home + '/run_duet.log', mode='a'))
+    for handler in handlers:
         handler.setFormatter(fmt)
         root.addHandler(handler)
 

@@ -32,6 +32,9 @@ extern "C" {
 
 #define DUET_ABI_VERSION 1
 
+/* The library is built with -fvisibility=hidden: only the functions declared in this header are exported. */
+#define DUET_API __attribute__((visibility("default")))
+
 typedef enum duet_status {
     DUET_OK = 0,
     DUET_ERR_INVALID = -1,    /* bad argument (NULL pointer, inconsistent sizes) */
@@ -94,19 +97,19 @@ typedef struct duet_ef_stats {
 
 typedef struct duet_ctx duet_ctx;
 
-int duet_abi_version(void);
+DUET_API int duet_abi_version(void);
 
 /* Context on HIP device `device_id`. NULL on failure; duet_last_error(NULL) then holds the reason. */
-duet_ctx *duet_ctx_create(int device_id);
-void duet_ctx_destroy(duet_ctx *ctx);
-const char *duet_last_error(const duet_ctx *ctx);
+DUET_API duet_ctx *duet_ctx_create(int device_id);
+DUET_API void duet_ctx_destroy(duet_ctx *ctx);
+DUET_API const char *duet_last_error(const duet_ctx *ctx);
 
 /* HIP events attached to the kernels' own dispatches (hipExtLaunchKernelGGL start/stop events on the run's
  * stream), resolved by duet_ef_profile_collect: 0 = none, 1 = the dominant kernel (ef_classify) only -- two
  * events per run --, 2 = every kernel (kernel_ms[] complete, total_ms = first start to last end; serialises
  * the stream a little more), 3 = like 1 but only on every 8th run (what bench.py uses inside its timed
  * region: event pairs cost ~6 us of stream time each, a quarter of a config-2 step). */
-int duet_ctx_set_profiling(duet_ctx *ctx, int mode);
+DUET_API int duet_ctx_set_profiling(duet_ctx *ctx, int mode);
 
 /*
  * Run E/F on device-resident inputs, asynchronously on `stream` (a hipStream_t passed as void*, NULL =
@@ -114,21 +117,21 @@ int duet_ctx_set_profiling(duet_ctx *ctx, int mode);
  * device pointers.  out_ps[c] is the PS predict_hp returns when the reference calls it for c, else 0.
  * The call does not synchronise; DUET_ERR_DIV_ZERO is reported by duet_ef_check (or by the host run).
  */
-int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pred, uint32_t *out_ps,
+DUET_API int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pred, uint32_t *out_ps,
                        void *stream);
 
 /* Synchronise `stream` and return the deferred status of the runs issued on this context since the
  * last check (DUET_OK or DUET_ERR_DIV_ZERO / DUET_ERR_HIP). */
-int duet_ef_check(duet_ctx *ctx, void *stream);
+DUET_API int duet_ef_check(duet_ctx *ctx, void *stream);
 
 /* Host convenience: copies the arrays to the device, runs, copies the results back, synchronises.
  * stats may be NULL. */
-int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pred, uint32_t *out_ps,
+DUET_API int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *prob, uint8_t *out_pred, uint32_t *out_ps,
                      duet_ef_stats *stats);
 
 /* Profiling mode: synchronise, average the per-kernel event timings of the runs since the last
  * collect into *stats, and reset. */
-int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
+DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 
 /* Diagnostics: low bits ablate E/F kernel phases (tools/ablate.py); DUET_DBG_CLUSTER_EXACT sends every A0
  * partition through the exact binary64 agglomeration instead of the threshold-graph fast path (the outputs are
@@ -137,11 +140,11 @@ int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */
 #define DUET_DBG_CLUSTER_PAIRS 0x400u   /* A0: sort (key, mark index) pairs even when the index fits the key's spare bits */
-int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags);
+DUET_API int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags);
 
 /* Debug/inspection: copy contig k's sorted seed-PS array of the LAST run to `out` (capacity `cap`),
  * return its length (or a negative status). */
-int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t cap);
+DUET_API int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t cap);
 
 /* ------------------------------------------------------------------------------------------------------
  * Stage A0: span-position clustering of SV marks into candidates.
@@ -186,9 +189,9 @@ typedef struct duet_cluster_result {
     uint32_t *n_cands;
 } duet_cluster_result;
 
-int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res,
+DUET_API int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res,
                             void *stream);
-int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res);
+DUET_API int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res);
 
 /* ------------------------------------------------------------------------------------------------------
  * Fused SVIM-mode pipeline: raw SV marks -> A0 clustering -> E/F phasing, everything resident in HBM, no VCF
@@ -221,7 +224,7 @@ typedef struct duet_svim_problem {
  * n_cands_host != NULL: the call waits once for the clustering to learn the candidate count, stores it there and
  * plans E/F on the host.  n_cands_host == NULL: nothing waits -- E/F is planned on the device for the upper bound of M
  * candidates and reads the count from res->n_cands; the caller gets the count from there after synchronising. */
-int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *prob, const duet_cluster_result *res,
+DUET_API int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *prob, const duet_cluster_result *res,
                            uint8_t *out_pred, uint32_t *out_ps, uint32_t *n_cands_host, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -253,14 +256,14 @@ typedef struct duet_rows_problem {
 
 /* Writes the rows, in final order, to out_text (device, out_cap bytes; pool_bytes + 96 * n_cands always suffices);
  * *out_len = bytes written, *n_rows = rows.  Synchronises `stream` (twice). */
-int duet_rows_run_device(duet_ctx *ctx, const duet_rows_problem *prob, char *out_text, uint64_t out_cap, uint64_t *out_len,
+DUET_API int duet_rows_run_device(duet_ctx *ctx, const duet_rows_problem *prob, char *out_text, uint64_t out_cap, uint64_t *out_len,
                          uint32_t *n_rows, void *stream);
 
 /* Host-array convenience of the two together: *prob as for duet_ef_run_host, *rows with HOST arrays cand_plus,
  * cand_chrom_rank, pool, str_off (+ n_cands, n_chrom_texts, max_pos, pool_bytes; the other fields are filled in here);
  * uploads, runs E/F and the row emission on the device and copies the rows' text to out_text (host, out_cap bytes).
  * Returns what duet_ef_run_host would (e.g. DUET_ERR_DIV_ZERO) before writing any row. */
-int duet_ef_rows_run_host(duet_ctx *ctx, const duet_ef_problem *prob, const duet_rows_problem *rows, char *out_text,
+DUET_API int duet_ef_rows_run_host(duet_ctx *ctx, const duet_ef_problem *prob, const duet_rows_problem *rows, char *out_text,
                           uint64_t out_cap, uint64_t *out_len, uint32_t *n_rows);
 
 #ifdef __cplusplus

@@ -48,12 +48,17 @@ const char *duet_ingest_error(const duet_ingest *ing);
 /* Tag dict of contig k from a BAM file (built-in BGZF/BAM reader, `threads` inflate workers). */
 int duet_ingest_add_bam(duet_ingest *ing, int contig, const char *bam_path, int threads);
 
+/* 1 when the BAM added for contig k held at least one alignment (the reference logs '  signatures extracted from k'
+ * then, '  no signature from k' otherwise: src/duet/sv_phasing_fn.py:30-33), 0 when it held none or none was added. */
+int duet_ingest_bam_has_alignments(const duet_ingest *ing, int contig);
+
 /* Parse the caller VCF (`threads` workers) and join its mark names against the tag dicts added so far. */
 int duet_ingest_parse_vcf(duet_ingest *ing, const char *vcf_path, int threads);
 int duet_ingest_get_arrays(const duet_ingest *ing, duet_ingest_arrays *out);
 
 /* Text of phased_sv.vcf: header (write_file.py:19-45; include_all_ctgs selects which ##contig lines are
- * copied) followed by the rows of every candidate with pred != 0.  Returns a malloc'ed buffer in *text
+ * copied; a negative value leaves the header out -- the caller has written it already, as the reference does before
+ * it evaluates anything, src/duet/sv_phasing.py:16) followed by the rows of every candidate with pred != 0.  Returns a malloc'ed buffer in *text
  * (free with duet_ingest_free) and its length in *len. */
 int duet_ingest_emit(duet_ingest *ing, const uint8_t *pred, const uint32_t *ps, int include_all_ctgs,
                      char **text, uint64_t *len);

@@ -39,6 +39,11 @@ def case_contigs(kind, seed):
 
 
 def build_case(home, kind, seed, dialect, write_bam=True, write_sam=True):
+    if kind == 'fuzz_a':                # -a mode (tests/golden/make_golden_r2.py: build_all_ctgs_case)
+        contigs, listing, header_contigs = synth.fuzz_case_all_ctgs(seed)
+        synth.write_workdir(home, contigs, dialect=dialect, seed=int(seed), write_bam=write_bam, write_sam=write_sam,
+                            listing=listing, header_contigs=header_contigs, extra_contig_records='chrM' not in listing)
+        return contigs
     contigs = case_contigs(kind, seed)
     synth.write_workdir(home, contigs, dialect=dialect, seed=int(seed), write_bam=write_bam, write_sam=write_sam)
     return contigs
@@ -56,3 +61,37 @@ def full_cases():
         with open(os.path.join(d, name, 'params.json')) as f:
             out.append((name, os.path.join(d, name), json.load(f)))
     return out
+
+
+def seeded_r2_plan():
+    """Round-2 pins (tests/golden/make_golden_r2.py): -a fuzz cases, genome_small in the SVIM / Sniffles dialects,
+    config 3, and the ZeroDivisionError case."""
+    with open(os.path.join(GOLDEN, 'seeded_r2.json')) as f:
+        return json.load(f)
+
+
+def all_ctgs_cases():
+    d = os.path.join(GOLDEN, 'cases_a')
+    out = []
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name, 'params.json')) as f:
+            out.append((name, os.path.join(d, name), json.load(f)))
+    return out
+
+
+def listing_of(home):
+    """The contig universe of a -a work dir (what the `tabix --list-chroms` shim prints)."""
+    with open(os.path.join(home, 'snp_calling', 'pileup.vcf.gz.chroms')) as f:
+        return f.read().split('\n')[:-1]
+
+
+def install_tabix_shim(tmp_dir, monkeypatch):
+    """-a mode asks `tabix --list-chroms <home>/snp_calling/pileup.vcf.gz` (read_file.py:13-15); tabix is not in the
+    image, so a PATH shim prints the listing laid beside that path."""
+    shim = os.path.join(str(tmp_dir), 'shim')
+    os.makedirs(shim, exist_ok=True)
+    p = os.path.join(shim, 'tabix')
+    with open(p, 'w') as f:
+        f.write('#!/bin/sh\nfor a; do last="$a"; done\ncat "$last.chroms"\n')
+    os.chmod(p, 0o755)
+    monkeypatch.setenv('PATH', shim + os.pathsep + os.environ['PATH'])

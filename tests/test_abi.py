@@ -31,6 +31,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.duet_abi_version() == 1
 
 
+def exported_duet_symbols(path):
+    import subprocess
+    out = subprocess.check_output(['nm', '-D', '--defined-only', path]).decode()
+    return sorted(set(l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith('duet_')))
+
+
+def test_library_exports_nothing_but_the_declared_symbols():
+    """-fvisibility=hidden + DUET_API: internal cross-unit helpers (duet_ef_upload, duet_ef_run_planned_on_device, ...)
+    are not part of the ABI and must not be visible."""
+    import __graft_entry__
+    from duet_amd import native
+    __graft_entry__.build()
+    assert exported_duet_symbols(_lib.LIB_PATH) == declared_functions()
+    assert exported_duet_symbols(native.LIB_PATH) == declared_functions('duet_ingest.h')
+
+
 def test_ingest_library_exports_every_declared_symbol():
     from duet_amd import native
     import __graft_entry__

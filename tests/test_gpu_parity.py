@@ -150,7 +150,7 @@ def test_many_contigs(ctx):
 
 
 def test_plan_reuse_and_relayout(ctx):
-    """Back-to-back runs on one context: same layout (self-cleaning hash set), then a different one."""
+    """Back-to-back runs on one context: same layout (nothing is memset between runs), then a different one."""
     a = soa_fuzz.random_soa(7, n_contigs=4)
     b = soa_fuzz.random_soa(8, n_contigs=2)
     for soa in (a, a, b, a, b, b):

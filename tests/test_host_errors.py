@@ -31,6 +31,10 @@ CASES = [
     ('support_not_a_number', [GOOD.replace('RE=5', 'RE=five')], ValueError),
     ('later_record_without_names', [GOOD, GOOD.replace('RNAMES=a,b;', '')], IndexError),
     ('pos_not_a_number', [GOOD.replace('\t100\t', '\t1e2\t')], ValueError),
+    # an 11th whitespace token (second sample column, or a space inside INFO): upstream appends its derived columns
+    # after the LAST token (read_file.py:37), generate_callinfo then iterates an int (sv_phasing_fn.py:47)
+    ('eleven_columns', [GOOD + '\t0/1:1:2:3,4,5:6'], TypeError),
+    ('space_inside_info', [GOOD.replace('PRECISE;', 'PRECISE; ')], IndexError),       # INFO is 'PRECISE;': no SVTYPE -> [][0] at parse
 ]
 
 
