@@ -4,9 +4,10 @@
 It consumes exactly what upstream's generate_callinfo returns (sv_phasing_fn.py:49-68: a list of dicts with
 chrom, pos, svlen, svtype, svread, refread, callgt, ref, alt and svreadinfo = [name] or [name, hap, ps, pc] per
 mark) and replaces lines 189-228 of generate_phased_callset.  tests/test_integration_stub.py runs it on such
-lists (with the C oracle in place of `_run`, no GPU needed) and compares with the product path.
+lists -- with the C oracle in place of `_run` where there is no GPU, and with the real `_run` (this file unchanged,
+libduet_ef.so on an MI355X) in tests/test_gpu_r2.py -- and compares with the reference's golden rows.
 """
-import ctypes, numpy as np
+import ctypes, os, numpy as np
 
 class _Problem(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in ('n_contigs', 'n_cands', 'n_marks', 'n_reads')] + \
@@ -21,7 +22,7 @@ def _run(problem, pred, ps):
     """duet_ef_run_host on device 0 (library and context created on first use)."""
     global _lib, _ctx
     if _lib is None:
-        _lib = ctypes.CDLL('libduet_ef.so')
+        _lib = ctypes.CDLL(os.environ.get('DUET_EF_LIB', 'libduet_ef.so'))   # on the loader path, or named explicitly
         _lib.duet_ctx_create.restype = ctypes.c_void_p
         _lib.duet_last_error.restype = ctypes.c_char_p
         _lib.duet_last_error.argtypes = [ctypes.c_void_p]

@@ -17,10 +17,12 @@ from tests.test_c_oracle import materialise_bams
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def load_stub():
+def load_stub(real_run=False):
     spec = importlib.util.spec_from_file_location('ef_gpu_stub', os.path.join(REPO, 'integration', 'ef_gpu.py'))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
+    if real_run:
+        return m                             # the stub exactly as a maintainer would add it: its own _run, the real library
 
     class View(object):                      # the stub's ctypes problem -> the arrays the oracle wants
         pass
@@ -66,10 +68,9 @@ def upstream_callstat(tab, soa):
     return out
 
 
-def test_stub_reproduces_golden_rows(tmp_path):
-    stub = load_stub()
+def stub_rows_match_goldens(stub, tmp_path, cases):
     from duet_amd import write_file as W, read_file as RF
-    for name, src, params in H.full_cases()[:6]:
+    for name, src, params in cases:
         home = str(tmp_path / name)
         shutil.copytree(src, home)
         materialise_bams(home)
@@ -81,3 +82,7 @@ def test_stub_reproduces_golden_rows(tmp_path):
         head = W.header_text(RF.read_file(vcf), init_chrom_list(False, home), False)
         with open(os.path.join(src, 'phased_sv.vcf')) as f:
             assert head + W.rows_text(rows) == f.read(), name
+
+
+def test_stub_reproduces_golden_rows(tmp_path):
+    stub_rows_match_goldens(load_stub(), tmp_path, H.full_cases()[:6])
