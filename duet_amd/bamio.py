@@ -179,10 +179,54 @@ def _fmt_float(x):
     return '%g' % x
 
 
-def _aux_fields(buf, p, end):
-    """Decode all aux fields of one record into SAM text fields."""
+def _real_cigar_from_cg(buf, aux_at, end, n_cig, cig_at, l_seq, ref_id, pos):
+    """SAMv1 section 4.2.2: a CIGAR of more than 65535 operations does not fit the 16-bit n_cigar_op field; BAM then
+    stores the placeholder `<l_seq>S<ref_len>N` and the real operations in a CG:B:I tag.  htslib (and therefore
+    `samtools view`, which the reference parses) moves them back on reading and DROPS the CG tag -- under exactly
+    these conditions: the record is placed (ref_id >= 0, pos >= 0), its first stored operation is a soft clip of the
+    whole read, and a CG tag of type B with subtype I or i holds at least n_cigar_op values.
+    -> (tuple of real cigar words, (start, end) of the CG field inside the aux block) or (None, None)."""
+    if n_cig == 0 or ref_id < 0 or pos < 0:
+        return None, None
+    first = struct.unpack_from('<I', buf, cig_at)[0]
+    if (first & 15) != 4 or (first >> 4) != l_seq:
+        return None, None
+    p = aux_at
+    while p + 3 <= end:
+        tag, typ = buf[p:p + 2], buf[p + 2]
+        q = p + 3
+        if typ in _INT_FMT:
+            q += _INT_FMT[typ][1]
+        elif typ == 65:
+            q += 1
+        elif typ == 102:
+            q += 4
+        elif typ in (90, 72):
+            q = buf.index(b'\0', q) + 1
+        elif typ == 66:
+            sub = buf[q]
+            cnt = struct.unpack_from('<I', buf, q + 1)[0]
+            w = 4 if sub == 102 else _INT_FMT[sub][1]
+            if tag == b'CG':
+                if sub in (ord('I'), ord('i')) and n_cig <= cnt < (1 << 29):
+                    return struct.unpack_from('<%dI' % cnt, buf, q + 5), (p, q + 5 + w * cnt)
+                return None, None
+            q += 5 + w * cnt
+        else:
+            raise ValueError('bad aux type byte %d' % typ)
+        if tag == b'CG':
+            return None, None                   # a CG tag of another type is left alone
+        p = q
+    return None, None
+
+
+def _aux_fields(buf, p, end, skip=None):
+    """Decode all aux fields of one record into SAM text fields (`skip` = byte range of a field to leave out)."""
     out = []
     while p < end:
+        if skip is not None and p == skip[0]:
+            p = skip[1]
+            continue
         tag = buf[p:p + 2].decode('ascii')
         typ = buf[p + 2]
         p += 3
@@ -252,10 +296,14 @@ def iter_bam_records(path):
         q += (l_seq + 1) // 2
         qual_at = q
         q += l_seq
-        aux = _aux_fields(buf, q, rec_end)
+        real_cigar, cg_field = _real_cigar_from_cg(buf, q, rec_end, n_cig, cig_at, l_seq, ref_id, pos)
+        aux = _aux_fields(buf, q, rec_end, cg_field)
 
-        def mandatory():
-            if n_cig:
+        def mandatory(n_cig=n_cig, cig_at=cig_at, real_cigar=real_cigar, seq_at=seq_at, qual_at=qual_at, l_seq=l_seq,
+                      ref_id=ref_id, next_id=next_id, qname=qname, flag=flag, pos=pos, mapq=mapq, next_pos=next_pos, tlen=tlen):
+            if real_cigar is not None:
+                cigar = ''.join('%d%s' % (o >> 4, 'MIDNSHP=X'[o & 15]) for o in real_cigar)
+            elif n_cig:
                 ops = struct.unpack_from('<%dI' % n_cig, buf, cig_at)
                 cigar = ''.join('%d%s' % (o >> 4, 'MIDNSHP=X'[o & 15]) for o in ops)
             else:

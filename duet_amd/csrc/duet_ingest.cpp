@@ -449,6 +449,30 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
         const size_t name_len = l_name ? l_name - 1 : 0;
         q += l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
         if (q > end) return unsupported(g, "corrupt BAM record");
+        // SAMv1 section 4.2.2: a CIGAR of more than 65535 operations is stored as the placeholder <l_seq>S<ref_len>N with
+        // the real operations in a CG:B:I tag; htslib -- hence the `samtools view` text the reference parses -- moves
+        // them back on reading and drops the tag, when the record is placed, its first stored operation soft-clips the
+        // whole read and the (first) CG tag is a B array of I / i with at least n_cigar_op values.
+        size_t cg_lo = 0, cg_hi = 0, cig_at = p + 36 + l_name;
+        uint32_t n_ops = n_cig;
+        if (n_cig && (int32_t)u32(p + 4) >= 0 && (int32_t)u32(p + 8) >= 0) {
+            const uint32_t first = u32(cig_at);
+            if ((first & 15u) == 4u && (first >> 4) == l_seq) {
+                size_t a = q;
+                while (a < end) {
+                    Aux x;
+                    if (!aux_step(b, a, end, x)) return unsupported(g, "corrupt aux field");
+                    if (x.tag[0] == 'C' && x.tag[1] == 'G') {
+                        if (x.type == 'B' && (b[x.val_off] == 'I' || b[x.val_off] == 'i')) {
+                            const uint32_t cnt = u32(x.val_off + 1);
+                            if (cnt >= n_cig && cnt < (1u << 29)) { cg_lo = a; cg_hi = x.next; cig_at = x.val_off + 5; n_ops = cnt; }
+                        }
+                        break;
+                    }
+                    a = x.next;
+                }
+            }
+        }
         if (g->extract) {
             // SVIM-mode signatures: insertions / deletions of at least min_sv_size inside the alignment's CIGAR
             // (primary and supplementary alignments with MAPQ >= min_mapq), and the alignment's span for the depth
@@ -456,8 +480,8 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
             const int32_t pos0 = (int32_t)u32(p + 8);
             if (!(flag & 0x104) && mapq >= g->min_mapq && pos0 >= 0) {
                 uint64_t ref = (uint64_t)pos0;
-                const size_t cg = p + 36 + l_name;
-                for (unsigned i = 0; i < n_cig; ++i) {
+                const size_t cg = cig_at;
+                for (uint32_t i = 0; i < n_ops; ++i) {
                     const uint32_t v = u32(cg + 4 * (size_t)i), op = v & 15u, len = v >> 4;
                     if (op == 1 || op == 2) {
                         if (len >= g->min_sv_size && ref < 0xFFFFFFFEull) {
@@ -486,6 +510,7 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
         Aux last[3];
         int n_aux = 0;
         while (q < end) {
+            if (cg_hi && q == cg_lo) { q = cg_hi; continue; }       // the CG tag is not printed (see above)
             Aux a;
             if (!aux_step(b, q, end, a)) return unsupported(g, "corrupt aux field");
             last[0] = last[1]; last[1] = last[2]; last[2] = a;
