@@ -263,6 +263,39 @@ def _aux_fields(buf, p, end, skip=None):
     return out
 
 
+def read_refs(path):
+    """The reference list of a BAM's header, [(name, length)], decompressing only as many BGZF members as it spans."""
+    with open(path, 'rb') as f:
+        blob = f.read(1 << 22)
+    buf, pos = b'', 0
+
+    def need(n):
+        nonlocal buf, pos
+        while len(buf) < n and pos < len(blob):
+            d = zlib.decompressobj(31)
+            buf += d.decompress(blob[pos:]) + d.flush()
+            pos = len(blob) - len(d.unused_data)
+        return len(buf) >= n
+
+    if not need(12) or buf[:4] != b'BAM\1':
+        return []
+    p = 8 + struct.unpack_from('<I', buf, 4)[0]
+    if not need(p + 4):
+        return []
+    n_ref = struct.unpack_from('<I', buf, p)[0]
+    p += 4
+    refs = []
+    for _ in range(n_ref):
+        if not need(p + 4):
+            break
+        l_name = struct.unpack_from('<I', buf, p)[0]
+        if not need(p + 8 + l_name):
+            break
+        refs.append((buf[p + 4:p + 4 + l_name - 1].decode('ascii'), struct.unpack_from('<I', buf, p + 4 + l_name)[0]))
+        p += 8 + l_name
+    return refs
+
+
 def iter_bam_records(path):
     """Yield (qname, sam_fields list[str]) per alignment, fields as `samtools view` prints them."""
     with open(path, 'rb') as f:

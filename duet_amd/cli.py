@@ -15,7 +15,17 @@ _BAR = '*' * 25
 
 
 def pipeline(a):
-    """(callable, arguments) per stage, in upstream's fixed order: SNP call, SV call, SNP phase, SV phase."""
+    """(callable, arguments) per stage, in upstream's fixed order: SNP call, SV call, SNP phase, SV phase.
+    `-b svim-gpu` (additive): no external SV caller -- signatures, `--cluster_max_distance` clustering and phasing all run on
+    the GPU from the haplotagged BAMs (duet_amd/svim_mode.py)."""
+    if a.sv_caller == 'svim-gpu':
+        from duet_amd.svim_mode import sv_phasing_from_bams
+        return (
+            (stages.snp_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.min_allele_frequency, a.thread, a.include_all_ctgs)),
+            (stages.snp_phasing, (a.OUTPUT, a.REFERENCE, a.BAM, a.thread)),
+            (sv_phasing_from_bams, (a.OUTPUT, a.sv_min_size, a.min_support_read, a.thread, a.include_all_ctgs,
+                                    a.cluster_max_distance, a.device)),
+        )
     return (
         (stages.snp_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.min_allele_frequency, a.thread, a.include_all_ctgs)),
         (stages.sv_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.cluster_max_distance, a.sv_min_size, a.thread, a.sv_caller,

@@ -436,6 +436,11 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     std::vector<uint64_t> &tags = g->tags[contig];
     struct Pend { const char *name; uint32_t len; uint8_t type; uint32_t pos, span; };
     std::vector<Pend> pend;
+    // split reads (SVIM mode): the kept alignments of one read name are its segments; in read orientation a segment covers
+    // [qs, qe) (qs = leading clip, or the trailing clip of a reverse alignment) and [rs, re) on the reference
+    struct Seg { const char *name; uint32_t len; uint64_t qs, qe, rs, re; uint32_t line; bool rev; };
+    std::vector<Seg> segs;
+    uint32_t line_no = 0;
     std::vector<int64_t> dep;
     while (p + 4 <= n) {
         const size_t bs = u32(p), end = p + 4 + bs;
@@ -478,9 +483,34 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
             // (primary and supplementary alignments with MAPQ >= min_mapq), and the alignment's span for the depth
             const unsigned flag = b[p + 18] | (b[p + 19] << 8), mapq = b[p + 13];
             const int32_t pos0 = (int32_t)u32(p + 8);
-            if (!(flag & 0x104) && mapq >= g->min_mapq && pos0 >= 0) {
+            if (!(flag & 0x104) && mapq >= g->min_mapq && pos0 >= 0 && n_ops) {
                 uint64_t ref = (uint64_t)pos0;
                 const size_t cg = cig_at;
+                {
+                    uint64_t lead = 0, trail = 0, aligned = 0;
+                    uint32_t i = 0;
+                    for (; i < n_ops; ++i) {
+                        const uint32_t v = u32(cg + 4 * (size_t)i), op = v & 15u;
+                        if (op != 4 && op != 5) break;
+                        lead += v >> 4;
+                    }
+                    for (uint32_t j = n_ops; j > 0; --j) {
+                        const uint32_t v = u32(cg + 4 * (size_t)(j - 1)), op = v & 15u;
+                        if (op != 4 && op != 5) break;
+                        trail += v >> 4;
+                    }
+                    uint64_t rlen = 0;
+                    for (uint32_t k = 0; k < n_ops; ++k) {
+                        const uint32_t v = u32(cg + 4 * (size_t)k), op = v & 15u;
+                        if (op == 0 || op == 1 || op == 7 || op == 8) aligned += v >> 4;
+                        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += v >> 4;
+                    }
+                    if (aligned) {
+                        const bool rev = (flag & 0x10) != 0;
+                        const uint64_t qs = rev ? trail : lead;
+                        segs.push_back({name, (uint32_t)name_len, qs, qs + aligned, (uint64_t)pos0, (uint64_t)pos0 + rlen, line_no, rev});
+                    }
+                }
                 for (uint32_t i = 0; i < n_ops; ++i) {
                     const uint32_t v = u32(cg + 4 * (size_t)i), op = v & 15u, len = v >> 4;
                     if (op == 1 || op == 2) {
@@ -505,6 +535,7 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
                 }
             }
         }
+        ++line_no;
         // the last three aux fields are the last three whitespace tokens of the text line -- provided there
         // are at least three and none of them contains whitespace
         Aux last[3];
@@ -558,6 +589,42 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
             if (added) tags.push_back(word); else tags[idx] = word;      // later lines win (:29)
         }
         p = end;
+    }
+    if (g->extract && !segs.empty()) {
+        // split-read marks (oracle/svim_oracle.py, SVIM_inter.py's insertion / deletion cases): reads in order of first
+        // appearance, their segments sorted by (qs, qe, line); consecutive segments on one strand whose gaps on the read
+        // and on the reference differ by at least min_sv_size
+        std::unordered_map<std::string, uint32_t> group_of;
+        std::vector<std::vector<uint32_t>> groups;
+        for (uint32_t i = 0; i < segs.size(); ++i) {
+            auto it = group_of.emplace(std::string(segs[i].name, segs[i].len), (uint32_t)groups.size());
+            if (it.second) groups.emplace_back();
+            groups[it.first->second].push_back(i);
+        }
+        const int64_t tol = 5, max_del = 100000, min_sv = (int64_t)g->min_sv_size;
+        for (auto &gr : groups) {
+            if (gr.size() < 2) continue;
+            std::sort(gr.begin(), gr.end(), [&](uint32_t x, uint32_t y) {
+                const Seg &a = segs[x], &c = segs[y];
+                if (a.qs != c.qs) return a.qs < c.qs;
+                if (a.qe != c.qe) return a.qe < c.qe;
+                return a.line < c.line;
+            });
+            for (size_t i = 0; i + 1 < gr.size(); ++i) {
+                const Seg &a = segs[gr[i]], &c = segs[gr[i + 1]];
+                if (a.rev != c.rev) continue;
+                const int64_t dread = (int64_t)c.qs - (int64_t)a.qe;
+                const int64_t dref = a.rev ? (int64_t)a.rs - (int64_t)c.re : (int64_t)c.rs - (int64_t)a.re;
+                if (dread < -tol || dref < -tol) continue;
+                const int64_t dev = dread - dref;
+                const uint64_t anchor = a.rev ? c.re : a.re;
+                if (anchor >= 0xFFFFFFFEull) continue;
+                if (dev >= min_sv && dev <= 0xFFFFFFFFll)
+                    pend.push_back({a.name, a.len, 1, (uint32_t)anchor + 1u, (uint32_t)dev});
+                else if (-dev >= min_sv && -dev <= max_del)
+                    pend.push_back({a.name, a.len, 0, (uint32_t)anchor + 1u, (uint32_t)(-dev)});
+            }
+        }
     }
     if (g->extract) {
         for (const Pend &m : pend) {

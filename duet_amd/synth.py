@@ -494,10 +494,12 @@ def sam_lines(c):
     return out
 
 
-def svim_sam_lines(c, seed, min_sv=40, pos_jitter=15, len_jitter_pct=4):
+def svim_sam_lines(c, seed, min_sv=40, pos_jitter=15, len_jitter_pct=4, split_every=7):
     """`samtools view` style text for contig c in which the SV evidence sits INSIDE the alignments (SVIM mode): the
     first line of every read that supports candidates carries one CIGAR insertion / deletion per supported INS / DEL
-    candidate (jittered position and length), the other lines are plain matches.  Tags as in sam_lines()."""
+    candidate (jittered position and length), the other lines are plain matches.  Tags as in sam_lines().
+    Every `split_every`-th INS / DEL candidate also gets one extra SPLIT read (two lines: primary + supplementary
+    alignment, forward and reverse strand alternating) whose segments leave the event between them."""
     rng = SplitMix(0x51A70000 + seed)
     names = c.names_of(c.line_name_id)
     L = len(names)
@@ -547,6 +549,33 @@ def svim_sam_lines(c, seed, min_sv=40, pos_jitter=15, len_jitter_pct=4):
         if c.line_tagged[i]:
             core += '\tHP:i:%d\tPC:i:%d\tPS:i:%d' % (int(c.line_hap[i]), int(c.line_pc[i]), int(c.line_ps[i]))
         out.append(core)
+    if split_every:
+        k = 0
+        for j in range(C):
+            t = c.cand_svtype[j]
+            ln = abs(int(c.cand_svlen[j])) if int(c.cand_svlen[j]) > -(1 << 61) else 0
+            p0 = int(c.cand_pos[j])
+            if t not in ('INS', 'DEL') or ln < min_sv or p0 < 1000:
+                continue
+            k += 1
+            if k % split_every:
+                continue
+            name = c.name_of(0x40000000 + j)
+            rev = (k // split_every) % 2 == 1
+            left_len, right_len = 500 + j % 40, 400 + j % 30
+            gap_read = ln if t == 'INS' else 0              # bases of the read between the two segments
+            right_pos = p0 + (ln if t == 'DEL' else 0)       # 0-based start of the right segment = p0 (+ deletion)
+            total = left_len + gap_read + right_len
+            if not rev:
+                left = '%dM%dS' % (left_len, total - left_len)
+                right = '%dH%dM' % (left_len + gap_read, right_len)
+            else:                                          # reverse strand: SAM shows the reverse complement
+                left = '%dM%dS' % (left_len, total - left_len)
+                right = '%dS%dM' % (left_len + gap_read, right_len)
+            tag = '\tHP:i:%d\tPC:i:%d\tPS:i:%d' % (1 + j % 2, 50 + j % 900, (p0 // 500000) * 500000 + 17) if j % 3 else ''
+            fl = 16 if rev else 0
+            out.append('%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*\tNM:i:1%s' % (name, fl, c.spelled, p0 - left_len + 1, left, tag))
+            out.append('%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*\tNM:i:2%s' % (name, fl | 2048, c.spelled, right_pos + 1, right, tag))
     return out
 
 

@@ -39,7 +39,8 @@ def build_parser():
                     help='call variants on all contigs, otherwise call chr{1..22,X,Y} [%(default)s]')
     ap.add_argument('-b', '--sv_caller', type=str, default='cutesv',
                     help='choose the base SV caller from cuteSV ("cutesv"), Sniffles (sniffles), or SVIM ("svim") '
-                         '[%(default)s]')
+                         '[%(default)s]; "svim-gpu" clusters the SV marks with --cluster_max_distance on the GPU instead of '
+                         'running svim')
     ap.add_argument('--device', type=int, default=0, help='HIP device index for SV phasing [%(default)s]')
     ap.add_argument('--gpus', type=int, default=1,
                     help='number of GPUs for SV phasing: contigs are sharded over them, one process per GPU [%(default)s]')

@@ -5,15 +5,24 @@ pipeline built from it (BAM text -> raw SV marks -> stage A0 -> adapter -> step 
 Parity status: UNPINNED against the reference.  The reference delegates signature extraction and clustering to the
 external `svim alignment` binary (src/duet/sv_calling.py:13-15; svim 1.4.2, README.md:31,42), whose source is not under
 /root/reference.  This file is the normative text of the repository's own deterministic rule, modelled on the
-intra-alignment part of SVIM (SVIM_intra.py, analyze_cigar_indel): large insertions and deletions inside one alignment.
-Split-read (inter-alignment) signatures are not part of it.
+intra-alignment part of SVIM (SVIM_intra.py, analyze_cigar_indel): large insertions and deletions inside one alignment,
+and on the insertion / deletion part of its inter-alignment analysis (SVIM_inter.py, analyze_read_segments): a read
+whose consecutive segments (primary + supplementary alignments) leave a gap on the read or on the reference.
 
 Rule, per `samtools view` text line of a contig's haplotagged BAM:
   * skipped: unmapped (flag 0x4), secondary (0x100), MAPQ < min_mapq (20);
   * walking the CIGAR from POS: M/=/X/N/D advance the reference; every I or D of at least min_sv_size (40) bases is
     one mark -- type INS=1 / DEL=0, pos = 1-based reference position where it starts, span = its length, read = the
     line's read name;
-  * depth[b] = number of kept alignments [POS-1, end) that contain b * bin + bin // 2 (0-based), bin = 1000.
+  * depth[b] = number of kept alignments [POS-1, end) that contain b * bin + bin // 2 (0-based), bin = 1000;
+  * split reads: the kept alignments of one read name (in one contig's file) are its segments.  In read orientation a
+    segment covers [qs, qe): qs = its leading clip (S or H) -- its TRAILING clip when the alignment is reverse (flag
+    0x10) --, qe = qs + the bases it aligns (M, I, =, X).  Segments sorted by (qs, qe, line order); for consecutive
+    segments a, b on the same strand: dread = b.qs - a.qe; dref = b.start - a.end (forward) or a.start - b.end
+    (reverse); both must be >= -5 (overlap tolerance); dev = dread - dref; the event sits at the reference end of the
+    left segment (a.end forward, b.end reverse), pos = that + 1: dev >= min_sv_size -> INS of span dev;
+    -100000 <= dev <= -min_sv_size -> DEL of span -dev.  These marks follow the contig's CIGAR marks, reads in order
+    of first appearance.
 The tag of a mark's read is looked up in the contig's tag table exactly like step E/F does (ef_oracle.tags_from_sam_text).
 """
 
@@ -27,12 +36,17 @@ from oracle import ef_oracle
 _CIG = re.compile(r'(\d+)([MIDNSHP=X])')
 
 
+SEG_TOL = 5
+SPLIT_MAX_DEL = 100000
+
+
 def extract_from_sam_text(text, min_sv_size=40, min_mapq=20, depth_bin=1000):
     """-> (marks [(type, pos, span, read name)], depth list[int])."""
     marks = []
     diff = {}
     top = 0
-    for line in text.split('\n')[:-1]:
+    segs = {}                                           # read name -> [(qs, qe, line index, start, end, reverse)]
+    for li, line in enumerate(text.split('\n')[:-1]):
         f = line.split('\t')
         flag, pos, mapq, cigar = int(f[1]), int(f[3]), int(f[4]), f[5]
         if flag & 0x104 or mapq < min_mapq or pos < 1 or cigar == '*':
@@ -40,8 +54,23 @@ def extract_from_sam_text(text, min_sv_size=40, min_mapq=20, depth_bin=1000):
                 pass                                    # no CIGAR: no marks, zero-length span, no depth
             continue
         ref = pos - 1
-        for n, op in _CIG.findall(cigar):
-            n = int(n)
+        ops = [(int(n), op) for n, op in _CIG.findall(cigar)]
+        lead = trail = 0
+        for n, op in ops:
+            if op not in 'SH':
+                break
+            lead += n
+        for n, op in reversed(ops):
+            if op not in 'SH':
+                break
+            trail += n
+        aligned = sum(n for n, op in ops if op in 'MI=X')
+        ref_len = sum(n for n, op in ops if op in 'MDN=X')
+        if aligned:
+            rev = bool(flag & 0x10)
+            qs = trail if rev else lead
+            segs.setdefault(f[0], []).append((qs, qs + aligned, li, pos - 1, pos - 1 + ref_len, rev))
+        for n, op in ops:
             if op in 'ID':
                 if n >= min_sv_size:
                     marks.append((1 if op == 'I' else 0, ref + 1, n, f[0]))
@@ -57,6 +86,21 @@ def extract_from_sam_text(text, min_sv_size=40, min_mapq=20, depth_bin=1000):
                 diff[lo] = diff.get(lo, 0) + 1
                 diff[hi] = diff.get(hi, 0) - 1
                 top = max(top, hi)
+    for name, sg in segs.items():                       # dict order = first appearance
+        sg.sort()
+        for a, b in zip(sg, sg[1:]):
+            if a[5] != b[5]:
+                continue
+            dread = b[0] - a[1]
+            dref = (a[3] - b[4]) if a[5] else (b[3] - a[4])
+            if dread < -SEG_TOL or dref < -SEG_TOL:
+                continue
+            dev = dread - dref
+            anchor = b[4] if a[5] else a[4]
+            if dev >= min_sv_size:
+                marks.append((1, anchor + 1, dev, name))
+            elif min_sv_size <= -dev <= SPLIT_MAX_DEL:
+                marks.append((0, anchor + 1, -dev, name))
     depth, run = [], 0
     for b in range(top):
         run += diff.get(b, 0)

@@ -60,3 +60,17 @@ def test_filters(tmp_path):
     assert got['type'].tolist() == [1, 0, 1] and got['span'].tolist() == [50, 40, 41]
     assert got['read'].tolist() == [0, 0xFFFFFFFF, 0xFFFFFFFF]
     ing.close()
+
+
+def test_header_of_the_svim_gpu_mode_comes_from_the_bam_reference_lists(tmp_path):
+    from duet_amd import bamio, svim_mode
+    d = tmp_path / 'snp_phasing'
+    d.mkdir()
+    line = ['a\t0\t%s\t1000\t60\t100M\t*\t0\t0\t*\t*\tNM:i:1']
+    bamio.write_bam_from_sam_lines(str(d / 'chr2.bam'), [('chr1', 249250621), ('chr2', 243199373)], [line[0] % 'chr2'])
+    bamio.write_bam_from_sam_lines(str(d / 'X.bam'), [('X', 155270560)], [line[0] % 'X'])
+    assert bamio.read_refs(str(d / 'chr2.bam')) == [('chr1', 249250621), ('chr2', 243199373)]
+    head = svim_mode.header_text(str(tmp_path), init_chrom_list(False, str(tmp_path)))
+    assert head.count('##contig=') == 2
+    assert head.index('##contig=<ID=chr2,length=243199373>') < head.index('##contig=<ID=X,length=155270560>')
+    assert head.endswith('FORMAT\tVALUE\n')
