@@ -24,7 +24,7 @@ KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
 EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
            'duet_ctx_set_profiling', 'duet_ctx_set_debug', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
            'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_rows_run_device',
-           'duet_ef_rows_run_host')
+           'duet_ef_rows_run_host', 'duet_eval_run_host')
 
 
 class EfProblem(ctypes.Structure):
@@ -71,6 +71,17 @@ class RowsProblem(ctypes.Structure):
                 ('n_chrom_texts', ctypes.c_uint32), ('max_pos', ctypes.c_uint32), ('pool', ctypes.c_void_p),
                 ('pool_bytes', ctypes.c_uint64), ('str_off', ctypes.c_void_p), ('cand_off', ctypes.c_void_p),
                 ('mark_read', ctypes.c_void_p), ('read_tag', ctypes.c_void_p)]
+
+
+class EvalProblem(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ('n_base', 'n_calls', 'n_groups', 'n_keys', 'n_base_uid', 'n_call_uid', 'refdist',
+                                               'reserved')] + [('ratio', ctypes.c_double)] + \
+               [(n, ctypes.c_void_p) for n in ('base_off', 'base_pos', 'base_len', 'base_uid', 'base_hp', 'call_key', 'call_pos',
+                                               'call_len', 'call_uid', 'call_group', 'call_hp')]
+
+
+class EvalCounts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ('call_tp', 'base_tp', 'call_gt', 'base_gt', 'call_hp', 'base_hp')]
 
 
 class DuetLibraryError(RuntimeError):
@@ -120,6 +131,7 @@ def load():
                                          ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
     lib.duet_ef_rows_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfProblem), ctypes.POINTER(RowsProblem), ctypes.c_void_p,
                                           ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+    lib.duet_eval_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(EvalProblem), ctypes.POINTER(EvalCounts)]
     lib.duet_svim_phase_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(SvimProblem), ctypes.POINTER(ClusterResult),
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
     _lib = lib
@@ -270,6 +282,26 @@ class Context(object):
         N = n.value
         return dict(order=out['order'][:M], cand_off=out['cand_off'][:N + 1], cand_contig=out['cand_contig'][:N],
                     cand_type=out['cand_type'][:N], cand_pos=out['cand_pos'][:N], cand_span=out['cand_span'][:N])
+
+    def eval_counts(self, arrays, refdist, ratio):
+        """duet_eval_run_host: `arrays` = dict of the flat host arrays (duet_amd/evaluation.py: flatten) -> EvalCounts."""
+        p = EvalProblem()
+        keep = {}
+        for name, dt in (('base_off', np.uint32), ('base_pos', np.uint32), ('base_len', np.uint32), ('base_uid', np.uint32),
+                         ('base_hp', np.uint8), ('call_key', np.uint32), ('call_pos', np.uint32), ('call_len', np.uint32),
+                         ('call_uid', np.uint32), ('call_group', np.uint32), ('call_hp', np.uint8)):
+            keep[name] = np.ascontiguousarray(arrays[name], dtype=dt)
+            setattr(p, name, keep[name].ctypes.data if keep[name].size else None)
+        p.n_base, p.n_calls = len(keep['base_pos']), len(keep['call_pos'])
+        p.n_keys, p.n_groups = len(keep['base_off']) - 1, int(arrays['n_groups'])
+        p.n_base_uid, p.n_call_uid = int(arrays['n_base_uid']), int(arrays['n_call_uid'])
+        p.refdist, p.ratio = clamp_u32(refdist), float(ratio)
+        out = EvalCounts()
+        rc = self.lib.duet_eval_run_host(self.handle, ctypes.byref(p), ctypes.byref(out))
+        del keep
+        if rc:
+            self._raise(rc)
+        return out
 
     def seed_ps(self, contig, cap=1 << 20):
         out = np.zeros(cap, dtype=np.uint32)

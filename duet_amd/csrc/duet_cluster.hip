@@ -14,11 +14,13 @@
 //                  change or centre gap > part_gap), a partition there and every part_max marks after -> partition ids
 //                  and the partition start list
 //   cl_classes     work lists by partition size (<= 8 / 16 / 32 / 64 / 128 marks)
-//   agglomeration  per size class, GROUP lanes per partition (cl_agg_*): clusters read off the threshold graph where that is
-//                  provably what average linkage produces (see the comment above fast_unit); what that cannot settle
-//                  gets the exact binary64 average linkage (nearest-neighbour cache per row) component by component in
-//                  the same wave; every mark is written to its place in the partition's output (order[], and in the
-//                  fused pipeline its read index), every cluster head gets rank/end/means
+//   fast pass      per size class, GROUP lanes per partition: clusters read off the threshold graph where that is
+//                  provably what average linkage produces (see the comment above fast_unit); what it cannot settle
+//                  goes, component by component, on work lists
+//   exact pass     binary64 average linkage for the listed components (nearest-neighbour cache per row)
+//   rank pass      finishes the partitions that had listed components
+//                  fast and rank passes write each mark to its place in the partition's output (order[], and in the
+//                  fused pipeline its read index) and leave, per cluster head, rank/end/means
 //   scan + cl_emit clusters per partition -> candidate bases; the cluster heads write cand_*[]
 //
 // Bit-exactness vs the oracle: what is emitted depends only on the final clusters; the exact pass evaluates the same
@@ -69,6 +71,8 @@ struct ClParams {
     uint32_t sv_depth_bin;
     uint32_t *sv_mark_out, *sv_svread, *sv_refread;
     uint8_t *sv_gt;
+    uint8_t *label8;                                  // [M] per sorted position: its cluster's smallest member (row inside the partition)
+    uint8_t *comp8;                                   // [M] rows left to the exact pass: smallest row of their component; else 0xFF
     uint32_t *e_info, *e_pos, *e_span;                // [M] per sorted position: rank | end << 8 | cluster << 16 | head << 24; head means
     uint32_t *pc;                                     // [P] clusters per partition
     const uint32_t *cbase;                            // [P] first candidate of each partition
@@ -176,9 +180,10 @@ __device__ __forceinline__ PartSum part_shfl_up(const PartSum &v, int d)
 {
     return PartSum{(uint32_t)__shfl_up((int)v.f, d, 64), (uint32_t)__shfl_up((int)v.l, d, 64), (uint32_t)__shfl_up((int)v.s, d, 64)};
 }
-// inclusive scan over the 256 threads of a block; returns the thread's EXCLUSIVE prefix (everything before it in the block)
-// and leaves the block total in s_w[4]
-__device__ __forceinline__ PartSum part_block_exscan(const PartSum &mine, uint32_t pm, PartSum *s_w /* [5] */)
+// scan over the NT threads of a block; returns the thread's EXCLUSIVE prefix (everything before it in the block) and leaves
+// the block total in s_w[NT / 64]
+template <int NT>
+__device__ __forceinline__ PartSum part_block_exscan(const PartSum &mine, uint32_t pm, PartSum *s_w /* [NT / 64 + 1] */)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     PartSum x = mine;
@@ -191,17 +196,17 @@ __device__ __forceinline__ PartSum part_block_exscan(const PartSum &mine, uint32
     __syncthreads();
     PartSum before{kNoHead, 0, 0};
     for (uint32_t w = 0; w < wave; ++w) before = part_combine(before, s_w[w], pm);
-    PartSum prev = part_shfl_up(x, 1);
+    const PartSum prev = part_shfl_up(x, 1);
     if (lane > 0) before = part_combine(before, prev, pm);
-    if (tid == kScanThreads - 1) s_w[4] = part_combine(before, mine, pm);
+    if (tid == NT - 1) s_w[NT / 64] = part_combine(before, mine, pm);
     return before;
 }
 
-__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero5)
+__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero14)
 {
-    __shared__ PartSum s_w[5];
+    __shared__ PartSum s_w[kScanThreads / 64 + 1];
     const uint32_t tid = threadIdx.x;
-    if (zero5 && blockIdx.x == 0 && tid < 5) zero5[tid] = 0;            // the size-class counters of cl_classes
+    if (zero14 && blockIdx.x == 0 && tid < 14) zero14[tid] = 0;         // the work-list counters of the kernels that follow
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     PartSum acc{kNoHead, 0, 0};
 #pragma unroll
@@ -209,28 +214,25 @@ __global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead in, u
         const uint32_t i = base + j;
         if (i < n && (i == 0 || in(i) != 0u)) acc = part_combine(acc, PartSum{i, i, 0}, pm);
     }
-    (void)part_block_exscan(acc, pm, s_w);
+    (void)part_block_exscan<kScanThreads>(acc, pm, s_w);
     __syncthreads();
-    if (tid == 0) tiles[blockIdx.x] = s_w[4];
+    if (tid == 0) tiles[blockIdx.x] = s_w[kScanThreads / 64];
 }
 
-// more tiles than a block wants to combine by itself: exclusive scan of the tile summaries, one block
-__global__ __launch_bounds__(kScanThreads) void part_spine(PartSum *tiles, uint32_t nb, uint32_t pm)
+// more tiles than a block wants to combine by itself: exclusive scan of the tile summaries by ONE block -- every thread
+// folds a contiguous run of them, one block scan over the threads, every thread writes its run's prefixes
+__global__ __launch_bounds__(1024) void part_spine(PartSum *tiles, uint32_t nb, uint32_t pm)
 {
-    __shared__ PartSum s_w[5];
-    __shared__ PartSum s_carry;
+    __shared__ PartSum s_w[1024 / 64 + 1];
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_carry = PartSum{kNoHead, 0, 0};
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < nb; b0 += kScanThreads) {
-        const uint32_t i = b0 + tid;
-        const PartSum mine = i < nb ? tiles[i] : PartSum{kNoHead, 0, 0};
-        const PartSum before = part_block_exscan(mine, pm, s_w);
-        const PartSum carry = s_carry;
-        if (i < nb) tiles[i] = part_combine(carry, before, pm);
-        __syncthreads();
-        if (tid == 0) s_carry = part_combine(carry, s_w[4], pm);
-        __syncthreads();
+    const uint32_t per = (nb + 1023u) / 1024u, lo = min(nb, tid * per), hi = min(nb, lo + per);
+    PartSum acc{kNoHead, 0, 0};
+    for (uint32_t t = lo; t < hi; ++t) acc = part_combine(acc, tiles[t], pm);
+    PartSum run = part_block_exscan<1024>(acc, pm, s_w);
+    for (uint32_t t = lo; t < hi; ++t) {
+        const PartSum mine = tiles[t];
+        tiles[t] = run;
+        run = part_combine(run, mine, pm);
     }
 }
 
@@ -239,7 +241,7 @@ template <bool SELF>
 __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, uint32_t n, uint32_t pm, const PartSum *tiles, uint32_t *pid,
                                                            uint32_t *part_start, uint32_t *n_parts)
 {
-    __shared__ PartSum s_w[5];
+    __shared__ PartSum s_w[kScanThreads / 64 + 1];
     __shared__ PartSum s_c[kScanThreads / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
@@ -267,13 +269,13 @@ __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, ui
     } else {
         carry = tiles[blockIdx.x];
     }
-    PartSum before = part_block_exscan(acc, pm, s_w);       // (synchronises: s_c is visible after it)
+    const PartSum before = part_block_exscan<kScanThreads>(acc, pm, s_w);       // (synchronises: s_c is visible after it)
     if (SELF) {
 #pragma unroll
         for (int w = 0; w < kScanThreads / 64; ++w) carry = part_combine(carry, s_c[w], pm);
     }
-    PartSum st = part_combine(carry, before, pm);
-    // the state before this thread's first element: natural start H (position 0 always is one) and the partitions before it
+    const PartSum st = part_combine(carry, before, pm);
+    // the state in front of this thread's first element: its natural partition's start H and the partitions before H.
     // (st.s counts the natural partitions between the starts of everything before; position 0 is itself a start, so nothing
     // lies in front of the first one)
     uint32_t H = st.f == kNoHead ? 0u : st.l, P = st.f == kNoHead ? 0u : st.s;
@@ -382,7 +384,16 @@ __device__ __forceinline__ void group_argmin(const double (&val)[R], uint32_t su
     for (int r = 1; r < R; ++r) m = val[r] < m ? val[r] : m;
     const uint32_t hi = (uint32_t)__double2hiint(m), lo = (uint32_t)__double2loint(m);
     const uint32_t mh = group_min_u32<GROUP>(hi);
-    const uint32_t ml = group_min_u32<GROUP>(hi == mh ? lo : 0xFFFFFFFFu);
+    uint32_t ml;
+    if (GROUP == 64) {
+        // one group per wave: when a single lane holds the smallest high word (the usual case: two distances share their top
+        // 32 bits only when they agree to 1e-6) its low word is the answer -- one reduction chain instead of two
+        const unsigned long long top = __ballot(hi == mh);
+        if (__popcll(top) == 1) ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)__ffsll((long long)top) - 1);
+        else ml = group_min_u32<GROUP>(hi == mh ? lo : 0xFFFFFFFFu);
+    } else {
+        ml = group_min_u32<GROUP>(hi == mh ? lo : 0xFFFFFFFFu);
+    }
     m = __hiloint2double((int)mh, (int)ml);
     gval = m;
     gcol = kNoCol;
@@ -425,10 +436,10 @@ __device__ __forceinline__ uint3 load_rec(const ClParams &p, uint32_t a)
     return make_uint3(q.x, q.y, 0u);
 }
 
-// One connected component of a partition's threshold graph (or a whole partition), its rows gathered in row order into
-// X.pos / X.span / X.size / X.row by the caller.
+// Work item: one connected component of a partition's threshold graph (list entry = partition, then
+// root row | rows << 8), gathered in row order from the partition through comp8; writes label8 for its rows.
 // NCAP = the most rows a unit can have (<= GROUP * R): with the default part_max of 100 the triangle of a >64-row unit
-// takes 39.6 KB instead of 65 KB.
+// takes 39.6 KB instead of 65 KB, i.e. four wavefronts per CU -- one per SIMD -- instead of two.
 template <int GROUP, int R, int NCAP = GROUP * R>
 struct ExactSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = NCAP;
@@ -437,20 +448,49 @@ struct ExactSmem {
     uint8_t size[SUBS][NMAX], row[SUBS][NMAX];
 };
 
-// Binary64 average linkage over the n rows of X (n may differ between the groups of the wave; a group with n < 2 only keeps
-// the collective operations company).  lab[r] <- the smallest row (index into X) of the cluster that row sl + r * GROUP ends
-// in.  The caller has synchronised after filling X.
-template <int GROUP, int R, int NCAP = GROUP * R>
-__device__ __forceinline__ void exact_core(ExactSmem<GROUP, R, NCAP> &X, uint32_t sub, uint32_t sl, uint32_t n, double max_dist,
-                                           double normalizer, uint32_t (&lab)[R])
+template <int GROUP, int R, bool WHOLE = false, int NCAP = GROUP * R>
+__device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
 {
     static_assert(NCAP <= GROUP * R && NCAP <= 128, "");
     constexpr int NMAX = NCAP;
+    ExactSmem<GROUP, R, NCAP> &X = *reinterpret_cast<ExactSmem<GROUP, R, NCAP> *>(smem);
+    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     double *D = X.d[sub];
     const double inf = __builtin_inf();
     // d(i, j), i < j, in the upper triangle: half the LDS of a square matrix, so twice the waves per CU
     auto tri = [](uint32_t i, uint32_t j) -> uint32_t { return i * (2u * NMAX - i - 1u) / 2u + (j - i - 1u); };
     {
+        const uint32_t li = base + sub;
+        const bool has = li < L;
+        // WHOLE: the list holds partitions (one word each) and the item is the whole partition
+        const uint32_t part = has ? (WHOLE ? list[li] : list[2 * (size_t)li]) : 0u;
+        const uint32_t item = has && !WHOLE ? list[2 * (size_t)li + 1] : 0u;
+        const uint32_t s = has ? p.part_start[part] : 0u;
+        const uint32_t np = has ? p.part_start[part + 1] - s : 0u;       // rows of the partition
+        const uint32_t root = item & 0xFFu, n = WHOLE ? np : (has ? item >> 8 : 0u);     // n = rows of the component
+        __syncthreads();
+        // gather the component's rows, in row order
+        uint32_t filled = 0;
+        uint32_t np_max = np;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) np_max = max(np_max, (uint32_t)__shfl_xor((int)np_max, d, 64));
+        for (uint32_t k0 = 0; k0 < np_max; k0 += GROUP) {
+            const uint32_t row = k0 + sl;
+            const bool mem = row < np && (WHOLE || p.comp8[s + row] == root);
+            const unsigned long long bal = (__ballot(mem) >> (sub * GROUP)) & gm;
+            if (mem) {
+                const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
+                const uint32_t a = mark_at(p, s + row);
+                const uint3 q = load_rec(p, a);
+                X.pos[sub][ci] = q.x;
+                X.span[sub][ci] = q.y;
+                X.size[sub][ci] = 1;
+                X.row[sub][ci] = (uint8_t)row;
+            }
+            filled += (uint32_t)__popcll(bal);
+        }
+        __syncthreads();
         // every unordered pair once: row k takes the columns k+1 .. k+n/2 (mod n); for even n the distance-n/2
         // pairs only from the lower half of the rows
         const uint32_t half = n >> 1;
@@ -463,14 +503,14 @@ __device__ __forceinline__ void exact_core(ExactSmem<GROUP, R, NCAP> &X, uint32_
                 for (uint32_t t = 1; t <= tmax; ++t) {
                     uint32_t j = k + t;
                     j = j >= n ? j - n : j;
-                    const double v = sp_distance(pk, spk, X.pos[sub][j], X.span[sub][j], normalizer);
+                    const double v = sp_distance(pk, spk, X.pos[sub][j], X.span[sub][j], p.normalizer);
                     D[k < j ? tri(k, j) : tri(j, k)] = v;
                 }
             }
         }
         __syncthreads();
         double rmin[R];
-        uint32_t rarg[R];
+        uint32_t rarg[R], lab[R];
         bool alive[R], stale[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -494,7 +534,7 @@ __device__ __forceinline__ void exact_core(ExactSmem<GROUP, R, NCAP> &X, uint32_
             double gval;
             uint32_t g;
             group_argmin<GROUP, R>(cand, sub, gval, g);
-            const bool act = !done && gval <= max_dist && g != kNoCol;      // distances are finite: inf = no pair left
+            const bool act = !done && gval <= p.max_dist && g != kNoCol;      // distances are finite: inf = no pair left
             done = done || !act;
             if (!__ballot(act)) break;
             // the picked row's cache, from its owner lane
@@ -502,7 +542,9 @@ __device__ __forceinline__ void exact_core(ExactSmem<GROUP, R, NCAP> &X, uint32_
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if ((uint32_t)r == g / GROUP) mine = rarg[r] | (stale[r] ? 0x80000000u : 0u);
-            const uint32_t info = __shfl(mine, act ? (int)(sub * GROUP + g % GROUP) : (int)threadIdx.x, 64);
+            // (one group per wave: the owner lane is uniform -- a lane read instead of a trip through the LDS crossbar)
+            const uint32_t info = GROUP == 64 ? (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(g == kNoCol ? 0u : g % GROUP))
+                                              : (uint32_t)__shfl(mine, act ? (int)(sub * GROUP + g % GROUP) : (int)lane, 64);
             const bool do_rescan = act && (info >> 31);
             const bool do_merge = act && !(info >> 31);
             if (__ballot(do_rescan)) {
@@ -559,7 +601,41 @@ __device__ __forceinline__ void exact_core(ExactSmem<GROUP, R, NCAP> &X, uint32_
             }
             __syncthreads();
         }
+        // the component's clusters, named after their smallest row of the partition
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            if (k < n) p.label8[s + X.row[sub][k]] = X.row[sub][lab[r]];
+        }
     }
+}
+
+// components of up to 64 rows, every size class in one launch (largest first).  For small inputs the partitions of more
+// than 64 marks do not go through the fast pass at all: one wavefront would spend ~100 us on one of them there, as long
+// as the exact agglomeration takes, so cl_exact_big<true> takes them whole, on a side stream, while the fast pass handles
+// the rest.  For large inputs there can be very many of them and throughput counts: the fast pass (20 waves per CU
+// instead of 2) settles what it can first, cl_exact_big<false> gets the components it leaves.
+__global__ __launch_bounds__(64) void cl_exact_small(const ClParams p, const uint32_t *lists, const uint32_t *cnts)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 1>)];
+    static_assert(sizeof(ExactSmem<64, 1>) >= sizeof(ExactSmem<32, 1>) && sizeof(ExactSmem<64, 1>) >= sizeof(ExactSmem<16, 1>), "");
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2];
+    const uint32_t b2 = c2, b1 = b2 + (c1 + 1) / 2, b0 = b1 + (c0 + 3) / 4;
+    const size_t M = p.M;
+    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
+        if (vb < b2) exact_unit<64, 1>(p, lists + 2 * M, c2, vb, smem);
+        else if (vb < b1) exact_unit<32, 1>(p, lists + 1 * M, c1, (vb - b2) * 2, smem);
+        else exact_unit<16, 1>(p, lists, c0, (vb - b1) * 4, smem);
+    }
+}
+
+template <bool WHOLE, int NCAP>
+__global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint32_t *list, const uint32_t *count)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 2, NCAP>)];
+    static_assert(sizeof(ExactSmem<64, 2, 100>) <= 40960, "four units per CU");
+    const uint32_t L = *count;
+    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2, WHOLE, NCAP>(p, list, L, vb, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,7 +654,7 @@ __device__ __forceinline__ void exact_core(ExactSmem<GROUP, R, NCAP> &X, uint32_
 // mark's closed neighbourhood as a bit mask, and accepts the partition when no pair falls inside the guard
 // band and every neighbourhood equals the neighbourhood of its smallest member (<=> every component is a
 // clique).  Everything else -- about one partition in a few hundred on SV-like data, nearly all on random data
-// -- gets the exact binary64 agglomeration (exact_core), component by component, in the same wave.  Both paths produce
+// -- gets the exact binary64 agglomeration (exact_unit), component by component.  Both paths produce
 // the oracle's clusters; tests/test_gpu_cluster.py and tools/stress.py cover both.
 
 template <int NW>
@@ -700,7 +776,13 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
     if (sl == 0) p.pc[part] = heads.count();
 }
 
+// work lists the fast pass leaves behind: per size class of the components (<= 16 / 32 / 64 / 128 rows) the
+// components for cl_exact (two words each), per size class of the partitions the partitions for cl_rank
 struct ClWork {
+    uint32_t *comp_list;      // [4][M]
+    uint32_t *comp_count;     // [4]
+    uint32_t *rank_list;      // [kClasses][M]
+    uint32_t *rank_count;     // [kClasses]
     uint32_t *why;            // diagnostics (DUET_CL_DEBUG): why the whole-partition test gave up, or null
 };
 
@@ -755,26 +837,14 @@ struct FastSmem {
     uint8_t atom[SUBS][NMAX];
 };
 
-template <int GROUP, int R, int KA, int NCAP>
-struct UnitSmem {
-    FastSmem<GROUP, R, KA> f;
-    alignas(16) ExactSmem<GROUP, R, NCAP> x;
-};
-
-// one wave's worth of partitions (64 / GROUP of them, list[base ...]) of one size class, from the gathered marks to the
-// per-mark output records: the threshold-graph fast pass and, for the components it cannot settle, the exact binary64
-// agglomeration -- in the same wave, so that a long merge chain only holds up its own wave while the rest of the launch goes on
-// (as separate launches the exact pass was a latency-bound tail behind the whole fast pass: 79 us after 71 us at 1 M marks,
-// 374 us after 1.3 ms at 2e7)
-template <int GROUP, int R, int KA, int NCAP = GROUP * R>
+// one wave's worth of partitions (64 / GROUP of them, list[base ...]) of one size class
+template <int GROUP, int R, int KA>
 __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, const ClWork &work,
                                           unsigned char *smem)
 {
     constexpr int NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
     static_assert(NMAX <= 128 && (R == 1 || (GROUP * R) % 64 == 0 || GROUP * R <= 64), "unsupported shape");
-    UnitSmem<GROUP, R, KA, NCAP> &U = *reinterpret_cast<UnitSmem<GROUP, R, KA, NCAP> *>(smem);
-    FastSmem<GROUP, R, KA> &S = U.f;
-    ExactSmem<GROUP, R, NCAP> &X = U.x;
+    FastSmem<GROUP, R, KA> &S = *reinterpret_cast<FastSmem<GROUP, R, KA> *>(smem);
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     auto group_any = [&](bool x) -> bool { return ((__ballot(x) >> (sub * GROUP)) & gm) != 0ull; };
@@ -1026,8 +1096,8 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
             // Not settled as a whole: settle it component by component.  A row is clean when it and all its
             // neighbours (level 0) have guard-band-free neighbourhoods equal to that of their smallest member: its
             // component is then a clique and one cluster.  The other rows are labelled with the smallest row of their
-            // component (min-label propagation over the neighbourhoods); each such component then gets the exact binary64
-            // agglomeration right here, one after the other, rows gathered in row order.
+            // component (min-label propagation over the neighbourhoods) and handed to cl_exact component by
+            // component; cl_rank finishes the partition once every row has its label.
             const bool todo = has && !solved;
             __syncthreads();
             BitSet<NW> pass;
@@ -1063,7 +1133,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 for (int i = 0; i < NW; ++i) c = c && (N[0][r].w[i] & ~pass.w[i]) == 0ull;
                 clean[r] = c;
                 lab[r] = unfit ? 0u : k;                     // unfit: the masks mean nothing, the partition is one component
-                if (todo && k < n) S.atom[sub][k] = (uint8_t)lab[r];
+                if (todo && k < n) { S.atom[sub][k] = (uint8_t)lab[r]; S.csz[sub][k] = 0; }
             }
             __syncthreads();
             for (;;) {
@@ -1092,112 +1162,148 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                 __syncthreads();
                 if (!__ballot(changed)) break;
             }
-            // the components that are left, smallest root first (one round per component of any group of the wave)
-            BitSet<NW> roots;
-            roots.clear();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (todo && sl + r * GROUP < n && !clean[r]) atomicAdd(&S.csz[sub][lab[r]], 1u);
+            __syncthreads();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t k = sl + r * GROUP;
-                const unsigned long long b = (__ballot(todo && k < n && !clean[r] && lab[r] == k) >> (sub * GROUP)) & gm;
-                roots.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
-            }
-            for (;;) {
-                bool any = false;
-                for (int i = 0; i < NW; ++i) any = any || roots.w[i] != 0ull;
-                if (!__ballot(any)) break;
-                const uint32_t h = any ? roots.first() : 0xFFFFFFu;
-                uint32_t filled = 0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t k = sl + r * GROUP;
-                    const bool mem = any && k < n && !clean[r] && lab[r] == h;
-                    const unsigned long long bal = (__ballot(mem) >> (sub * GROUP)) & gm;
-                    if (mem) {
-                        const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
-                        X.pos[sub][ci] = pk[r];
-                        X.span[sub][ci] = spk[r];
-                        X.size[sub][ci] = 1;
-                        X.row[sub][ci] = (uint8_t)k;
+                if (todo && k < n) {
+                    p.label8[s + k] = clean[r] ? (uint8_t)N[0][r].first() : (uint8_t)0xFF;
+                    p.comp8[s + k] = clean[r] ? (uint8_t)0xFF : (uint8_t)lab[r];
+                    if (!clean[r] && lab[r] == k) {
+                        const uint32_t m = S.csz[sub][k];
+                        const uint32_t hc = m <= 16 ? 0u : (m <= 32 ? 1u : (m <= 64 ? 2u : 3u));
+                        const uint32_t at = atomicAdd(&work.comp_count[hc], 1u);
+                        work.comp_list[(size_t)hc * p.M + 2 * (size_t)at] = part;
+                        work.comp_list[(size_t)hc * p.M + 2 * (size_t)at + 1] = k | (m << 8);
                     }
-                    filled += (uint32_t)__popcll(bal);
                 }
-                __syncthreads();
-                uint32_t lc[R];
-                exact_core<GROUP, R, NCAP>(X, sub, sl, filled, p.max_dist, p.normalizer, lc);
-                // every row's cluster, named after its smallest row of the partition, back to the row's own lane
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t ci = sl + r * GROUP;
-                    if (ci < filled) S.atom[sub][X.row[sub][ci]] = X.row[sub][lc[r]];
-                }
-                __syncthreads();
-                if (any)
-                    for (int i = 0; i < NW; ++i) roots.w[i] &= (h >> 6) == (uint32_t)i ? ~(1ull << (h & 63u)) : ~0ull;
             }
-            // clusters as bit sets: clean rows have theirs (the clique); the others are grouped by label, one round per
-            // cluster head (wave-uniform trip count: ballots inside)
-            uint32_t fin[R];
-            BitSet<NW> left;
-            left.clear();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                const bool dirty = todo && k < n && !clean[r];
-                fin[r] = dirty ? (uint32_t)S.atom[sub][k] : 0xFFFFu;
-                const unsigned long long b = (__ballot(dirty && fin[r] == k) >> (sub * GROUP)) & gm;
-                left.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+            if (todo && sl == 0) {
+                const int rc = size_class(n);
+                work.rank_list[(size_t)rc * p.M + atomicAdd(&work.rank_count[rc], 1u)] = part;
             }
-            for (;;) {
-                bool any = false;
-                for (int i = 0; i < NW; ++i) any = any || left.w[i] != 0ull;
-                if (!__ballot(any)) break;
-                const uint32_t h = any ? left.first() : 0xFFFFFFu;
-                BitSet<NW> mh;
-                mh.clear();
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const unsigned long long b = (__ballot(any && fin[r] == h) >> (sub * GROUP)) & gm;
-                    mh.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (any && fin[r] == h) F[r] = mh;
-                if (any)
-                    for (int i = 0; i < NW; ++i) left.w[i] &= (h >> 6) == (uint32_t)i ? ~(1ull << (h & 63u)) : ~0ull;
-            }
-            solved = solved || todo;
         }
         emit_prep<GROUP, R, NW, NMAX>(p, has && solved, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
     }
 }
 
-// one size class per launch (64 / GROUP partitions per wave)
-template <int GROUP, int R, int KA, int NCAP = GROUP * R>
-__global__ __launch_bounds__(64) void cl_agg_one(const ClParams p, const uint32_t *list, const uint32_t *count, const ClWork work)
+// every size class in one launch, largest partitions first (they are the longest chains): a virtual block is one
+// wave's worth of partitions of one class
+constexpr size_t kFastSmemBytes = sizeof(FastSmem<64, 1, 8>) > sizeof(FastSmem<8, 1, 4>) ? sizeof(FastSmem<64, 1, 8>) : sizeof(FastSmem<8, 1, 4>);
+static_assert(kFastSmemBytes >= sizeof(FastSmem<32, 1, 4>) && kFastSmemBytes >= sizeof(FastSmem<16, 1, 4>), "shared scratch too small");
+
+// one size class per launch: what large inputs use (the fused kernel needs the registers of all five variants at
+// once, which halves the occupancy; with millions of partitions per class there is nothing to gain from fusing)
+template <int GROUP, int R, int KA>
+__global__ __launch_bounds__(64) void cl_fast_one(const ClParams p, const uint32_t *list, const uint32_t *count, const ClWork work)
 {
-    __shared__ __align__(16) unsigned char smem[sizeof(UnitSmem<GROUP, R, KA, NCAP>)];
+    __shared__ __align__(16) unsigned char smem[sizeof(FastSmem<GROUP, R, KA>)];
     const uint32_t L = *count;
     for (uint32_t base = blockIdx.x * (64 / GROUP); base < L; base += gridDim.x * (64 / GROUP))
-        fast_unit<GROUP, R, KA, NCAP>(p, list, L, base, work, smem);
+        fast_unit<GROUP, R, KA>(p, list, L, base, work, smem);
 }
 
-// the three classes of up to 32 marks in one launch, largest partitions first (they are the longest chains): a virtual block
-// is one wave's worth of partitions of one class.  What small inputs use: there the launch and stream latencies of separate
-// launches would dominate.  (The 33..64 and > 64 classes keep launches of their own: their triangles -- 16 and 40 KB of LDS
-// per wave -- would cap the occupancy of every block of a fused kernel.)
-constexpr size_t kSmallSmemBytes = sizeof(UnitSmem<32, 1, 4, 32>) > sizeof(UnitSmem<8, 1, 4, 8>) ? sizeof(UnitSmem<32, 1, 4, 32>) : sizeof(UnitSmem<8, 1, 4, 8>);
-static_assert(kSmallSmemBytes >= sizeof(UnitSmem<16, 1, 4, 16>), "shared scratch too small");
-
-__global__ __launch_bounds__(64, 3) void cl_agg_small(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const ClWork work)
+__global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const ClWork work)
 {
-    __shared__ __align__(16) unsigned char smem[kSmallSmemBytes];
-    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2];
-    const uint32_t b2 = (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3];
+    const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
     const size_t M = p.M;
     for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
-        if (vb < b2) fast_unit<32, 1, 4>(p, lists + 2 * M, c2, vb * 2, work, smem);
+        if (vb < b3) fast_unit<64, 1, 8>(p, lists + 3 * M, c3, vb, work, smem);
+        else if (vb < b2) fast_unit<32, 1, 4>(p, lists + 2 * M, c2, (vb - b3) * 2, work, smem);
         else if (vb < b1) fast_unit<16, 1, 4>(p, lists + 1 * M, c1, (vb - b2) * 4, work, smem);
         else fast_unit<8, 1, 4>(p, lists, c0, (vb - b1) * 8, work, smem);
+    }
+}
+
+// Partitions the fast pass did not settle as a whole, after cl_exact: every row has its label; group the rows by
+// label and finish like the fast pass does.
+template <int GROUP, int R>
+struct RankSmem {
+    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
+    uint2 ps[SUBS][NMAX];
+    uint64_t mask[SUBS][NMAX][NW];
+    unsigned long long sum[SUBS][NMAX][2];
+};
+
+template <int GROUP, int R>
+__device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
+{
+    constexpr int NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
+    RankSmem<GROUP, R> &S = *reinterpret_cast<RankSmem<GROUP, R> *>(smem);
+    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    {
+        const uint32_t li = base + sub;
+        const bool has = li < L;
+        const uint32_t part = has ? list[li] : 0u;
+        const uint32_t s = has ? p.part_start[part] : 0u;
+        const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+        __syncthreads();
+        uint32_t lab[R], mk[R], rd[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            lab[r] = 0xFFFFu;
+            mk[r] = rd[r] = 0;
+            if (k < n) {
+                mk[r] = mark_at(p, s + k);
+                const uint3 q = load_rec(p, mk[r]);
+                S.ps[sub][k] = make_uint2(q.x, q.y);
+                rd[r] = q.z;
+                lab[r] = p.label8[s + k];
+            }
+        }
+        BitSet<NW> heads, F[R];
+        heads.clear();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            F[r].clear();
+            const unsigned long long b = (__ballot(lab[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
+            heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+        }
+        // one round per cluster head of any group of the wave (wave-uniform trip count: ballots inside)
+        BitSet<NW> left = heads;
+        for (;;) {
+            bool any = false;
+            for (int i = 0; i < NW; ++i) any = any || left.w[i] != 0ull;
+            if (!__ballot(any)) break;
+            const uint32_t h = any ? left.first() : 0xFFFFFFu;
+            BitSet<NW> mh;
+            mh.clear();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned long long b = (__ballot(any && lab[r] == h) >> (sub * GROUP)) & gm;
+                mh.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (any && lab[r] == h) F[r] = mh;
+            if (any)
+                for (int i = 0; i < NW; ++i) left.w[i] &= (h >> 6) == (uint32_t)i ? ~(1ull << (h & 63u)) : ~0ull;
+        }
+        emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
+    }
+}
+
+// (the partitions of more than 64 marks -- all of them went to the exact pass -- come straight from their class list)
+__global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const uint32_t *big_list,
+                                                  const uint32_t *big_count)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(RankSmem<64, 2>)];
+    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3], c4 = *big_count;
+    const uint32_t b4 = c4, b3 = b4 + c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    const size_t M = p.M;
+    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
+        if (vb < b4) rank_unit<64, 2>(p, big_list, c4, vb, smem);
+        else if (vb < b3) rank_unit<64, 1>(p, lists + 3 * M, c3, vb - b4, smem);
+        else if (vb < b2) rank_unit<32, 1>(p, lists + 2 * M, c2, (vb - b3) * 2, smem);
+        else if (vb < b1) rank_unit<16, 1>(p, lists + 1 * M, c1, (vb - b2) * 4, smem);
+        else rank_unit<8, 1>(p, lists, c0, (vb - b1) * 8, smem);
     }
 }
 
@@ -1317,7 +1423,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
     uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
     uint32_t *e_info = (uint32_t *)ctx->cl_ws[9].ptr;
-    uint32_t *cbase = (uint32_t *)ctx->cl_ws[13].ptr + (M + 1);      // (the first M + 1 words are spare)
+    uint32_t *cbase = (uint32_t *)ctx->cl_ws[13].ptr + (M + 1);      // (the first M + 1 words hold label8 / comp8)
     uint32_t *pc = (uint32_t *)ctx->cl_ws[10].ptr;
     uint32_t *scal = (uint32_t *)ctx->cl_ws[11].ptr;      // [0] = n_parts
 
@@ -1369,7 +1475,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.sorted = vin;
     p.skeys = kin;
     // partitions: one composite scan straight off the sorted keys -> each position's partition id, the partition start
-    // list and their number (scal[0]); it also zeroes the size-class counters
+    // list and their number (scal[0]); it also zeroes the work-list counters
     {
         const LoadHead heads{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)};
         PartSum *tiles = (PartSum *)tmpA;                         // 3 words per 2048 marks
@@ -1378,7 +1484,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
             hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, tmpB,
                                part_start, scal);
         } else {
-            hipLaunchKernelGGL(part_spine, dim3(1), dim3(kScanThreads), 0, st, tiles, nb_sc, p.part_max);
+            hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
             hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, tmpB,
                                part_start, scal);
         }
@@ -1388,14 +1494,20 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.e_pos = (uint32_t *)kout;                                   // the spare key buffer: 2 x M words
     p.e_span = p.e_pos + M;
     const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
-    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M] partitions by size class
+    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M] partitions by size class, then the work lists
     uint32_t *cnts = scal + 2;
     ClWork work;
+    work.comp_list = lists + (size_t)kClasses * M;               // [4][M]
+    work.rank_list = work.comp_list + 4 * (size_t)M;             // [kClasses][M]
+    work.comp_count = scal + 7;
+    work.rank_count = scal + 11;
     work.why = nullptr;
     if (getenv("DUET_CL_DEBUG")) {
         work.why = scal + 16;
         HIP_TRY(ctx, hipMemsetAsync(work.why, 0, 64, st));
     }
+    p.label8 = (uint8_t *)ctx->cl_ws[13].ptr;
+    p.comp8 = p.label8 + M;
     p.inv_norm = (float)(1.0 / pr->normalizer);
     for (int l = 0; l < 3; ++l) {
         p.t_lo[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 - 1e-5));
@@ -1406,32 +1518,45 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     hipLaunchKernelGGL(cl_classes, dim3((M + 1023) / 1024), dim3(1024), 0, st, p, lists, cnts);
     const uint32_t gridw = M < 32768u ? M : 32768u;
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
-    const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
-    const uint32_t *l0 = lists, *l1 = lists + (size_t)M, *l2 = lists + 2 * (size_t)M, *l3 = lists + 3 * (size_t)M,
-                   *l4 = lists + 4 * (size_t)M;
-    // the size classes agglomerate side by side: the two classes of long chains (> 64 marks: few partitions; 33..64) on side
-    // streams, the rest on the caller's stream -- in one launch for small inputs, largest class first for large ones
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[1], ctx->cl_fork, 0));
+    const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
     if (small) {
-        // (8 atoms at most for the > 64 class here: the linkage over the atoms is serial, m^3 steps of LDS latency)
-        if (cap100) hipLaunchKernelGGL((cl_agg_one<64, 2, 8, 100>), dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p, l4, (const uint32_t *)(cnts + 4), work);
-        else hipLaunchKernelGGL((cl_agg_one<64, 2, 8, 128>), dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p, l4, (const uint32_t *)(cnts + 4), work);
-        hipLaunchKernelGGL((cl_agg_one<64, 1, 8>), dim3(grid), dim3(64), 0, ctx->cl_side[1], p, l3, (const uint32_t *)(cnts + 3), work);
-        hipLaunchKernelGGL(cl_agg_small, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
+        // partitions of more than 64 marks go whole to the exact pass, on a side stream, right away; beside them the fast
+        // pass over the other size classes in one launch
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cap100 ? cl_exact_big<true, 100> : cl_exact_big<true, 128>), dim3(grid < 4096u ? grid : 4096u),
+                           dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+        hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
     } else {
-        if (cap100) hipLaunchKernelGGL((cl_agg_one<64, 2, 16, 100>), dim3(grid), dim3(64), 0, ctx->cl_side[0], p, l4, (const uint32_t *)(cnts + 4), work);
-        else hipLaunchKernelGGL((cl_agg_one<64, 2, 16, 128>), dim3(grid), dim3(64), 0, ctx->cl_side[0], p, l4, (const uint32_t *)(cnts + 4), work);
-        hipLaunchKernelGGL((cl_agg_one<64, 1, 8>), dim3(grid), dim3(64), 0, ctx->cl_side[1], p, l3, (const uint32_t *)(cnts + 3), work);
-        hipLaunchKernelGGL((cl_agg_one<32, 1, 4>), dim3(grid), dim3(64), 0, st, p, l2, (const uint32_t *)(cnts + 2), work);
-        hipLaunchKernelGGL((cl_agg_one<16, 1, 4>), dim3(grid), dim3(64), 0, st, p, l1, (const uint32_t *)(cnts + 1), work);
-        hipLaunchKernelGGL((cl_agg_one<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, l0, (const uint32_t *)(cnts + 0), work);
+        // the side stream takes the partitions of more than 64 marks (few, long chains: a launch of their own would leave most
+        // of the chip idle) and then the components of more than 64 rows they leave; beside them one launch per size class
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+        hipLaunchKernelGGL((cl_fast_one<64, 2, 16>), dim3(grid), dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(lists + 4 * (size_t)M),
+                           (const uint32_t *)(cnts + 4), work);
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], ctx->cl_side[0]));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cap100 ? cl_exact_big<false, 100> : cl_exact_big<false, 128>), dim3(grid < 4096u ? grid : 4096u),
+                           dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(work.comp_list + 3 * (size_t)M),
+                           (const uint32_t *)(work.comp_count + 3));
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+        hipLaunchKernelGGL((cl_fast_one<64, 1, 8>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
+                           (const uint32_t *)(cnts + 3), work);
+        hipLaunchKernelGGL((cl_fast_one<32, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
+                           (const uint32_t *)(cnts + 2), work);
+        hipLaunchKernelGGL((cl_fast_one<16, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
+                           (const uint32_t *)(cnts + 1), work);
+        hipLaunchKernelGGL((cl_fast_one<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), work);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[1], 0));        // cl_exact_small also takes what the >64 class left
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], ctx->cl_side[1]));
+    hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
+                       (const uint32_t *)work.comp_count);
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[1], 0));
+    // ranks: the partitions of more than 64 marks come from their class list (small: all of them) or from the fast pass's
+    // list of unsettled ones
+    hipLaunchKernelGGL(cl_rank_all, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.rank_list,
+                       (const uint32_t *)work.rank_count,
+                       (const uint32_t *)(small ? lists + 4 * (size_t)M : work.rank_list + 4 * (size_t)M),
+                       (const uint32_t *)(small ? cnts + 4 : work.rank_count + 4));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort);       // cbase[part] = its first candidate
     p.cbase = cbase;
@@ -1441,7 +1566,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         uint32_t h[32];
         HIP_TRY(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6]);
+        fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u components %u %u %u %u partitions to rank %u %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
         fprintf(stderr, "[duet_cluster] gave up (no clean level / too many atoms / decision too close): >64: %u %u %u  33..64: %u %u %u  <=32: %u %u %u;  "
                         "not settled by level 0: %u %u %u\n",
                 h[16], h[17], h[18], h[20], h[21], h[22], h[24], h[25], h[26], h[19], h[23], h[27]);

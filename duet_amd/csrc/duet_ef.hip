@@ -604,6 +604,7 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         rec0 = recs[my_lo];
         if (my_lo > b_lo) recp = recs[my_lo - 1];
     }
+    STAMP(1, 4);
     uint32_t prev0 = kEmpty;
     if (my_lo < my_hi && my_lo > b_lo && (uint32_t)recp.x) {
         const uint64_t pe = entry(my_lo - 1, (uint32_t)recp.x - 1, recp);
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
             uint32_t total;
             at = n_lo + block_exscan(mine, tid, s_part, kSortThreads, &total);
             mid_total = total;
+            STAMP(1, 5);
         }
         uint32_t prev_ps = prev0;
         for (uint32_t b = my_lo; b < my_hi; ++b) {
@@ -700,6 +702,7 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         }
     }
     __syncthreads();
+    STAMP(1, 6);
     {
         const uint32_t nl = min(s_nlong, kLongTiles);
         for (uint32_t w = 0; w < nl; ++w) {
@@ -727,6 +730,7 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
             }
     }
     __syncthreads();
+    STAMP(1, 7);
     const bool unsorted = s_nruns != 0;
     uint32_t n_one;
     if (n == 0) {
@@ -1186,6 +1190,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf &b : ctx->sv_ws) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->rows_ws) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->rows_in) if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->eval_ws.ptr) (void)hipFree(ctx->eval_ws.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->rx_dtot) (void)hipFree(ctx->rx_dtot);
     for (int i = 0; i < 3; ++i) {

@@ -41,6 +41,7 @@ struct duet_ctx {
     DevBuf cl_ws[14], cl_in[4], cl_out[6];
     DevBuf rows_ws[8];                     // device-side row emission
     DevBuf rows_in[5];                     // host-array entry: uploaded text pool, offsets, ranks, sign flags; the rows
+    DevBuf eval_ws;                        // evaluator (duet_eval.hip): one arena
     DevBuf sv_ws[5];                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};

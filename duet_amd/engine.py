@@ -23,7 +23,14 @@ class EfSoA(object):
 
     def __init__(self, **kw):
         for name, dt in self.FIELDS:
-            a = np.ascontiguousarray(kw[name], dtype=dt)
+            src = np.asarray(kw[name])
+            if src.dtype != dt and src.size and src.dtype.kind in 'iu':
+                # the C ABI counts marks, candidates and reads in 32 bits (include/duet_ef.h): a wider host array must not
+                # wrap silently when it is narrowed
+                lim = int(np.iinfo(dt).max)
+                if int(src.min()) < 0 or int(src.max()) > lim:
+                    raise ValueError('%s does not fit the %d-bit arrays of the C ABI' % (name, 8 * np.dtype(dt).itemsize))
+            a = np.ascontiguousarray(src, dtype=dt)
             setattr(self, name, a)
         self.read_off = np.ascontiguousarray(kw.get('read_off', [0, len(self.read_tag)]), dtype=np.uint32)
         self.validate()

@@ -9,6 +9,10 @@ scored per phase set with the better of the two haplotype labelings (evaluation.
 
 Differences in form only: records are flattened into per-(contig, type) position-sorted numpy arrays once, and
 each phase set is matched with one vectorised `searchsorted` instead of Python loops over dicts.
+
+`evaluation_gpu` is the same scoring on the MI355X (duet_eval_run_host, duet_amd/csrc/duet_eval.hip): the host flattens the
+parsed records (`flatten`), the device matches, builds the id sets and picks each phase set's labelling, and the six set
+sizes come back; the ten numbers are the same binary64 quotients.  `--gpu` on the command line selects it.
 """
 
 import argparse
@@ -147,6 +151,78 @@ def evaluation(baseinfo, callinfo, threshold_tp_range, ratio):
     return (avg_sv_num,) + prf(call_tp, base_tp) + prf(call_gt, base_gt) + prf(call_hp, base_hp)
 
 
+_HP_FIXED = {'1|0': 0, '0|1': 1, '1|1': 2}
+
+
+def flatten(baseinfo, callinfo):
+    """The parsed records as the flat arrays of include/duet_ef.h's duet_eval_problem.  Raises IndexError where upstream
+    indexes an empty truth list (a call whose (contig, type) has no truth record, evaluation.py:120-125)."""
+    hp_code = dict(_HP_FIXED)
+
+    def code(hp):
+        if hp not in hp_code:
+            hp_code[hp] = len(hp_code)
+            if len(hp_code) > 255:
+                raise ValueError('more than 255 distinct haplotype strings')
+        return hp_code[hp]
+
+    types = {'INS': 0, 'DEL': 1}
+    contig = {c: k for k, c in enumerate(CHROMS)}
+    base_uid, call_uid, groups = {}, {}, {}
+    lists = [[] for _ in range(2 * len(CHROMS))]
+    for r in baseinfo:
+        base_uid.setdefault(r['id'], len(base_uid))
+        if r['chr'] in contig and r['type'] in types:
+            lists[2 * contig[r['chr']] + types[r['type']]].append(r)
+    base_off = np.zeros(len(lists) + 1, dtype=np.int64)
+    rows = []
+    for i, lst in enumerate(lists):
+        lst.sort(key=lambda r: r['pos'])                 # stable, like sorted(..., key=itemgetter('pos')) upstream
+        rows.extend(lst)
+        base_off[i + 1] = len(rows)
+    a = dict(base_off=base_off, base_pos=[r['pos'] for r in rows], base_len=[r['len'] for r in rows],
+             base_uid=[base_uid[r['id']] for r in rows], base_hp=[code(r['hp']) for r in rows])
+    ck, cp, cl, cu, cg, ch = [], [], [], [], [], []
+    for r in callinfo:
+        call_uid.setdefault(r['id'], len(call_uid))
+        if r['chr'] not in contig:
+            continue
+        g = groups.setdefault((r['chr'], r['ps']), len(groups))
+        if r['type'] not in types:
+            continue
+        key = 2 * contig[r['chr']] + types[r['type']]
+        if base_off[key + 1] == base_off[key]:
+            raise IndexError('list index out of range')
+        ck.append(key); cp.append(r['pos']); cl.append(r['len']); cu.append(call_uid[r['id']]); cg.append(g); ch.append(code(r['hp']))
+    a.update(call_key=ck, call_pos=cp, call_len=cl, call_uid=cu, call_group=cg, call_hp=ch, n_groups=len(groups),
+             n_base_uid=len(base_uid), n_call_uid=len(call_uid))
+    for k in ('base_pos', 'base_len', 'call_pos', 'call_len'):
+        v = np.asarray(a[k], dtype=np.int64)
+        if v.size and (int(v.min()) < 0 or int(v.max()) > 0xFFFFFFFF):
+            raise ValueError(k + ' outside the 32-bit range of the device arrays')
+    return a
+
+
+def evaluation_gpu(baseinfo, callinfo, threshold_tp_range, ratio, ctx=None):
+    """evaluation() on the GPU: same ten numbers, same exceptions."""
+    from duet_amd import engine
+    avg_sv_num = len(callinfo) / len(set(s['ps'] for s in callinfo))
+    a = flatten(baseinfo, callinfo)
+    if ctx is None:
+        ctx = engine.default_context()
+    if threshold_tp_range < 0:
+        a['call_key'] = []                               # abs(...) <= negative never holds: nothing matches
+        for k in ('call_pos', 'call_len', 'call_uid', 'call_group', 'call_hp'):
+            a[k] = []
+    n = ctx.eval_counts(a, max(int(threshold_tp_range), 0), ratio)
+
+    def prf(tp_c, tp_b):
+        p, r = tp_c / len(callinfo), tp_b / len(baseinfo)
+        return p, r, 2 * p * r / (p + r)
+
+    return (avg_sv_num,) + prf(n.call_tp, n.base_tp) + prf(n.call_gt, n.base_gt) + prf(n.call_hp, n.base_hp)
+
+
 def parse_args(argv):
     ap = argparse.ArgumentParser(description='precision / recall / F1 of SV calling, genotyping and phasing against a truth set')
     ap.add_argument('callset', type=str, help='VCF of phased SV calls to score')
@@ -158,6 +234,7 @@ def parse_args(argv):
     ap.add_argument('-b', '--bed_file', type=str, help='BED file; only calls inside its regions are scored')
     ap.add_argument('--skip_phasing', action='store_true',
                     help='score calling and genotyping only')
+    ap.add_argument('--gpu', action='store_true', help='score on the MI355X (libduet_ef.so) instead of with numpy')
     return ap.parse_args(argv)
 
 
@@ -165,7 +242,7 @@ def main(argv):
     args = parse_args(argv)
     bed = args.bed_file or ''
     truth, calls = (parse_vcf(path, args.skip_phasing, bed) for path in (args.truthset, args.callset))
-    res = evaluation(truth, calls, args.refdist, args.pctsim)
+    res = (evaluation_gpu if args.gpu else evaluation)(truth, calls, args.refdist, args.pctsim)
     # upstream's report lines, verbatim (evaluation.py:184-189)
     if not args.skip_phasing:
         print('Average SV number per phase set is', res[0])

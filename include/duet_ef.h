@@ -266,6 +266,38 @@ DUET_API int duet_rows_run_device(duet_ctx *ctx, const duet_rows_problem *prob, 
 DUET_API int duet_ef_rows_run_host(duet_ctx *ctx, const duet_ef_problem *prob, const duet_rows_problem *rows, char *out_text,
                           uint64_t out_cap, uint64_t *out_len, uint32_t *n_rows);
 
+/* ---------------------------------------------------------------------------------------------
+ * Accuracy evaluator: a phased callset scored against a truth set, the arithmetic of
+ * src/scripts/evaluation.py:99-159.  The host parses the two VCFs the way :35-97 does and flattens them:
+ *   truth ("base") records grouped by list key = 2 * contig + type (0 INS, 1 DEL), position-sorted (stably) inside a list;
+ *   calls that sit on a listed contig and have one of the two types, with their list key, their phase-set group
+ *   (= distinct (contig, phase set) pair, :109-111) and their haplotype as a code: 0 '1|0', 1 '0|1', 2 '1|1', >= 3 any other
+ *   string (compared for equality only); record ids (:51) as dense integers -- equal id strings share one integer, because
+ *   upstream counts SETS of ids.
+ * Out: the sizes of the six sets of :100 -- call_tp, base_tp, call_tp_gt, base_tp_gt, call_tp_hp, base_tp_hp.  The ten
+ * numbers upstream prints are quotients of these and of len(callinfo) / len(baseinfo), taken on the host. */
+typedef struct duet_eval_problem {
+    uint32_t n_base, n_calls, n_groups, n_keys;      /* n_keys = 2 * contigs */
+    uint32_t n_base_uid, n_call_uid;                 /* distinct ids on either side */
+    uint32_t refdist;                                /* -r / --refdist (:126) */
+    uint32_t reserved;
+    double ratio;                                    /* -p / --pctsim (:127) */
+    const uint32_t *base_off;                        /* [n_keys + 1] */
+    const uint32_t *base_pos, *base_len, *base_uid;  /* [n_base] */
+    const uint8_t *base_hp;                          /* [n_base] */
+    const uint32_t *call_key;                        /* [n_calls]; every call's list must be non-empty (upstream raises
+                                                        IndexError otherwise, :120-125: the host checks) */
+    const uint32_t *call_pos, *call_len, *call_uid, *call_group;
+    const uint8_t *call_hp;
+} duet_eval_problem;
+
+typedef struct duet_eval_counts {
+    uint32_t call_tp, base_tp, call_gt, base_gt, call_hp, base_hp;
+} duet_eval_counts;
+
+/* All arrays are HOST pointers; uploads, runs four small kernels, synchronises. */
+DUET_API int duet_eval_run_host(duet_ctx *ctx, const duet_eval_problem *prob, duet_eval_counts *counts);
+
 #ifdef __cplusplus
 }
 #endif

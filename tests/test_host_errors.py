@@ -53,3 +53,16 @@ def test_bad_tag_values_are_rejected(tmp_path):
         engine.pack_tags([1], [-1], [5])
     with pytest.raises(ValueError):
         engine.pack_tags([1], [1], [0xFFFFFFFF])
+
+
+def test_values_that_do_not_fit_the_abi_are_rejected_not_wrapped():
+    """cand_off is built as int64 on the host; more than 2**32 - 1 marks must raise, not wrap, when it is narrowed."""
+    import numpy as np
+    from duet_amd import engine
+    ok = dict(cand_ctg_off=[0, 1], read_tag=np.zeros(1, np.uint64), cand_pos=[5], cand_svlen=[60], cand_svread=[3],
+              cand_refread=[1], cand_gt_ok=[1], cand_off=np.array([0, 1], dtype=np.int64), mark_read=[0])
+    engine.EfSoA(**ok)
+    for name, bad in (('cand_off', np.array([0, 1 << 32], dtype=np.int64)), ('cand_pos', np.array([1 << 33], dtype=np.int64)),
+                      ('cand_svread', np.array([-1], dtype=np.int64)), ('mark_read', np.array([1 << 32], dtype=np.int64))):
+        with pytest.raises(ValueError):
+            engine.EfSoA(**dict(ok, **{name: bad}))

@@ -43,7 +43,8 @@ buf = np.zeros(3 * 65536 * 8, dtype=np.uint64)
 lib.duet_dbg_stamps(ctx.handle, 0, buf.ctypes.data)
 st = buf.reshape(3, 65536, 8).astype(np.int64)
 t0 = st[0][st[0][:, 0] > 0][:, 0].min()
-names = [['start', 'offsets', 'staged', 'consumed', 'loop_end', 'decided', 'end'], ['start', 'gathered', 'sorted', 'end'],
+names = [['start', 'offsets', 'staged', 'consumed', 'loop_end', 'decided', 'end'],
+         ['start', 'gathered', 'sorted', 'end', 'recs', 'counted', 'written', 'runs'],
          ['start', 'meta', 'staged']]
 for k in range(3):
     blk = st[k][st[k][:, 0] > 0]
@@ -55,5 +56,10 @@ for k in range(3):
         col = col[blk[:, i] > 0]
         if len(col):
             print('  %-9s first %.2f  median %.2f  p90 %.2f  last %.2f us' % (nm, col.min(), np.median(col), np.percentile(col, 90), col.max()))
+    if k == 1:
+        order = [0, 4, 5, 6, 1, 7, 2, 3]          # stamp indices in program order
+        for b in range(nb):
+            print('  contig block %d:' % b, ' '.join('%s@%.2f' % (names[1][i], rel[b, i]) for i in order if blk[b, i] > 0))
+        continue
     d = np.diff(rel[:, :len(names[k])], axis=1)
     print('  phase durations (median us):', ' '.join('%s=%.2f' % (names[k][i + 1], np.median(d[:, i])) for i in range(d.shape[1])))
