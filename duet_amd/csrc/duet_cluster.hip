@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(64) void cl_fast_one(const ClParams p, const uint32
         fast_unit<GROUP, R, KA>(p, list, L, base, work, smem);
 }
 
-__global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const ClWork work)
+__global__ __launch_bounds__(64, 4) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const ClWork work)
 {
     __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
     const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3];

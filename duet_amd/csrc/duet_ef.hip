@@ -66,7 +66,6 @@ constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB
 constexpr uint32_t kLongCnt = 16;                   // ... when they hold more entries than this
 constexpr uint32_t kLongTiles = 256;                // ef_seed_sort: tiles whose entries are copied by the whole workgroup
 constexpr uint32_t kMaxRuns = 32;                  // ef_seed_sort merges up to this many ascending runs by rank
-constexpr uint32_t kDirectRuns = 8;                // ... and skips the odd-even rounds when it finds no more descents than this
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
 constexpr uint32_t kC2Quota = 32;                 // group-summary slots per classify block
 constexpr int kC2Groups = 2;                      // voter groups kept per summary (first two seen)
@@ -736,24 +735,26 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     if (n == 0) {
         n_one = 0;
     } else if (n <= kSortLds) {
-        // A handful of long ascending runs (candidates ordered by type, then position -- stage A0's order -- give one run per
-        // type) are merged by rank right away.  Many descents are the local disorder of a position-sorted VCF (neighbouring
-        // candidates that straddle a phase-set boundary): that goes in a few odd-even rounds; what is left after them are
-        // again long runs.
-        const bool direct = unsorted && s_nruns <= kDirectRuns;
-        bool todo = unsorted && !direct && !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 6);
-        if (todo) {
-            __syncthreads();
-            if (tid == 0) s_nruns = 0;
-            __syncthreads();
-            for (uint32_t i = tid + 1; i < n; i += kSortThreads)
-                if (s_key[i] < s_key[i - 1]) {
-                    const uint32_t r = atomicAdd(&s_nruns, 1u);
-                    if (r < kMaxRuns) s_run[r] = i;
-                }
-            __syncthreads();
+        // Up to kMaxRuns - 1 ascending runs are merged by rank right away.  More descents than that are the local disorder of
+        // position-ordered candidates (neighbours that straddle a phase-set boundary): a couple of odd-even rounds remove it;
+        // what is left then is sorted, or a few long runs (candidates ordered by type, then position -- stage A0's order --
+        // give one run per type), or real disorder for the bitonic network.  (Six rounds before looking at the runs again cost
+        // the fused pipeline 12 of its 31 us here: the long runs never go away.)
+        bool todo = unsorted;
+        for (int more = 2; todo && s_nruns >= kMaxRuns && more <= 4; more += 2) {
+            todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, more);
+            if (todo) {
+                __syncthreads();
+                if (tid == 0) s_nruns = 0;
+                __syncthreads();
+                for (uint32_t i = tid + 1; i < n; i += kSortThreads)
+                    if (s_key[i] < s_key[i - 1]) {
+                        const uint32_t r = atomicAdd(&s_nruns, 1u);
+                        if (r < kMaxRuns) s_run[r] = i;
+                    }
+                __syncthreads();
+            }
         }
-        todo = todo || direct;
         if (todo && s_nruns < kMaxRuns) {
             // A few ascending runs (candidates ordered by type, then position -- stage A0's order -- give one run per
             // type): merge them by rank.  An element's final place is its index in its own run plus, for every other
