@@ -193,3 +193,24 @@ def test_integration_stub_with_its_own_run(tmp_path):
         stub_rows_match_goldens(load_stub(real_run=True), tmp_path, H.full_cases())
     finally:
         del os.environ['DUET_EF_LIB']
+
+
+def test_bench_self_spawns_and_runs_the_sharded_genome(tmp_path):
+    """`python bench.py --gpus 2` started plainly: the parent spawns one process per rank before touching the GPU; the ranks
+    run the LPT-sharded whole-genome problem with ONE all-gather per problem and rank 0 prints one JSON line whose merged
+    result matches the C oracle.  One GPU here: DUET_BENCH_ONE_GPU=1 (ranks share device 0, gloo) -- plumbing, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['DUET_BENCH_ONE_GPU'] = '1'
+    out = subprocess.check_output([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                                   '--genome-marks', '400000', '--no-extra'], env=env, timeout=600).decode()
+    line = [l for l in out.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 3 and d['parity_vs_oracle'] is True
+    assert d['gather']['collectives_per_problem'] == 1 and d['topology']['world_size'] == 2 and len(d['per_rank']) == 2
+    assert sum(r['marks'] for r in d['per_rank']) == d['config']['marks']
+    assert d['same_problem_on_1_gpu']['parity_vs_oracle'] is True
+    assert 1.0 <= d['sharding']['lpt_imbalance_max_over_mean_marks'] < 1.2
