@@ -156,6 +156,7 @@ struct Params {
     uint32_t n_small;                 // K when K <= kSmallK: the contig offsets then also ride in the kernel arguments
     uint32_t ctg_small[kSmallK + 1];  //   (scalar loads instead of a dependent HBM round trip)
     const uint32_t *dyn_c;            // device-planned runs (DYN kernels): the candidate count lives on the device, C is an upper bound
+    const uint16_t *cand_contig;      // ... and, when the plan came from the candidates' contig column, that column (else null)
     uint32_t dbg;                     // diagnostic ablation bits (0 in production)
     unsigned long long *stamps;       // diagnostic build only: [kernel][block][8] wall-clock stamps
 };
@@ -402,11 +403,17 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         refread = p.cand_refread[c0 + tid];
         gt_ok = p.cand_gt_ok[c0 + tid];
         if (DYN) {
-            // device-planned runs have no start flags: the contig of this candidate, from the contig of the tile's first one
+            // device-planned runs have no start flags.  With the candidates' contig column at hand a start is where the column
+            // changes (two coalesced loads beside the other scalars, no dependent chain); else the contig of this candidate is
+            // walked from the contig of the tile's first one
             const uint32_t c = c0 + tid;
-            uint32_t k = p.blk_ctg[blockIdx.x];
-            while (c >= p.ctg_off[k + 1]) ++k;
-            is_start = c == p.ctg_off[k] ? 1u : 0u;
+            if (p.cand_contig) {
+                is_start = (c == 0 || p.cand_contig[c] != p.cand_contig[c - 1]) ? 1u : 0u;
+            } else {
+                uint32_t k = p.blk_ctg[blockIdx.x];
+                while (c >= p.ctg_off[k + 1]) ++k;
+                is_start = c == p.ctg_off[k] ? 1u : 0u;
+            }
         } else {
             is_start = p.ctg_start[c0 + tid];
         }
@@ -1336,6 +1343,7 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     memset(&p, 0, sizeof(p));
     p.K = K; p.C = C; p.M = pr->n_marks;
     p.dyn_c = d_n_cands;
+    p.cand_contig = d_cand_contig;
     p.read_tag = pr->n_reads ? pr->read_tag : (const uint64_t *)ctx->d_n_one;
     p.cand_pos = pr->cand_pos; p.cand_svlen = pr->cand_svlen; p.cand_svread = pr->cand_svread;
     p.cand_refread = pr->cand_refread; p.cand_gt_ok = pr->cand_gt_ok;
