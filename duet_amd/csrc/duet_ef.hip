@@ -66,6 +66,7 @@ constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB
 constexpr uint32_t kLongCnt = 16;                   // ... when they hold more entries than this
 constexpr uint32_t kLongTiles = 256;                // ef_seed_sort: tiles whose entries are copied by the whole workgroup
 constexpr uint32_t kMaxRuns = 32;                  // ef_seed_sort merges up to this many ascending runs by rank
+constexpr uint32_t kFewRuns = 4;                   // ... right away when it finds no more descents than this
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
 constexpr uint32_t kC2Quota = 32;                 // group-summary slots per classify block
 constexpr int kC2Groups = 2;                      // voter groups kept per summary (first two seen)
@@ -742,31 +743,39 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     if (n == 0) {
         n_one = 0;
     } else if (n <= kSortLds) {
-        // Up to kMaxRuns - 1 ascending runs are merged by rank right away.  More descents than that are the local disorder of
-        // position-ordered candidates (neighbours that straddle a phase-set boundary): a couple of odd-even rounds remove it;
-        // what is left then is sorted, or a few long runs (candidates ordered by type, then position -- stage A0's order --
-        // give one run per type), or real disorder for the bitonic network.  (Six rounds before looking at the runs again cost
-        // the fused pipeline 12 of its 31 us here: the long runs never go away.)
+        // A few long ascending runs (candidates ordered by type, then position -- stage A0's order -- give one run per type) are
+        // merged by rank right away.  More descents than that are the local disorder of position-ordered candidates (neighbours
+        // that straddle a phase-set boundary): one or two odd-even rounds remove it (the rounds stop as soon as nothing moves);
+        // what is left then is sorted, or a few long runs again, or -- after four more rounds -- real disorder for the bitonic
+        // network.  (Six rounds before looking at the runs again cost the fused pipeline 12 of its 31 us here -- the long runs
+        // never go away --, and merging 20 short runs by rank costs a position-sorted VCF 10 us where two rounds cost 1.)
         bool todo = unsorted;
-        for (int more = 2; todo && s_nruns >= kMaxRuns && more <= 4; more += 2) {
-            todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, more);
-            if (todo) {
-                __syncthreads();
-                if (tid == 0) s_nruns = 0;
-                __syncthreads();
-                for (uint32_t i = tid + 1; i < n; i += kSortThreads)
-                    if (s_key[i] < s_key[i - 1]) {
-                        const uint32_t r = atomicAdd(&s_nruns, 1u);
-                        if (r < kMaxRuns) s_run[r] = i;
-                    }
-                __syncthreads();
+        auto count_runs = [&]() {
+            __syncthreads();
+            if (tid == 0) s_nruns = 0;
+            __syncthreads();
+            for (uint32_t i = tid + 1; i < n; i += kSortThreads)
+                if (s_key[i] < s_key[i - 1]) {
+                    const uint32_t r = atomicAdd(&s_nruns, 1u);
+                    if (r < kMaxRuns) s_run[r] = i;
+                }
+            __syncthreads();
+        };
+        if (todo && s_nruns > kFewRuns) {
+            todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 2);
+            if (todo) count_runs();
+            if (todo && s_nruns >= kMaxRuns) {
+                todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 4);
+                if (todo) count_runs();
             }
         }
         if (todo && s_nruns < kMaxRuns) {
-            // A few ascending runs (candidates ordered by type, then position -- stage A0's order -- give one run per
-            // type): merge them by rank.  An element's final place is its index in its own run plus, for every other
-            // run, the number of elements that go before it (<= for earlier runs, < for later ones: distinct places).
-            const uint32_t R = s_nruns + 1;
+            // Up to 31 ascending runs: merge neighbouring runs pairwise, log2(runs) rounds.  An element's place in the merged
+            // run is its index in its own run plus the number of elements of the sibling run that go before it (for the left
+            // run those smaller than it, for the right run those smaller or equal: distinct places, equal seeds stay apart until
+            // unique_copy drops them).  One binary search per element and round -- ranking every element against every other
+            // run at once took 19 searches per element for 20 runs.
+            uint32_t R = s_nruns + 1;
             if (tid == 0) {
                 for (uint32_t a = 1; a < R - 1; ++a) {          // the descents were appended in any order
                     const uint32_t v = s_run[a];
@@ -780,31 +789,41 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
             }
             __syncthreads();
             constexpr uint32_t kPer = (kSortLds + kSortThreads - 1) / kSortThreads;
-            uint32_t val[kPer], dst[kPer];
+            while (R > 1) {
+                uint32_t val[kPer], dst[kPer];
 #pragma unroll
-            for (uint32_t t = 0; t < kPer; ++t) {
-                const uint32_t i = tid + t * kSortThreads;
-                dst[t] = kEmpty;
-                if (i < n) {
-                    const uint32_t x = s_key[i];
-                    uint32_t mine = 0;
-                    while (s_run[mine + 1] <= i) ++mine;
-                    uint32_t at = i - s_run[mine];
-                    for (uint32_t q = 0; q < R; ++q) {
-                        if (q == mine) continue;
-                        const uint32_t *a = s_key + s_run[q];
-                        const uint32_t len = s_run[q + 1] - s_run[q];
-                        at += lower_bound_u32(a, len, q < mine ? x + 1u : x);       // PS <= 2^32 - 2: x + 1 cannot wrap
+                for (uint32_t t = 0; t < kPer; ++t) {
+                    const uint32_t i = tid + t * kSortThreads;
+                    dst[t] = kEmpty;
+                    if (i < n) {
+                        uint32_t lo_r = 0, hi_r = R;                 // the run of position i: last a with s_run[a] <= i
+                        while (hi_r - lo_r > 1) {
+                            const uint32_t mid = (lo_r + hi_r) >> 1;
+                            if (s_run[mid] <= i) lo_r = mid; else hi_r = mid;
+                        }
+                        const uint32_t a = lo_r, b = a ^ 1u;
+                        if (b < R) {
+                            const uint32_t x = s_key[i], lo = s_run[a], blo = s_run[b], blen = s_run[b + 1] - blo;
+                            // PS <= 2^32 - 2: x + 1 cannot wrap
+                            const uint32_t before = lower_bound_u32(s_key + blo, blen, a < b ? x : x + 1u);
+                            val[t] = x;
+                            dst[t] = (a < b ? lo : blo) + (i - lo) + before;
+                        }
                     }
-                    val[t] = x;
-                    dst[t] = at;
                 }
-            }
-            __syncthreads();
+                __syncthreads();
 #pragma unroll
-            for (uint32_t t = 0; t < kPer; ++t)
-                if (dst[t] != kEmpty) s_key[dst[t]] = val[t];
-            __syncthreads();
+                for (uint32_t t = 0; t < kPer; ++t)
+                    if (dst[t] != kEmpty) s_key[dst[t]] = val[t];
+                __syncthreads();
+                const uint32_t newR = (R + 1u) >> 1;
+                if (tid == 0) {
+                    for (uint32_t j = 1; j < newR; ++j) s_run[j] = s_run[2 * j];
+                    s_run[newR] = n;
+                }
+                __syncthreads();
+                R = newR;
+            }
         } else if (todo) {
             bitonic_sort(s_key, n, tid, kSortThreads);
         }

@@ -159,6 +159,13 @@ def sv_phasing_sharded(home, svlen_thres, suppread_thres, thread, include_all_ct
     if extra_env:
         env.update(extra_env)
     rc = launch.spawn_ranks(gpus, argv, extra_env=env)
+    for h in logging.getLogger().handlers:              # rank 0 appended to the log file: go on behind its lines
+        if isinstance(h, logging.FileHandler) and h.stream is not None:
+            h.acquire()
+            try:
+                h.stream.seek(0, os.SEEK_END)
+            finally:
+                h.release()
     if rc == 0:
         return True
     if rc == RC_DECLINED:
