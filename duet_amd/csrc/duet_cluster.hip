@@ -20,8 +20,9 @@
 //   exact pass     binary64 average linkage for the listed components (nearest-neighbour cache per row)
 //   rank pass      finishes the partitions that had listed components
 //                  fast and rank passes write each mark to its place in the partition's output (order[], and in the
-//                  fused pipeline its read index) and leave, per cluster head, rank/end/means
-//   scan + cl_emit clusters per partition -> candidate bases; the cluster heads write cand_*[]
+//                  fused pipeline its read index) and leave, per cluster, a record (rank, end, floor means) at the
+//                  partition's start + the cluster's index
+//   scan + cl_emit clusters per partition -> candidate bases; one thread per partition turns its clusters' records into cand_*[]
 //
 // Bit-exactness vs the oracle: what is emitted depends only on the final clusters; the exact pass evaluates the same
 // binary64 expressions in the same order as the oracle (-ffp-contract=off; ties to the smallest (first, second)
@@ -73,7 +74,7 @@ struct ClParams {
     uint8_t *sv_gt;
     uint8_t *label8;                                  // [M] per sorted position: its cluster's smallest member (row inside the partition)
     uint8_t *comp8;                                   // [M] rows left to the exact pass: smallest row of their component; else 0xFF
-    uint32_t *e_info, *e_pos, *e_span;                // [M] per sorted position: rank | end << 8 | cluster << 16 | head << 24; head means
+    uint32_t *e_info, *e_pos, *e_span;                // [M] cluster c of the partition that starts at s, at s + c: rank | end << 8; floor means
     uint32_t *pc;                                     // [P] clusters per partition
     const uint32_t *cbase;                            // [P] first candidate of each partition
     // outputs
@@ -144,6 +145,33 @@ struct LoadHead {
         return cut ? i : 0u;
     }
 };
+// the same for the kScanItems consecutive positions base .. base + kScanItems - 1 of one scan thread, from 16-byte loads (base is a
+// multiple of kScanItems and the key buffer is hipMalloc-aligned): head[j] = position base + j starts a natural partition
+__device__ __forceinline__ void load_heads(const LoadHead &h, uint32_t base, uint32_t n, bool (&head)[kScanItems])
+{
+    static_assert(kScanItems % 2 == 0, "two keys per load");
+    uint64_t k[kScanItems + 1];
+    k[0] = base > 0 && base <= n ? h.keys[base - 1] & h.km : 0ull;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j += 2) {
+        if (base + j + 1 < n) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(h.keys + base + j);
+            k[j + 1] = v.x & h.km;
+            k[j + 2] = v.y & h.km;
+        } else {
+            k[j + 1] = base + j < n ? h.keys[base + j] & h.km : 0ull;
+            k[j + 2] = 0ull;
+        }
+    }
+    const uint64_t cm = (1ull << h.centre_bits) - 1ull;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        const uint32_t i = base + j;
+        const uint64_t a = k[j], b = k[j + 1];
+        head[j] = i < n && (i == 0 || (a >> h.centre_bits) != (b >> h.centre_bits) || (b & cm) - (a & cm) > (uint64_t)h.part_gap);
+    }
+}
+
 // clusters of partition i.  The partition count lives on the device: the scan is launched over the M positions (an upper
 // bound) and the elements past the count neither load nor store anything
 struct LoadPc {
@@ -209,11 +237,11 @@ __global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead in, u
     if (zero14 && blockIdx.x == 0 && tid < 14) zero14[tid] = 0;         // the work-list counters of the kernels that follow
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     PartSum acc{kNoHead, 0, 0};
+    bool head[kScanItems];
+    load_heads(in, base, n, head);
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        const uint32_t i = base + j;
-        if (i < n && (i == 0 || in(i) != 0u)) acc = part_combine(acc, PartSum{i, i, 0}, pm);
-    }
+    for (int j = 0; j < kScanItems; ++j)
+        if (head[j]) acc = part_combine(acc, PartSum{base + j, base + j, 0}, pm);
     (void)part_block_exscan<kScanThreads>(acc, pm, s_w);
     __syncthreads();
     if (tid == 0) tiles[blockIdx.x] = s_w[kScanThreads / 64];
@@ -236,7 +264,8 @@ __global__ __launch_bounds__(1024) void part_spine(PartSum *tiles, uint32_t nb, 
     }
 }
 
-// SELF: tiles[] holds the tiles' own summaries and every block combines the ones before it by itself
+// SELF: tiles[] holds the tiles' own summaries and every block combines the ones before it by itself.  pid (optional): every
+// position's partition id -- nobody downstream needs it since cl_emit walks partitions
 template <bool SELF>
 __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, uint32_t n, uint32_t pm, const PartSum *tiles, uint32_t *pid,
                                                            uint32_t *part_start, uint32_t *n_parts)
@@ -247,12 +276,10 @@ __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, ui
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     bool head[kScanItems];
     PartSum acc{kNoHead, 0, 0};
+    load_heads(in, base, n, head);
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        const uint32_t i = base + j;
-        head[j] = i < n && (i == 0 || in(i) != 0u);
-        if (head[j]) acc = part_combine(acc, PartSum{i, i, 0}, pm);
-    }
+    for (int j = 0; j < kScanItems; ++j)
+        if (head[j]) acc = part_combine(acc, PartSum{base + j, base + j, 0}, pm);
     PartSum carry{kNoHead, 0, 0};
     if (SELF) {
         // the tiles before this one, combined in order: thread t takes a contiguous run of them
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, ui
         }
         const uint32_t d = i - H, q = d < pm ? 0u : d / pm;
         const bool starts = d == q * pm;
-        pid[i] = P + q;
+        if (pid) pid[i] = P + q;
         if (starts) part_start[P + q] = i;
         if (i == n - 1) {
             part_start[P + q + 1] = n;
@@ -761,15 +788,18 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
         if (k < n) {
             const bool head = rt[r] == k;
             const uint32_t size = F[r].count(), rank = before[r] + F[r].count_below(k);
-            p.e_info[s + k] = rank | ((before[r] + size) << 8) | (heads.count_below(rt[r]) << 16) | (head ? 1u << 24 : 0u);
             // the mark's place in the output: clusters in order of their smallest member, members in sorted order
             p.order[s + rank] = mk[r];
             if (p.sv_mark_out) p.sv_mark_out[s + rank] = rd[r];
             if (head) {
-                // floor means.  A sum stays below 2^40 and size <= 128, so the correctly rounded binary64 quotient
+                // the cluster's record, at the partition's start + the cluster's index: cl_emit walks a partition's clusters
+                // from there (one dense record per cluster instead of a word per mark with the heads scattered among them).
+                // Floor means: a sum stays below 2^40 and size <= 128, so the correctly rounded binary64 quotient
                 // lies strictly between the same two integers as the true one (or is that integer): no 64-bit division
-                p.e_pos[s + k] = (uint32_t)((double)s_sum[k][0] / (double)size);
-                p.e_span[s + k] = (uint32_t)((double)s_sum[k][1] / (double)size);
+                const uint32_t ci = heads.count_below(rt[r]);
+                p.e_info[s + ci] = rank | ((before[r] + size) << 8);
+                p.e_pos[s + ci] = (uint32_t)((double)s_sum[k][0] / (double)size);
+                p.e_span[s + ci] = (uint32_t)((double)s_sum[k][1] / (double)size);
             }
         }
     }
@@ -1307,39 +1337,42 @@ __global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32
     }
 }
 
-// one thread per sorted position: members to their place in order[], cluster heads write the candidate
-__global__ void cl_emit(const ClParams p, const uint32_t *pid)
+// one thread per partition (their count lives on the device: launched over an upper bound): its clusters' records, dense from the
+// partition's start, become the candidates cbase[part] ...; neighbouring partitions write neighbouring candidates
+__global__ void cl_emit(const ClParams p)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.M) return;
-    const uint32_t info = p.e_info[i];
-    if (info >> 24) {                                                            // a cluster's smallest member speaks for the candidate
-        const uint32_t part = pid[i];
-        const uint32_t s = p.part_start[part];
-        const uint32_t cand = p.cbase[part] + ((info >> 16) & 0xFFu);
-        p.cand_off[cand + 1] = s + ((info >> 8) & 0xFFu);
-        const uint64_t hi = (p.skeys[i] & key_mask(p.key_bits)) >> p.centre_bits;                    // contig | type, straight from the sorted key
-        const uint32_t k = (uint32_t)(hi >> p.type_bits), pos = p.e_pos[i];
+    const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
+    if (part == 0) p.cand_off[0] = 0;
+    if (part >= *p.n_parts) return;
+    const uint32_t s = p.part_start[part], nc = p.pc[part], c0 = p.cbase[part];
+    const uint64_t hi = (p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits;                        // contig | type, straight from the sorted key
+    const uint32_t k = (uint32_t)(hi >> p.type_bits), type = (uint32_t)(hi & ((1ull << p.type_bits) - 1ull));
+    uint32_t d_lo = 0, nb = 0;
+    if (p.sv_svread) {
+        d_lo = p.sv_depth_off[k];
+        nb = p.sv_depth_off[k + 1] - d_lo;
+    }
+    for (uint32_t c = 0; c < nc; ++c) {
+        const uint32_t info = p.e_info[s + c], pos = p.e_pos[s + c], cand = c0 + c;
+        p.cand_off[cand + 1] = s + (info >> 8);
         p.cand_contig[cand] = (uint16_t)k;
-        p.cand_type[cand] = (uint8_t)(hi & ((1ull << p.type_bits) - 1ull));
+        p.cand_type[cand] = (uint8_t)type;
         p.cand_pos[cand] = pos;
-        p.cand_span[cand] = p.e_span[i];
+        p.cand_span[cand] = p.e_span[s + c];
         if (p.sv_svread) {
             // what a caller VCF would have carried: support = members, reference reads = depth(contig, pos) - support
-            const uint32_t support = ((info >> 8) & 0xFFu) - (info & 0xFFu);      // a head's rank is its cluster's start
-            const uint32_t nb = p.sv_depth_off[k + 1] - p.sv_depth_off[k];
+            const uint32_t support = (info >> 8) - (info & 0xFFu);                  // a cluster's end - its first member's rank
             uint32_t d = 0;
             if (nb) {
                 uint32_t bin = pos / p.sv_depth_bin;
                 bin = bin < nb ? bin : nb - 1;
-                d = p.sv_depth[p.sv_depth_off[k] + bin];
+                d = p.sv_depth[d_lo + bin];
             }
             p.sv_svread[cand] = support;
             p.sv_refread[cand] = d > support ? d - support : 0u;
             p.sv_gt[cand] = 1;
         }
     }
-    if (i == 0) p.cand_off[0] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1407,8 +1440,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         !res->cand_contig || !res->cand_type || !res->cand_pos || !res->cand_span)
         return duet_fail(ctx, DUET_ERR_INVALID, "null array");
 
-    const uint32_t nb_rx = (M + kRxTile - 1) / kRxTile;
     const uint32_t nb_sc = (M + kScanTile - 1) / kScanTile;
+    const uint32_t nb_rx = (M + kRxTile - 1) / kRxTile;
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
@@ -1419,7 +1452,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint64_t *keysA = (uint64_t *)ctx->cl_ws[0].ptr, *keysB = (uint64_t *)ctx->cl_ws[1].ptr;
     uint32_t *valsA = (uint32_t *)ctx->cl_ws[2].ptr, *valsB = (uint32_t *)ctx->cl_ws[3].ptr;
     uint32_t *hist = (uint32_t *)ctx->cl_ws[4].ptr;
-    uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr, *tmpB = (uint32_t *)ctx->cl_ws[6].ptr;
+    uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr;
     uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
     uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
     uint32_t *e_info = (uint32_t *)ctx->cl_ws[9].ptr;
@@ -1481,11 +1514,11 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         PartSum *tiles = (PartSum *)tmpA;                         // 3 words per 2048 marks
         hipLaunchKernelGGL(part_reduce, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 2);
         if (nb_sc <= kSelfSpine && !big_sort) {
-            hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, tmpB,
+            hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal);
         } else {
             hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
-            hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, tmpB,
+            hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal);
         }
     }
@@ -1560,7 +1593,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort);       // cbase[part] = its first candidate
     p.cbase = cbase;
-    hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p, (const uint32_t *)tmpB);
+    hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p);
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
         uint32_t h[32];
@@ -1649,7 +1682,15 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     for (int i = 0; i < 5; ++i)
         if ((rc = duet_reserve(ctx, ctx->sv_ws[i], sz[i]))) return rc;
     uint32_t *d_ctg_off = (uint32_t *)ctx->sv_ws[0].ptr, *d_depth_off = d_ctg_off + (K + 1);
-    HIP_TRY(ctx, hipMemcpyAsync(d_depth_off, pr->depth_off, ((size_t)K + 1) * 4, hipMemcpyHostToDevice, st));
+    // (uploaded only when they change: a pageable host-to-device copy in front of every run keeps the host from queueing the
+    // run's thirty launches ahead of the device -- 45 us of gaps per 0.37 ms run at 1 M marks)
+    if (ctx->sv_depth_off_at != (void *)d_depth_off || ctx->sv_depth_off.size() != (size_t)K + 1 ||
+        memcmp(ctx->sv_depth_off.data(), pr->depth_off, ((size_t)K + 1) * 4) != 0) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));                  // the previous copy's source is about to change
+        ctx->sv_depth_off.assign(pr->depth_off, pr->depth_off + K + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(d_depth_off, ctx->sv_depth_off.data(), ((size_t)K + 1) * 4, hipMemcpyHostToDevice, st));
+        ctx->sv_depth_off_at = (void *)d_depth_off;
+    }
     // clustering; its emit kernel also writes what a caller VCF would have carried (support, reference reads, GT)
     // and the marks' read indices in output order
     SvExtra sv;

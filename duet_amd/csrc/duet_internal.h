@@ -42,7 +42,9 @@ struct duet_ctx {
     DevBuf rows_ws[8];                     // device-side row emission
     DevBuf rows_in[5];                     // host-array entry: uploaded text pool, offsets, ranks, sign flags; the rows
     DevBuf eval_ws;                        // evaluator (duet_eval.hip): one arena
-    DevBuf sv_ws[5];                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
+    DevBuf sv_ws[5];
+    std::vector<uint32_t> sv_depth_off;    // the depth offsets the device copy in sv_ws[0] holds (uploaded only when they change)
+    void *sv_depth_off_at = nullptr;                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};
     // profiling events: 6 per run

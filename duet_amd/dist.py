@@ -97,6 +97,10 @@ class GroupedGather(object):
         self.n_groups = max(1, storage.numel() // (self.rb * self.G))
         self.pending = [None] * self.n_groups
         self.gathered = [None] * self.n_groups
+        if self.world > 1:
+            import torch                                     # receive buffers up front: no allocation inside a timed region
+            for g in range(self.n_groups):
+                self.gathered[g] = torch.empty(self.world * self.G * self.rb, dtype=torch.uint8, device=storage.device)
         self.filled, self.group, self.last, self.slot = 0, 0, None, 0
 
     def next_slot(self):
