@@ -74,7 +74,7 @@ struct ClParams {
     uint8_t *sv_gt;
     uint8_t *label8;                                  // [M] per sorted position: its cluster's smallest member (row inside the partition)
     uint8_t *comp8;                                   // [M] rows left to the exact pass: smallest row of their component; else 0xFF
-    uint32_t *e_info, *e_pos, *e_span;                // [M] cluster c of the partition that starts at s, at s + c: rank | end << 8; floor means
+    uint4 *e_rec;                                     // [M] cluster c of the partition that starts at s, at s + c: (rank | end << 8, floor mean pos, floor mean span, -)
     uint32_t *pc;                                     // [P] clusters per partition
     const uint32_t *cbase;                            // [P] first candidate of each partition
     // outputs
@@ -797,9 +797,8 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
                 // Floor means: a sum stays below 2^40 and size <= 128, so the correctly rounded binary64 quotient
                 // lies strictly between the same two integers as the true one (or is that integer): no 64-bit division
                 const uint32_t ci = heads.count_below(rt[r]);
-                p.e_info[s + ci] = rank | ((before[r] + size) << 8);
-                p.e_pos[s + ci] = (uint32_t)((double)s_sum[k][0] / (double)size);
-                p.e_span[s + ci] = (uint32_t)((double)s_sum[k][1] / (double)size);
+                p.e_rec[s + ci] = make_uint4(rank | ((before[r] + size) << 8), (uint32_t)((double)s_sum[k][0] / (double)size),
+                                             (uint32_t)((double)s_sum[k][1] / (double)size), 0u);
             }
         }
     }
@@ -1353,12 +1352,13 @@ __global__ void cl_emit(const ClParams p)
         nb = p.sv_depth_off[k + 1] - d_lo;
     }
     for (uint32_t c = 0; c < nc; ++c) {
-        const uint32_t info = p.e_info[s + c], pos = p.e_pos[s + c], cand = c0 + c;
+        const uint4 rec = p.e_rec[s + c];
+        const uint32_t info = rec.x, pos = rec.y, cand = c0 + c;
         p.cand_off[cand + 1] = s + (info >> 8);
         p.cand_contig[cand] = (uint16_t)k;
         p.cand_type[cand] = (uint8_t)type;
         p.cand_pos[cand] = pos;
-        p.cand_span[cand] = p.e_span[s + c];
+        p.cand_span[cand] = rec.z;
         if (p.sv_svread) {
             // what a caller VCF would have carried: support = members, reference reads = depth(contig, pos) - support
             const uint32_t support = (info >> 8) - (info & 0xFFu);                  // a cluster's end - its first member's rank
@@ -1445,7 +1445,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M * 4, (size_t)M * 4, 128, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8)};
+                              ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 128, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8)};
     int rc;
     for (int i = 0; i < 14; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
@@ -1455,7 +1455,6 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr;
     uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
     uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
-    uint32_t *e_info = (uint32_t *)ctx->cl_ws[9].ptr;
     uint32_t *cbase = (uint32_t *)ctx->cl_ws[13].ptr + (M + 1);      // (the first M + 1 words hold label8 / comp8)
     uint32_t *pc = (uint32_t *)ctx->cl_ws[10].ptr;
     uint32_t *scal = (uint32_t *)ctx->cl_ws[11].ptr;      // [0] = n_parts
@@ -1523,9 +1522,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         }
     }
     p.part_start = part_start; p.n_parts = scal; p.pc = pc;
-    p.e_info = e_info;
-    p.e_pos = (uint32_t *)kout;                                   // the spare key buffer: 2 x M words
-    p.e_span = p.e_pos + M;
+    p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
     const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
     uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M] partitions by size class, then the work lists
     uint32_t *cnts = scal + 2;
@@ -1554,13 +1551,18 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
     const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
     if (small) {
-        // partitions of more than 64 marks go whole to the exact pass, on a side stream, right away; beside them the fast
-        // pass over the other size classes in one launch
+        // partitions of more than 64 marks go whole to the exact pass right away, beside the fast pass over the other size
+        // classes (one launch) and the exact pass over what that leaves.  The two chains take about as long as each other; the
+        // whole-partition chain stays on the CALLER's stream and the other one goes to the side stream: a cross-stream event
+        // that is already signalled when its waiter arrives costs nothing, one that is not costs ~13 us after the signal --
+        // so the stream that goes on afterwards should be the one that finishes last, and on SV-like data that is this chain.
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(cap100 ? cl_exact_big<true, 100> : cl_exact_big<true, 128>), dim3(grid < 4096u ? grid : 4096u),
-                           dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
+                           dim3(64), 0, st, p, (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
+        hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
+        hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)work.comp_list,
+                           (const uint32_t *)work.comp_count);
         HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
-        hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
     } else {
         // the side stream takes the partitions of more than 64 marks (few, long chains: a launch of their own would leave most
         // of the chip idle) and then the components of more than 64 rows they leave; beside them one launch per size class
@@ -1580,9 +1582,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
                            (const uint32_t *)(cnts + 1), work);
         hipLaunchKernelGGL((cl_fast_one<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), work);
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[1], 0));        // cl_exact_small also takes what the >64 class left
+        hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
+                           (const uint32_t *)work.comp_count);
     }
-    hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
-                       (const uint32_t *)work.comp_count);
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
     // ranks: the partitions of more than 64 marks come from their class list (small: all of them) or from the fast pass's
     // list of unsettled ones
