@@ -146,3 +146,14 @@ def test_config2_marks_recover_candidates(ctx):
 def test_genome_marks(ctx):
     marks = synth.raw_marks(synth.bench_genome(400000, 3), 3)
     check(ctx, marks)
+
+
+def test_between_one_and_four_million_marks(ctx):
+    """1.5 M marks (367 radix tiles): the sort's middle regime -- digit totals by atomics + one rx_offsets launch per pass
+    (up to 256 tiles every scatter block sums the tiles before it itself; beyond 1024 the generic scan takes over)."""
+    marks = synth.raw_marks([synth.bench_contig('1', 300000, 150000, 11)], 11)
+    assert 1400000 < len(marks['pos']) < 1600000
+    want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'])
+    got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'])
+    for f in FIELDS:
+        assert np.array_equal(got[f], want[f]), f
