@@ -115,17 +115,35 @@ __global__ __launch_bounds__(256) void cl_maxima(const ClParams p, uint32_t *out
     }
 }
 
-__global__ void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps, uint4 *rec4)
+// sort keys, the marks' records -- and, since the keys are at hand, the sort's first digit histogram (what rx_hist would
+// read them back for): one workgroup per radix tile
+__global__ __launch_bounds__(kRxHistThreads) void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps, uint4 *rec4, uint32_t dmask,
+                                                          uint32_t nb, uint32_t *hist /* [256][nb] */, uint32_t *dtot /* or null */)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.M) return;
-    const uint64_t hi = ((uint64_t)p.contig[i] << p.type_bits) | (uint64_t)p.type[i];
-    const uint32_t ps_ = p.pos[i], sp_ = p.span[i];
-    const uint64_t key = (hi << p.centre_bits) | centre_of(ps_, sp_);
-    if (p.sv_mark_in) rec4[i] = make_uint4(ps_, sp_, p.sv_mark_in[i], 0u);
-    else ps[i] = make_uint2(ps_, sp_);
-    if (p.idx_packed) keys[i] = key | ((uint64_t)i << p.key_bits);
-    else { keys[i] = key; vals[i] = i; }
+    __shared__ uint32_t s_h[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256) s_h[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kRxTile / kRxHistThreads; ++it) {
+        const uint32_t i = blockIdx.x * kRxTile + it * kRxHistThreads + tid;
+        if (i < p.M) {
+            const uint64_t hi = ((uint64_t)p.contig[i] << p.type_bits) | (uint64_t)p.type[i];
+            const uint32_t ps_ = p.pos[i], sp_ = p.span[i];
+            const uint64_t key = (hi << p.centre_bits) | centre_of(ps_, sp_);
+            if (p.sv_mark_in) rec4[i] = make_uint4(ps_, sp_, p.sv_mark_in[i], 0u);
+            else ps[i] = make_uint2(ps_, sp_);
+            if (p.idx_packed) keys[i] = key | ((uint64_t)i << p.key_bits);
+            else { keys[i] = key; vals[i] = i; }
+            atomicAdd(&s_h[(uint32_t)key & dmask], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t c = s_h[tid];
+        hist[(size_t)tid * nb + blockIdx.x] = c;
+        if (dtot && c) atomicAdd(&dtot[(blockIdx.x % kDtotCopies) * 256u + tid], c);
+    }
 }
 
 // element sources / sinks of the scans: what used to be separate elementwise kernels rides on the scan's own
@@ -384,7 +402,7 @@ constexpr uint32_t kNoCol = 0xFFFFu;
 // Minimum of a 32-bit value over each group of GROUP consecutive lanes, delivered to every lane of the group.
 // Inside a 16-lane row the steps are DPP lane permutes fused into v_min_u32 (pairs, quads, halves, row: each step
 // combines two sets that are already uniform); across rows the four row minima go through SGPRs.
-#define DUET_DPP_MIN(v, ctrl) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, 0xF, 0xF, false))
+#define DUET_DPP_MIN(v, ctrl) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true))
 template <int GROUP>
 __device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
 {
@@ -1498,12 +1516,14 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     unsigned char *recs = (unsigned char *)ctx->cl_ws[13].ptr + ((8 * ((size_t)M + 1) + 15) & ~(size_t)15);
     if (sv) p.rec4 = (const uint4 *)recs;
     else p.ps = (const uint2 *)recs;
-    hipLaunchKernelGGL(cl_keys, g256, b256, 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs);
+    const bool big_sort = (ctx->dbg & DUET_DBG_CLUSTER_LARGE) != 0;     // (tests: the tile-offset path of > 4 M keys)
+    const bool rx_totals = nb_rx <= kRxTotalsTiles && !big_sort;
+    hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs,
+                       key_bits >= 8u ? 255u : (1u << key_bits) - 1u, nb_rx, hist, rx_totals ? ctx->rx_dtot : (uint32_t *)nullptr);
     uint64_t *kin = nullptr, *kout = nullptr;
     uint32_t *vin = nullptr;
-    const bool big_sort = (ctx->dbg & DUET_DBG_CLUSTER_LARGE) != 0;     // (tests: the tile-offset path of > 4 M keys)
-    if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, nullptr, &kout, big_sort);
-    else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, &vin, &kout, big_sort);
+    if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, nullptr, &kout, big_sort, true);
+    else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, &vin, &kout, big_sort, true);
     p.sorted = vin;
     p.skeys = kin;
     // partitions: one composite scan straight off the sorted keys -> each position's partition id, the partition start

@@ -389,83 +389,89 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
 
     const uint32_t tid = threadIdx.x;
     STAMP(0, 0);
-    const uint32_t c0 = blockIdx.x * kCandPerBlock;
     const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
-    if (DYN && c0 >= n_cands) return;                          // the grid was sized for the upper bound
-    const uint32_t nc = min((uint32_t)kCandPerBlock, n_cands - c0);
-    for (uint32_t i = tid; i <= nc; i += kCandPerBlock) s_off[i] = p.cand_off[c0 + i];
-    if (tid == 0) sh.c2n = 0;
+    // device-planned runs know only an upper bound of the candidate count on the host: their grid is a fraction of that
+    // bound and strides over the real tiles (a grid of the full bound is ~10x too many workgroups on SV-like data, and
+    // starting the empty ones cost the fused pipeline 9 of 18 us at 1 M marks)
+    for (uint32_t tile = blockIdx.x; !DYN || tile * (uint32_t)kCandPerBlock < n_cands; tile += gridDim.x) {
+        const uint32_t c0 = tile * kCandPerBlock;
+        const uint32_t nc = min((uint32_t)kCandPerBlock, n_cands - c0);
+        for (uint32_t i = tid; i <= nc; i += kCandPerBlock) s_off[i] = p.cand_off[c0 + i];
+        if (tid == 0) sh.c2n = 0;
 
-    // candidate scalars, coalesced (candidate c0 + tid)
-    uint32_t svlen = 0, svread = 0, refread = 0, gt_ok = 0, is_start = 0;
-    if (tid < nc) {
-        svlen = p.cand_svlen[c0 + tid];
-        svread = p.cand_svread[c0 + tid];
-        refread = p.cand_refread[c0 + tid];
-        gt_ok = p.cand_gt_ok[c0 + tid];
-        if (DYN) {
-            // device-planned runs have no start flags.  With the candidates' contig column at hand a start is where the column
-            // changes (two coalesced loads beside the other scalars, no dependent chain); else the contig of this candidate is
-            // walked from the contig of the tile's first one
-            const uint32_t c = c0 + tid;
-            if (p.cand_contig) {
-                is_start = (c == 0 || p.cand_contig[c] != p.cand_contig[c - 1]) ? 1u : 0u;
+        // candidate scalars, coalesced (candidate c0 + tid)
+        uint32_t svlen = 0, svread = 0, refread = 0, gt_ok = 0, is_start = 0;
+        if (tid < nc) {
+            svlen = p.cand_svlen[c0 + tid];
+            svread = p.cand_svread[c0 + tid];
+            refread = p.cand_refread[c0 + tid];
+            gt_ok = p.cand_gt_ok[c0 + tid];
+            if (DYN) {
+                // device-planned runs have no start flags.  With the candidates' contig column at hand a start is where the column
+                // changes (two coalesced loads beside the other scalars, no dependent chain); else the contig of this candidate is
+                // walked from the contig of the tile's first one
+                const uint32_t c = c0 + tid;
+                if (p.cand_contig) {
+                    is_start = (c == 0 || p.cand_contig[c] != p.cand_contig[c - 1]) ? 1u : 0u;
+                } else {
+                    uint32_t k = p.blk_ctg[tile];
+                    while (c >= p.ctg_off[k + 1]) ++k;
+                    is_start = c == p.ctg_off[k] ? 1u : 0u;
+                }
             } else {
-                uint32_t k = p.blk_ctg[blockIdx.x];
-                while (c >= p.ctg_off[k + 1]) ++k;
-                is_start = c == p.ctg_off[k] ? 1u : 0u;
-            }
-        } else {
-            is_start = p.ctg_start[c0 + tid];
-        }
-    }
-    const bool kept = tid < nc && svlen >= p.svlen_thres && svread >= p.suppread_thres && gt_ok != 0;     // :189-190
-    const bool divzero = kept && ((uint64_t)svread + (uint64_t)refread == 0);
-    __syncthreads();
-    STAMP(0, 1);
-    const uint32_t m_begin = s_off[0], m_end = s_off[nc];
-
-    // thread t walks candidate c0 + t.  (Dealing a tile's candidates to lanes in descending order of their mark
-    // count -- so that the four waves loop 18/14/10/6 times instead of 4 x 18 -- was measured and is NOT faster: a
-    // workgroup holds its LDS until its slowest wave is done, and that wave still loops 18 times.)
-    const uint32_t j = tid;
-    const bool live = j < nc;
-    const bool active = kept && !divzero;
-    const uint32_t my_b = live ? s_off[j] : 0, my_e = live ? s_off[j + 1] : 0;
-    CandState st;
-
-    const uint32_t base = VEC ? (m_begin & ~3u) : m_begin;
-    for (uint32_t cs = base; cs < m_end; cs += kChunk) {
-        // ---- stage: LDS[i] = tag of mark cs+i -----------------------------------------------
-        if (VEC) {
-            uint4 r[kStageIt];
-            uint64_t t[4 * kStageIt];
-            uint32_t valid;
-            stage_load_marks(p, r, cs, m_end, tid);
-            stage_gather(p, t, valid, r, cs, m_end, tid);
-            stage_store(s_tag, t, valid, cs, m_end, tid);
-        } else {
-            for (uint32_t i = tid; i < kChunk && cs + i < m_end; i += kCandPerBlock) {
-                const uint32_t r = p.mark_read[cs + i];
-                s_tag[i] = r == kEmpty ? kUntagged : p.read_tag[r];
+                is_start = p.ctg_start[c0 + tid];
             }
         }
+        const bool kept = tid < nc && svlen >= p.svlen_thres && svread >= p.suppread_thres && gt_ok != 0;     // :189-190
+        const bool divzero = kept && ((uint64_t)svread + (uint64_t)refread == 0);
         __syncthreads();
-        STAMP(0, 2);
-        // ---- consume: each thread walks its candidate's part of this chunk ----------------------
-        uint32_t lo = max(my_b, cs);
-        const uint32_t hi = min(my_e, cs + (uint32_t)kChunk);
-        if (!kept || (p.dbg & 4)) lo = hi;
-        consume_range(st, s_tag, lo, hi, cs);
-        STAMP(0, 3);
+        STAMP(0, 1);
+        const uint32_t m_begin = s_off[0], m_end = s_off[nc];
+
+        // thread t walks candidate c0 + t.  (Dealing a tile's candidates to lanes in descending order of their mark
+        // count -- so that the four waves loop 18/14/10/6 times instead of 4 x 18 -- was measured and is NOT faster: a
+        // workgroup holds its LDS until its slowest wave is done, and that wave still loops 18 times.)
+        const uint32_t j = tid;
+        const bool live = j < nc;
+        const bool active = kept && !divzero;
+        const uint32_t my_b = live ? s_off[j] : 0, my_e = live ? s_off[j + 1] : 0;
+        CandState st;
+
+        const uint32_t base = VEC ? (m_begin & ~3u) : m_begin;
+        for (uint32_t cs = base; cs < m_end; cs += kChunk) {
+            // ---- stage: LDS[i] = tag of mark cs+i -----------------------------------------------
+            if (VEC) {
+                uint4 r[kStageIt];
+                uint64_t t[4 * kStageIt];
+                uint32_t valid;
+                stage_load_marks(p, r, cs, m_end, tid);
+                stage_gather(p, t, valid, r, cs, m_end, tid);
+                stage_store(s_tag, t, valid, cs, m_end, tid);
+            } else {
+                for (uint32_t i = tid; i < kChunk && cs + i < m_end; i += kCandPerBlock) {
+                    const uint32_t r = p.mark_read[cs + i];
+                    s_tag[i] = r == kEmpty ? kUntagged : p.read_tag[r];
+                }
+            }
+            __syncthreads();
+            STAMP(0, 2);
+            // ---- consume: each thread walks its candidate's part of this chunk ----------------------
+            uint32_t lo = max(my_b, cs);
+            const uint32_t hi = min(my_e, cs + (uint32_t)kChunk);
+            if (!kept || (p.dbg & 4)) lo = hi;
+            consume_range(st, s_tag, lo, hi, cs);
+            STAMP(0, 3);
+            __syncthreads();
+        }
+        STAMP(0, 4);
+        const uint32_t seed = decide_store(p, sh, tile, live, c0 + j, active, divzero, st, my_e - my_b, svread, refread);
+        sh.seed[j] = seed;
         __syncthreads();
+        seeds_tile(p, sh, tile, tid, c0 + tid, is_start);
+        STAMP(0, 6);
+        if (!DYN) break;
+        __syncthreads();                                           // the tile's LDS is reused
     }
-    STAMP(0, 4);
-    const uint32_t seed = decide_store(p, sh, blockIdx.x, live, c0 + j, active, divzero, st, my_e - my_b, svread, refread);
-    sh.seed[j] = seed;
-    __syncthreads();
-    seeds_tile(p, sh, blockIdx.x, tid, c0 + tid, is_start);
-    STAMP(0, 6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,6 +617,8 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         rec0 = recs[my_lo];
         if (my_lo > b_lo) recp = recs[my_lo - 1];
     }
+    // (the edge tiles' counts ride in the same round trip)
+    const uint32_t cnt_lo = (uint32_t)recs[b_lo].x, cnt_hi = (uint32_t)recs[b_hi].x;
     STAMP(1, 4);
     uint32_t prev0 = kEmpty;
     if (my_lo < my_hi && my_lo > b_lo && (uint32_t)recp.x) {
@@ -627,7 +635,6 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     };
     // A tile on the contig's edge holds entries of two contigs: its owner walks it -- unless it is long, then the
     // workgroup filters it together (one scan), in front of / behind the tiles in between.
-    const uint32_t cnt_lo = (uint32_t)recs[b_lo].x, cnt_hi = (uint32_t)recs[b_hi].x;
     const bool lo_coop = !interior(b_lo) && cnt_lo > kLongCnt;
     const bool hi_coop = b_hi != b_lo && !interior(b_hi) && cnt_hi > kLongCnt;
     auto edge_tile = [&](uint32_t b, uint32_t cnt, uint32_t base) -> uint32_t {
@@ -712,10 +719,11 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     STAMP(1, 6);
     {
         const uint32_t nl = min(s_nlong, kLongTiles);
-        for (uint32_t w = 0; w < nl; ++w) {
+        // (one wave per long tile: the tiles' round trips overlap instead of queueing behind each other)
+        for (uint32_t w = tid >> 6; w < nl; w += kSortThreads / 64) {
             const uint32_t b = s_long[w][0], at = s_long[w][1];
             const uint32_t cnt = (uint32_t)recs[b].x;
-            for (uint32_t j = 3 + tid; j < cnt; j += kSortThreads) {
+            for (uint32_t j = 3 + (tid & 63u); j < cnt; j += 64u) {
                 const uint32_t ps = (uint32_t)p.seed_ent[(size_t)b * kCandPerBlock + j];
                 if (at + j - 3 < kSortLds) s_key[at + j - 3] = ps;
                 glist[at + j - 3] = ps;
@@ -907,44 +915,10 @@ __device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *o
     }
 }
 
-template <bool DYN = false>
-__global__ __launch_bounds__(256) void ef_finalize(const Params p)
+// one candidate's part of ef_finalize (everything after the tile's seed array is staged)
+__device__ __forceinline__ void finalize_candidate(const Params &p, uint32_t c, uint8_t code, uint32_t ps_in, uint32_t k0, bool lds_mode,
+                                                   const uint32_t *s_one, uint32_t n_lds, uint32_t any_empty)
 {
-    __shared__ uint32_t s_one[kOneLds];
-    __shared__ uint32_t s_meta[4];                             // k0, n_one[k0] or ~0 (not LDS mode), any_empty, seed base of k0
-    const uint32_t tid = threadIdx.x;
-    STAMP(2, 0);
-    const uint32_t c0 = blockIdx.x * 256u;
-    const uint32_t c = c0 + tid;
-    const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
-    if (DYN && c0 >= n_cands) return;
-    const bool live = c < n_cands;
-    const uint8_t code = live ? p.out_pred[c] : 0;
-    const uint32_t ps_in = live ? p.out_ps[c] : 0;
-    if (tid == 0) {
-        const uint32_t last = min(c0 + 255u, n_cands - 1);
-        const uint32_t k0 = p.blk_ctg[blockIdx.x];
-        uint32_t k1 = k0;
-        while (last >= p.ctg_off[k1 + 1]) ++k1;
-        uint32_t any = 0;
-        for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0);
-        const uint32_t n0 = p.n_one[k0];
-        s_meta[0] = k0;
-        s_meta[1] = (k0 == k1 && n0 > 0 && n0 <= kOneLds) ? n0 : kEmpty;
-        s_meta[2] = any;
-        s_meta[3] = p.ctg_off[k0] + k0 + 1;
-    }
-    __syncthreads();
-    STAMP(2, 1);
-    const uint32_t k0 = s_meta[0], n_lds = s_meta[1], any_empty = s_meta[2];
-    const bool lds_mode = n_lds != kEmpty;
-    if (lds_mode) {
-        const uint32_t *src = p.onebuf + s_meta[3];
-        for (uint32_t i = tid; i < n_lds; i += 256u) s_one[i] = src[i];
-        __syncthreads();
-    }
-    STAMP(2, 2);
-    if (!live) return;
     if (code < 4 && !any_empty) return;                        // already final
     const uint32_t *one;
     uint32_t n_one;
@@ -1002,6 +976,50 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
     // kNeedNearest
     p.out_pred[c] = code & 3;
     p.out_ps[c] = nearest_ps(one, n_one, p.cand_pos[c]);
+}
+
+template <bool DYN = false>
+__global__ __launch_bounds__(256) void ef_finalize(const Params p)
+{
+    __shared__ uint32_t s_one[kOneLds];
+    __shared__ uint32_t s_meta[4];                             // k0, n_one[k0] or ~0 (not LDS mode), any_empty, seed base of k0
+    const uint32_t tid = threadIdx.x;
+    STAMP(2, 0);
+    const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
+    // (device-planned runs stride over the real tiles like ef_classify)
+    for (uint32_t tile = blockIdx.x; !DYN || tile * 256u < n_cands; tile += gridDim.x) {
+        const uint32_t c0 = tile * 256u;
+        const uint32_t c = c0 + tid;
+        const bool live = c < n_cands;
+        const uint8_t code = live ? p.out_pred[c] : 0;
+        const uint32_t ps_in = live ? p.out_ps[c] : 0;
+        if (tid == 0) {
+            const uint32_t last = min(c0 + 255u, n_cands - 1);
+            const uint32_t k0 = p.blk_ctg[tile];
+            uint32_t k1 = k0;
+            while (last >= p.ctg_off[k1 + 1]) ++k1;
+            uint32_t any = 0;
+            for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0);
+            const uint32_t n0 = p.n_one[k0];
+            s_meta[0] = k0;
+            s_meta[1] = (k0 == k1 && n0 > 0 && n0 <= kOneLds) ? n0 : kEmpty;
+            s_meta[2] = any;
+            s_meta[3] = p.ctg_off[k0] + k0 + 1;
+        }
+        __syncthreads();
+        STAMP(2, 1);
+        const uint32_t k0 = s_meta[0], n_lds = s_meta[1], any_empty = s_meta[2];
+        const bool lds_mode = n_lds != kEmpty;
+        if (lds_mode) {
+            const uint32_t *src = p.onebuf + s_meta[3];
+            for (uint32_t i = tid; i < n_lds; i += 256u) s_one[i] = src[i];
+            __syncthreads();
+        }
+        STAMP(2, 2);
+        if (live) finalize_candidate(p, c, code, ps_in, k0, lds_mode, s_one, n_lds, any_empty);
+        if (!DYN) break;
+        __syncthreads();                                       // s_meta / s_one are reused
+    }
 }
 
 // plan time: ctg_start[c] = 1 for the first candidate of every non-empty contig
@@ -1377,12 +1395,14 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     p.out_pred = out_pred; p.out_ps = out_ps;
     p.dbg = ctx->dbg;
     p.stamps = ctx->d_stamps;
+    // the kernels stride over the real tiles: an eighth of the bound's tiles (SV-like data: ~10 marks per candidate), at least 512
+    const uint32_t G = B < 512u ? B : (B / 8u > 512u ? B / 8u : 512u);
     if (((uintptr_t)pr->mark_read & 15) == 0)
-        hipLaunchKernelGGL((ef_classify<true, true>), dim3(B), dim3(kCandPerBlock), 0, stream, p);
+        hipLaunchKernelGGL((ef_classify<true, true>), dim3(G), dim3(kCandPerBlock), 0, stream, p);
     else
-        hipLaunchKernelGGL((ef_classify<false, true>), dim3(B), dim3(kCandPerBlock), 0, stream, p);
+        hipLaunchKernelGGL((ef_classify<false, true>), dim3(G), dim3(kCandPerBlock), 0, stream, p);
     hipLaunchKernelGGL(ef_seed_sort, dim3(K), dim3(kSortThreads), 0, stream, p);
-    hipLaunchKernelGGL(ef_finalize<true>, dim3((C + 255) / 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(ef_finalize<true>, dim3(G), dim3(256), 0, stream, p);
     HIP_TRY(ctx, hipGetLastError());
     ctx->pending_check = true;
     return DUET_OK;

@@ -14,6 +14,7 @@ constexpr int kScanTile = kScanThreads * kScanItems;
 // 1024 threads per 4096-key tile (the tile of rx_scatter): four keys per thread, so that a small input -- one tile per CU at
 // 1 M keys -- still has 16 wavefronts per CU loading
 constexpr int kRxHistThreads = 1024;
+constexpr uint32_t kRxTotalsTiles = 1024;             // up to this many tiles rx_hist also accumulates the digit totals (see radix_sort_pairs)
 constexpr int kDtotCopies = 8;                        // the digit totals are kept in 8 copies (by tile index): 8x fewer atomics per address
 __global__ __launch_bounds__(kRxHistThreads) void rx_hist(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t dmask, uint32_t nb,
                                                           uint32_t *hist /* [256][nb] */, uint32_t *dtot /* [256] digit totals, zero on entry */)
@@ -358,18 +359,20 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
 // spart: ceil(256 * ceil(n / kRxTile) / kScanTile) + 1 words.
 inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, uint32_t n, uint32_t key_bits,
                              uint32_t *hist, uint32_t *spart, uint32_t *dtot /* [kDtotCopies][256], zero between sorts */, hipStream_t st,
-                             uint64_t **keys_out, uint32_t **vals_out, uint64_t **keys_spare, bool force_scan = false)
+                             uint64_t **keys_out, uint32_t **vals_out, uint64_t **keys_spare, bool force_scan = false,
+                             bool first_hist_done = false /* the producer of the keys already filled hist (and dtot) for digit 0 */)
 {
     const uint32_t nb_rx = (n + kRxTile - 1) / kRxTile, nh = 256 * nb_rx;
     // up to 1024 tiles (4 M keys) the tile offsets take ONE launch: rx_hist also accumulates the digit totals (atomics, a
     // few hundred per address) and rx_offsets scans one digit row per workgroup; beyond, the atomics would cost more
     // than the launch they save (2e7 keys: +40 us per pass) and the generic scan does it
-    if (nb_rx > 1024 || force_scan) dtot = nullptr;
+    if (nb_rx > kRxTotalsTiles || force_scan) dtot = nullptr;
     uint64_t *kin = keysA, *kout = keysB;
     uint32_t *vin = valsA, *vout = valsB;
     for (uint32_t shift = 0; shift < key_bits; shift += 8) {
         const uint32_t dmask = key_bits - shift >= 8 ? 255u : (1u << (key_bits - shift)) - 1u;
-        hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxHistThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist, dtot);
+        if (shift != 0 || !first_hist_done)
+            hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxHistThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist, dtot);
         if (dtot) hipLaunchKernelGGL(rx_offsets, dim3(256), dim3(256), 0, st, hist, nb_rx, (const uint32_t *)dtot);
         else launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st, nullptr, force_scan);   // in place: scan_apply reads a tile before writing it
         if (valsA)

@@ -8,6 +8,9 @@ from duet_amd.devmem import DeviceSvim
 wait = 'wait' in sys.argv[1:]
 big = 'big' in sys.argv[1:]          # 2e7 marks over 24 contigs instead of config 2's 1e6
 ctx = _lib.Context(0)
+for a in sys.argv[1:]:
+    if a.startswith('dbg='):
+        ctx.set_debug(int(a[4:], 0))      # DUET_DBG_* bits of include/duet_ef.h, e.g. dbg=0x200
 contigs = synth.bench_genome(20000000, 3) if big else [synth.bench_contig('1', 200000, 100000, 1)]
 soa = engine.soa_from_synth(contigs)
 marks = synth.raw_marks(contigs, 1, reads_of=soa)
