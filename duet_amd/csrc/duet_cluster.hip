@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -273,6 +274,25 @@ __global__ __launch_bounds__(1024) void part_spine(PartSum *tiles, uint32_t nb, 
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (nb + 1023u) / 1024u, lo = min(nb, tid * per), hi = min(nb, lo + per);
     PartSum acc{kNoHead, 0, 0};
+    constexpr uint32_t kHold = 16;                             // summaries a thread keeps in registers (inputs up to 33 M marks)
+    if (per <= kHold) {
+        // all of the thread's loads at once: one round trip instead of one per summary (2 x 10 of them at 2e7 marks)
+        PartSum mine[kHold];
+#pragma unroll
+        for (uint32_t j = 0; j < kHold; ++j) mine[j] = tiles[min(lo + j, nb - 1u)];
+#pragma unroll
+        for (uint32_t j = 0; j < kHold; ++j)
+            if (lo + j < hi) acc = part_combine(acc, mine[j], pm);
+        PartSum run = part_block_exscan<1024>(acc, pm, s_w);
+#pragma unroll
+        for (uint32_t j = 0; j < kHold; ++j) {
+            if (lo + j < hi) {
+                tiles[lo + j] = run;
+                run = part_combine(run, mine[j], pm);
+            }
+        }
+        return;
+    }
     for (uint32_t t = lo; t < hi; ++t) acc = part_combine(acc, tiles[t], pm);
     PartSum run = part_block_exscan<1024>(acc, pm, s_w);
     for (uint32_t t = lo; t < hi; ++t) {
@@ -355,26 +375,31 @@ __device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <
 __global__ __launch_bounds__(1024) void cl_classes(const ClParams p, uint32_t *lists /* [kClasses][M] */, uint32_t *counts /* [kClasses] */)
 {
     __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
-    if (threadIdx.x < kClasses) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = part < *p.n_parts;
-    const int cls = live ? size_class(p.part_start[part + 1] - p.part_start[part]) : -1;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t at = 0;
+    // (the partitions' number lives on the device: the grid is a fraction of its bound -- the marks -- and strides)
+    const uint32_t n_parts = *p.n_parts;
+    for (uint32_t tile = blockIdx.x; tile * blockDim.x < n_parts; tile += gridDim.x) {
+        if (threadIdx.x < kClasses) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t part = tile * blockDim.x + threadIdx.x;
+        const bool live = part < n_parts;
+        const int cls = live ? size_class(p.part_start[part + 1] - p.part_start[part]) : -1;
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t at = 0;
 #pragma unroll
-    for (int c = 0; c < kClasses; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (!m) continue;
-        uint32_t base = 0;
-        if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&s_cnt[c], (uint32_t)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1, 64);
-        if (cls == c) at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int c = 0; c < kClasses; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (!m) continue;
+            uint32_t base = 0;
+            if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&s_cnt[c], (uint32_t)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1, 64);
+            if (cls == c) at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (threadIdx.x < kClasses && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+        __syncthreads();
+        if (cls >= 0) lists[(size_t)cls * p.M + s_base[cls] + at] = part;
+        __syncthreads();                                     // s_cnt / s_base are reused
     }
-    __syncthreads();
-    if (threadIdx.x < kClasses && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (cls >= 0) lists[(size_t)cls * p.M + s_base[cls] + at] = part;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1358,37 +1383,50 @@ __global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32
 // partition's start, become the candidates cbase[part] ...; neighbouring partitions write neighbouring candidates
 __global__ void cl_emit(const ClParams p)
 {
-    const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
-    if (part == 0) p.cand_off[0] = 0;
-    if (part >= *p.n_parts) return;
-    const uint32_t s = p.part_start[part], nc = p.pc[part], c0 = p.cbase[part];
-    const uint64_t hi = (p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits;                        // contig | type, straight from the sorted key
-    const uint32_t k = (uint32_t)(hi >> p.type_bits), type = (uint32_t)(hi & ((1ull << p.type_bits) - 1ull));
-    uint32_t d_lo = 0, nb = 0;
-    if (p.sv_svread) {
-        d_lo = p.sv_depth_off[k];
-        nb = p.sv_depth_off[k + 1] - d_lo;
-    }
-    for (uint32_t c = 0; c < nc; ++c) {
-        const uint4 rec = p.e_rec[s + c];
-        const uint32_t info = rec.x, pos = rec.y, cand = c0 + c;
-        p.cand_off[cand + 1] = s + (info >> 8);
-        p.cand_contig[cand] = (uint16_t)k;
-        p.cand_type[cand] = (uint8_t)type;
-        p.cand_pos[cand] = pos;
-        p.cand_span[cand] = rec.z;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.cand_off[0] = 0;
+    const uint32_t n_parts = *p.n_parts;
+    // (a grid of a fraction of the bound -- the marks -- strides over the partitions: see cl_classes)
+    for (uint32_t part = blockIdx.x * blockDim.x + threadIdx.x; part < n_parts; part += gridDim.x * blockDim.x) {
+        const uint32_t s = p.part_start[part], nc = p.pc[part], c0 = p.cbase[part];
+        const uint64_t hi = (p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits;                        // contig | type, straight from the sorted key
+        const uint32_t k = (uint32_t)(hi >> p.type_bits), type = (uint32_t)(hi & ((1ull << p.type_bits) - 1ull));
+        uint32_t d_lo = 0, nb = 0;
         if (p.sv_svread) {
-            // what a caller VCF would have carried: support = members, reference reads = depth(contig, pos) - support
-            const uint32_t support = (info >> 8) - (info & 0xFFu);                  // a cluster's end - its first member's rank
-            uint32_t d = 0;
-            if (nb) {
-                uint32_t bin = pos / p.sv_depth_bin;
-                bin = bin < nb ? bin : nb - 1;
-                d = p.sv_depth[d_lo + bin];
+            d_lo = p.sv_depth_off[k];
+            nb = p.sv_depth_off[k + 1] - d_lo;
+        }
+        // four clusters at a time, their loads side by side: records first, then the depth bins the records' positions select
+        // (one cluster per trip made a partition's clusters queue behind each other's two round trips)
+        for (uint32_t cb = 0; cb < nc; cb += 4) {
+            uint4 rec[4];
+            uint32_t d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rec[j] = p.e_rec[s + min(cb + j, nc - 1u)];
+            if (p.sv_svread) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t bin = rec[j].y / p.sv_depth_bin;
+                    bin = bin < nb ? bin : nb - 1;
+                    d[j] = nb ? p.sv_depth[d_lo + bin] : 0u;
+                }
             }
-            p.sv_svread[cand] = support;
-            p.sv_refread[cand] = d > support ? d - support : 0u;
-            p.sv_gt[cand] = 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (cb + j >= nc) break;
+                const uint32_t info = rec[j].x, cand = c0 + cb + j;
+                p.cand_off[cand + 1] = s + (info >> 8);
+                p.cand_contig[cand] = (uint16_t)k;
+                p.cand_type[cand] = (uint8_t)type;
+                p.cand_pos[cand] = rec[j].y;
+                p.cand_span[cand] = rec[j].z;
+                if (p.sv_svread) {
+                    // what a caller VCF would have carried: support = members, reference reads = depth(contig, pos) - support
+                    const uint32_t support = (info >> 8) - (info & 0xFFu);                  // a cluster's end - its first member's rank
+                    p.sv_svread[cand] = support;
+                    p.sv_refread[cand] = d[j] > support ? d[j] - support : 0u;
+                    p.sv_gt[cand] = 1;
+                }
+            }
         }
     }
 }
@@ -1565,7 +1603,10 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     }
     p.fast = (pr->max_dist >= 0 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
-    hipLaunchKernelGGL(cl_classes, dim3((M + 1023) / 1024), dim3(1024), 0, st, p, lists, cnts);
+    // launches over the partitions, whose number only the device knows: an eighth of the bound (SV-like data: ~10 marks per
+    // partition), at least 256 workgroups, striding
+    const uint32_t g_parts = std::min((M + 1023u) / 1024u, std::max(256u, (M + 1023u) / 1024u / 8u));
+    hipLaunchKernelGGL(cl_classes, dim3(g_parts), dim3(1024), 0, st, p, lists, cnts);
     const uint32_t gridw = M < 32768u ? M : 32768u;
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
@@ -1613,9 +1654,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
                        (const uint32_t *)(small ? lists + 4 * (size_t)M : work.rank_list + 4 * (size_t)M),
                        (const uint32_t *)(small ? cnts + 4 : work.rank_count + 4));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
-    launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort);       // cbase[part] = its first candidate
+    launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
     p.cbase = cbase;
-    hipLaunchKernelGGL(cl_emit, g256, b256, 0, st, p);
+    hipLaunchKernelGGL(cl_emit, dim3(std::min(g256.x, std::max(1024u, g256.x / 8u))), b256, 0, st, p);
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
         uint32_t h[32];

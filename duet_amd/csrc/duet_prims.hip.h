@@ -105,12 +105,22 @@ struct StorePlain {
     uint32_t *out;
     __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { out[i] = v; }
 };
+// n_dyn (may be null): the real element count when the host only knows the bound n -- tiles past it hold nothing (the neutral
+// element, for both operations) and are not read
 template <int OP, class Load>
-__global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint32_t n, uint32_t *part, uint32_t *zero14)
+__global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint32_t n, uint32_t *part, uint32_t *zero14, const uint32_t *n_dyn)
 {
     __shared__ uint32_t s_w[kScanThreads / 64];
     const uint32_t tid = threadIdx.x;
     if (zero14 && blockIdx.x == 0 && tid < 14) zero14[tid] = 0;     // (scans without a spine launch: see scan_spine)
+    if (n_dyn) {
+        const uint32_t nd = *n_dyn;
+        n = nd < n ? nd : n;
+        if (blockIdx.x * kScanTile >= n) {
+            if (tid == 0) part[blockIdx.x] = 0;
+            return;
+        }
+    }
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     uint32_t acc = 0;
 #pragma unroll
@@ -127,39 +137,56 @@ __global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint3
     }
 }
 
-// single block: part[i] <- combination of part[0..i) (exclusive); *total <- combination of everything
+// single block: part[i] <- combination of part[0..i) (exclusive); *total <- combination of everything.
+// Thread t owns a contiguous run of `per` entries: up to 16 of them are loaded at once (one round trip), combined in
+// registers, the runs' totals scanned across the block, and the entries written back -- no loop of block-wide rounds.
 template <int OP>
 __global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, uint32_t *total, uint32_t *zero14)
 {
     if (zero14 && threadIdx.x < 14) zero14[threadIdx.x] = 0;     // the work-list counters of the kernels that follow
     __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < n ? part[i] : 0u;
-        uint32_t x = v;
+    const uint32_t per = (n + 1023u) / 1024u, lo = min(n, tid * per), hi = min(n, lo + per);
+    constexpr uint32_t kHold = 16;
+    uint32_t mine[kHold];
+    uint32_t acc = 0;
+    if (per <= kHold) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 64);
-            if ((int)lane >= d) x = scan_op<OP>(x, y);
-        }
-        if (lane == 63) s_w[wave] = x;
-        __syncthreads();
-        uint32_t before = s_carry;
-        for (uint32_t w = 0; w < wave; ++w) before = scan_op<OP>(before, s_w[w]);
-        // exclusive value for element i: everything before it
-        uint32_t excl = before;
-        const uint32_t prev_in_wave = __shfl_up(x, 1, 64);
-        if (lane > 0) excl = scan_op<OP>(before, prev_in_wave);
-        if (i < n) part[i] = excl;
-        __syncthreads();
-        if (tid == 1023) s_carry = scan_op<OP>(before, x);
-        __syncthreads();
+        for (uint32_t j = 0; j < kHold; ++j) mine[j] = n ? part[min(lo + j, n - 1u)] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kHold; ++j)
+            if (lo + j < hi) acc = scan_op<OP>(acc, mine[j]);
+    } else {
+        for (uint32_t t = lo; t < hi; ++t) acc = scan_op<OP>(acc, part[t]);
     }
-    if (tid == 0 && total) *total = s_carry;
+    uint32_t x = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x = scan_op<OP>(x, y);
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t w = 0; w < wave; ++w) run = scan_op<OP>(run, s_w[w]);
+    const uint32_t prev = __shfl_up(x, 1, 64);
+    if (lane > 0) run = scan_op<OP>(run, prev);
+    if (tid == 1023 && total) *total = scan_op<OP>(run, acc);
+    if (per <= kHold) {
+#pragma unroll
+        for (uint32_t j = 0; j < kHold; ++j) {
+            if (lo + j < hi) {
+                part[lo + j] = run;
+                run = scan_op<OP>(run, mine[j]);
+            }
+        }
+    } else {
+        for (uint32_t t = lo; t < hi; ++t) {
+            const uint32_t v = part[t];
+            part[t] = run;
+            run = scan_op<OP>(run, v);
+        }
+    }
 }
 
 // out[i] = exclusive sum (OP 0) / inclusive max (OP 1) of in[0..i] given the per-tile carries in part[].
@@ -169,11 +196,17 @@ __global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, u
 constexpr uint32_t kSelfSpine = 2048;
 template <int OP, class Load, class Store, bool SELF>
 __global__ __launch_bounds__(kScanThreads) void scan_apply(const Load in, uint32_t n, const uint32_t *part, const Store out,
-                                                           uint32_t *total)
+                                                           uint32_t *total, const uint32_t *n_dyn)
 {
     __shared__ uint32_t s_w[kScanThreads / 64];
     __shared__ uint32_t s_c[kScanThreads / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (n_dyn) {
+        const uint32_t nd = *n_dyn;
+        n = nd < n ? nd : n;
+        // a tile past the real count has nothing to store; only the last block of a spine-less scan still has the total to deliver
+        if (blockIdx.x * kScanTile >= n && !(SELF && total && blockIdx.x == gridDim.x - 1)) return;
+    }
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     uint32_t v[kScanItems];
     uint32_t acc = 0;
@@ -338,19 +371,20 @@ uint32_t bits_for(uint64_t max_value)
 
 template <int OP, class Load, class Store>
 void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uint32_t *total, hipStream_t st,
-                 uint32_t *zero14 = nullptr, bool force_spine = false /* tests: the path of more than kSelfSpine tiles */)
+                 uint32_t *zero14 = nullptr, bool force_spine = false /* tests: the path of more than kSelfSpine tiles */,
+                 const uint32_t *n_dyn = nullptr /* device: the real element count, n being its bound */)
 {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
     if (nb >= 1 && nb <= kSelfSpine && !force_spine) {
-        hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, zero14);
+        hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, zero14, n_dyn);
         hipLaunchKernelGGL((scan_apply<OP, Load, Store, true>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out,
-                           total);
+                           total, n_dyn);
         return;
     }
-    hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, (uint32_t *)nullptr);
+    hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, (uint32_t *)nullptr, n_dyn);
     hipLaunchKernelGGL(scan_spine<OP>, dim3(1), dim3(1024), 0, st, part, nb, total, zero14);
     hipLaunchKernelGGL((scan_apply<OP, Load, Store, false>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out,
-                       (uint32_t *)nullptr);
+                       (uint32_t *)nullptr, n_dyn);
 }
 
 // stable LSD radix sort of n (key, value) pairs -- or, with null value buffers, of the keys alone -- on the low key_bits of
