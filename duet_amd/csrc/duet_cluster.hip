@@ -273,32 +273,30 @@ __global__ __launch_bounds__(1024) void part_spine(PartSum *tiles, uint32_t nb, 
     __shared__ PartSum s_w[1024 / 64 + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (nb + 1023u) / 1024u, lo = min(nb, tid * per), hi = min(nb, lo + per);
+    // a thread's summaries go through registers sixteen at a time: their loads leave together (one round trip per sixteen
+    // instead of one per summary -- 2 x 10 dependent trips at 2e7 marks)
+    constexpr uint32_t kHold = 16;
     PartSum acc{kNoHead, 0, 0};
-    constexpr uint32_t kHold = 16;                             // summaries a thread keeps in registers (inputs up to 33 M marks)
-    if (per <= kHold) {
-        // all of the thread's loads at once: one round trip instead of one per summary (2 x 10 of them at 2e7 marks)
+    for (uint32_t t0 = lo; t0 < hi; t0 += kHold) {
         PartSum mine[kHold];
 #pragma unroll
-        for (uint32_t j = 0; j < kHold; ++j) mine[j] = tiles[min(lo + j, nb - 1u)];
+        for (uint32_t j = 0; j < kHold; ++j) mine[j] = tiles[min(t0 + j, hi - 1u)];
 #pragma unroll
         for (uint32_t j = 0; j < kHold; ++j)
-            if (lo + j < hi) acc = part_combine(acc, mine[j], pm);
-        PartSum run = part_block_exscan<1024>(acc, pm, s_w);
+            if (t0 + j < hi) acc = part_combine(acc, mine[j], pm);
+    }
+    PartSum run = part_block_exscan<1024>(acc, pm, s_w);
+    for (uint32_t t0 = lo; t0 < hi; t0 += kHold) {
+        PartSum mine[kHold];
+#pragma unroll
+        for (uint32_t j = 0; j < kHold; ++j) mine[j] = tiles[min(t0 + j, hi - 1u)];
 #pragma unroll
         for (uint32_t j = 0; j < kHold; ++j) {
-            if (lo + j < hi) {
-                tiles[lo + j] = run;
+            if (t0 + j < hi) {
+                tiles[t0 + j] = run;
                 run = part_combine(run, mine[j], pm);
             }
         }
-        return;
-    }
-    for (uint32_t t = lo; t < hi; ++t) acc = part_combine(acc, tiles[t], pm);
-    PartSum run = part_block_exscan<1024>(acc, pm, s_w);
-    for (uint32_t t = lo; t < hi; ++t) {
-        const PartSum mine = tiles[t];
-        tiles[t] = run;
-        run = part_combine(run, mine, pm);
     }
 }
 
@@ -515,7 +513,7 @@ struct ExactSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = NCAP;
     double d[SUBS][NMAX * (NMAX - 1) / 2];                   // upper triangle, row by row
     uint32_t pos[SUBS][NMAX], span[SUBS][NMAX];
-    uint8_t size[SUBS][NMAX], row[SUBS][NMAX];
+    uint8_t row[SUBS][NMAX];
 };
 
 template <int GROUP, int R, bool WHOLE = false, int NCAP = GROUP * R>
@@ -555,7 +553,6 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
                 const uint3 q = load_rec(p, a);
                 X.pos[sub][ci] = q.x;
                 X.span[sub][ci] = q.y;
-                X.size[sub][ci] = 1;
                 X.row[sub][ci] = (uint8_t)row;
             }
             filled += (uint32_t)__popcll(bal);
@@ -580,11 +577,12 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
         }
         __syncthreads();
         double rmin[R];
-        uint32_t rarg[R], lab[R];
+        uint32_t rarg[R], lab[R], csize[R];
         bool alive[R], stale[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t k = sl + r * GROUP;
+            csize[r] = 1;
             rmin[r] = inf;
             rarg[r] = kNoCol;
             lab[r] = k;
@@ -633,29 +631,49 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
             }
             if (__ballot(do_merge)) {
                 const uint32_t a = g, b = info & 0xFFFFu;
+                // cluster sizes live with their rows' lanes (csize[r] of the lane that owns the row): a lane read per merge
+                // instead of two LDS round trips at the head of the merge's dependent chain
                 uint32_t za = 0, zb = 0;
-                if (do_merge) { za = X.size[sub][a]; zb = X.size[sub][b]; }
+                if (GROUP == 64) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t va = (uint32_t)__builtin_amdgcn_readlane((int)csize[r], (int)(a % GROUP));
+                        const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)csize[r], (int)(b % GROUP));
+                        za = (uint32_t)r == a / GROUP ? va : za;
+                        zb = (uint32_t)r == b / GROUP ? vb : zb;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t va = (uint32_t)__shfl((int)csize[r], do_merge ? (int)(sub * GROUP + a % GROUP) : (int)lane, 64);
+                        const uint32_t vb = (uint32_t)__shfl((int)csize[r], do_merge ? (int)(sub * GROUP + b % GROUP) : (int)lane, 64);
+                        za = (uint32_t)r == a / GROUP ? va : za;
+                        zb = (uint32_t)r == b / GROUP ? vb : zb;
+                    }
+                }
                 const double na = (double)za, nb = (double)zb;
                 double cv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t k = sl + r * GROUP;
-                    cv[r] = inf;
-                    if (do_merge && alive[r] && k != a && k != b) {
-                        const uint32_t ia = k < a ? tri(k, a) : tri(a, k);
+                    const bool act = do_merge && alive[r] && k != a && k != b;
+                    const bool ka = k < a;
+                    double v = inf;
+                    if (act) {
+                        const uint32_t ia = ka ? tri(k, a) : tri(a, k);
                         const double da = D[ia], db = D[k < b ? tri(k, b) : tri(b, k)];
-                        const double v = (na * da + nb * db) / (na + nb);
+                        v = (na * da + nb * db) / (na + nb);
                         D[ia] = v;
-                        if (k < a) {
-                            const bool hit = rarg[r] == a || rarg[r] == b;
-                            if (v < rmin[r]) { rmin[r] = v; rarg[r] = a; stale[r] = false; }
-                            else if (v == rmin[r]) { if (!stale[r] && (hit || a < rarg[r])) rarg[r] = a; }
-                            else if (hit) stale[r] = true;
-                        } else {
-                            if (k < b && rarg[r] == b) stale[r] = true;
-                            cv[r] = v;
-                        }
                     }
+                    // the row's cached minimum, as selects (no divergent control flow behind the division)
+                    const bool upd = act && ka, hit = rarg[r] == a || rarg[r] == b;
+                    const bool lt = upd && v < rmin[r], eq = upd && v == rmin[r];
+                    const bool take = lt || (eq && !stale[r] && (hit || a < rarg[r]));
+                    const bool spoil = (upd && !lt && !eq && hit) || (act && !ka && k < b && rarg[r] == b);
+                    rmin[r] = lt ? v : rmin[r];
+                    rarg[r] = take ? a : rarg[r];
+                    stale[r] = lt ? false : (spoil ? true : stale[r]);
+                    cv[r] = (act && !ka) ? v : inf;
                     if (do_merge && lab[r] == b) lab[r] = a;
                 }
                 double nv;
@@ -664,10 +682,9 @@ __device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *li
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t k = sl + r * GROUP;
-                    if (do_merge && k == a) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; }
+                    if (do_merge && k == a) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; csize[r] = za + zb; }
                     if (do_merge && k == b) alive[r] = false;
                 }
-                if (do_merge && sl == 0) X.size[sub][a] = (uint8_t)(za + zb);
             }
             __syncthreads();
         }

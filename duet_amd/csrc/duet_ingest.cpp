@@ -837,6 +837,11 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
     auto work_b = [&](int t) {
         PartB &o = pb[t];
         const size_t lo = C * t / TB, hi = C * (t + 1) / TB;
+        // (collected in a vector of the thread's own and handed over at the end: the pb[] headers of all threads share a
+        // cache line, and a push_back per mark through them made four threads as slow as one)
+        std::vector<uint32_t> marks;
+        marks.reserve((hi - lo) * 12);
+        struct HandOver { std::vector<uint32_t> &from, &to; ~HandOver() { to.swap(from); } } hand_over{marks, o.marks};
         int k = 0;
         for (size_t c = lo; c < hi; ++c) {
             while (c >= g->cand_ctg_off[k + 1]) ++k;
@@ -890,7 +895,7 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
                     for (int q = 0; q < nb; ++q) tab.prefetch_entry(hh[q]);
                     for (int q = 0; q < nb; ++q) {
                         const int idx = tab.find_hashed(nm[q].p, nm[q].n, hh[q]);
-                        o.marks.push_back(idx < 0 ? kAbsent : rbase + (uint32_t)idx);
+                        marks.push_back(idx < 0 ? kAbsent : rbase + (uint32_t)idx);
                     }
                     cnt += (uint32_t)nb;
                 }

@@ -138,8 +138,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_reduce(const Load in, uint3
 }
 
 // single block: part[i] <- combination of part[0..i) (exclusive); *total <- combination of everything.
-// Thread t owns a contiguous run of `per` entries: up to 16 of them are loaded at once (one round trip), combined in
-// registers, the runs' totals scanned across the block, and the entries written back -- no loop of block-wide rounds.
+// Thread t owns a contiguous run of entries and takes them through registers sixteen at a time (their loads leave
+// together: one round trip per sixteen), the runs' totals are scanned across the block, a second sweep writes the
+// entries back -- no loop of block-wide rounds.
 template <int OP>
 __global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, uint32_t *total, uint32_t *zero14)
 {
@@ -148,16 +149,14 @@ __global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, u
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per = (n + 1023u) / 1024u, lo = min(n, tid * per), hi = min(n, lo + per);
     constexpr uint32_t kHold = 16;
-    uint32_t mine[kHold];
     uint32_t acc = 0;
-    if (per <= kHold) {
+    for (uint32_t t0 = lo; t0 < hi; t0 += kHold) {
+        uint32_t mine[kHold];
 #pragma unroll
-        for (uint32_t j = 0; j < kHold; ++j) mine[j] = n ? part[min(lo + j, n - 1u)] : 0u;
+        for (uint32_t j = 0; j < kHold; ++j) mine[j] = part[min(t0 + j, hi - 1u)];
 #pragma unroll
         for (uint32_t j = 0; j < kHold; ++j)
-            if (lo + j < hi) acc = scan_op<OP>(acc, mine[j]);
-    } else {
-        for (uint32_t t = lo; t < hi; ++t) acc = scan_op<OP>(acc, part[t]);
+            if (t0 + j < hi) acc = scan_op<OP>(acc, mine[j]);
     }
     uint32_t x = acc;
 #pragma unroll
@@ -172,19 +171,16 @@ __global__ __launch_bounds__(1024) void scan_spine(uint32_t *part, uint32_t n, u
     const uint32_t prev = __shfl_up(x, 1, 64);
     if (lane > 0) run = scan_op<OP>(run, prev);
     if (tid == 1023 && total) *total = scan_op<OP>(run, acc);
-    if (per <= kHold) {
+    for (uint32_t t0 = lo; t0 < hi; t0 += kHold) {
+        uint32_t mine[kHold];
+#pragma unroll
+        for (uint32_t j = 0; j < kHold; ++j) mine[j] = part[min(t0 + j, hi - 1u)];
 #pragma unroll
         for (uint32_t j = 0; j < kHold; ++j) {
-            if (lo + j < hi) {
-                part[lo + j] = run;
+            if (t0 + j < hi) {
+                part[t0 + j] = run;
                 run = scan_op<OP>(run, mine[j]);
             }
-        }
-    } else {
-        for (uint32_t t = lo; t < hi; ++t) {
-            const uint32_t v = part[t];
-            part[t] = run;
-            run = scan_op<OP>(run, v);
         }
     }
 }

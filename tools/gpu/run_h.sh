@@ -7,7 +7,7 @@ mkdir -p $O
 cd $R
 timeout 1200 python3 -m pytest tests -m gpu -x -q > $O/${T}_tests.log 2>&1
 echo "rc=$?" >> $O/${T}_tests.log
-timeout 600 python3 tools/stress.py 300 2000 > $O/${T}_stress.log 2>&1
+timeout 900 python3 tools/stress.py 300 ${STRESS_A0:-2000} > $O/${T}_stress.log 2>&1
 echo "rc=$?" >> $O/${T}_stress.log
 timeout 300 python3 tools/stamps.py fused > $O/${T}_stamps_fused.log 2>&1
 timeout 300 python3 tools/stamps.py cfg2 > $O/${T}_stamps_cfg2.log 2>&1

@@ -43,4 +43,5 @@ for d in ${T}_tl_fused ${T}_tl_fused_big; do
   python3 tools/timeline.py $O/$d cl_keys > $O/$d.timeline.txt 2>&1
   find $O/$d -name '*.csv' -size +2M -delete
 done
-tail -2 $O/${T}_tests.log; ls $P | head -40; grep -h "duet_cluster" $O/${T}_cldebug_*.log | sort | uniq | head; tail -1 $O/${T}_tl_fused.timeline.txt; tail -1 $O/${T}_tl_fused_big.timeline.txt
+timeout 600 python3 tools/e2e_time.py > $O/${T}_e2e.log 2> $O/${T}_e2e.err
+tail -2 $O/${T}_tests.log; cat $O/${T}_e2e.log; ls $P | head -40; grep -h "duet_cluster" $O/${T}_cldebug_*.log | sort | uniq | head; tail -1 $O/${T}_tl_fused.timeline.txt; tail -1 $O/${T}_tl_fused_big.timeline.txt
