@@ -206,6 +206,8 @@ struct duet_ingest {
     uint32_t n_chrom_texts = 0, max_pos = 0;
     bool rows_ready = false;
     int threads = 4;                               // what parse_vcf was given
+    void *stage = nullptr;                         // between duet_ingest_parse_vcf_begin and _finish: the first half's result
+    ~duet_ingest();
     // SVIM-mode signature extraction (optional, set before add_bam): CIGAR indels -> raw SV marks, binned depth
     bool extract = false;
     uint32_t min_sv_size = 40, min_mapq = 20, depth_bin = 1000;
@@ -686,11 +688,21 @@ void scan_info(Span info, InfoHits &h)
 
 struct Layout { size_t supp_cut, rn_cut; int fmt_kind; };
 
-}  // namespace
+// what the first half of the VCF parse hands to the second (duet_ingest::stage between the two calls)
+struct PartA { std::vector<std::vector<Rec>> per; std::vector<Span> contig_lines; std::string why; };
+struct VcfStage {
+    int rc = DUET_INGEST_OK;
+    std::string err;
+    int T = 1;
+    std::vector<PartA> pa;
+};
 
-int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
+// Caller VCF, first half: read, index the lines, tokenise, pick the records of the listed contigs (parallel over lines).
+// Touches only the VCF side of *g (vcf, contig_lines, threads) and reports through st.err -- it may run beside
+// duet_ingest_add_bam calls on the same object.
+int vcf_begin(duet_ingest *g, const char *path, int threads, VcfStage &st)
 {
-    if (!g || !path) return DUET_INGEST_INVALID;
+    auto decline = [&](const std::string &why) { st.err = why; return DUET_INGEST_UNSUPPORTED; };
     const bool timing = getenv("DUET_INGEST_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -700,11 +712,11 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
         t_last = now;
     };
     g->threads = threads > 0 ? threads : 1;
-    if (g->alias) return unsupported(g, "contig list names a contig twice");
-    if (!read_file(path, g->vcf)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+    if (g->alias) return decline("contig list names a contig twice");
+    if (!read_file(path, g->vcf)) { st.err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
     const char *d = g->vcf.data();
     const size_t n = g->vcf.size();
-    if (n && memchr(d, 0, n)) return unsupported(g, "NUL byte in the VCF");
+    if (n && memchr(d, 0, n)) return decline("NUL byte in the VCF");
     lap("read+ascii");
     const int K = (int)g->contigs.size();
     int T = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
@@ -734,8 +746,9 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
     lap("lines");
 
     // ---- phase A (parallel over lines): tokenise, pick the records of listed contigs ------------------
-    struct PartA { std::vector<std::vector<Rec>> per; std::vector<Span> contig_lines; std::string why; };
-    std::vector<PartA> pa(T);
+    st.T = T;
+    st.pa.assign(T, PartA());
+    std::vector<PartA> &pa = st.pa;
     auto work_a = [&](int t) {
         PartA &o = pa[t];
         o.per.resize(K);
@@ -783,10 +796,25 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
     }
     lap("phase A");
     for (int t = 0; t < T; ++t)
-        if (!pa[t].why.empty()) return unsupported(g, pa[t].why);
+        if (!pa[t].why.empty()) return decline(pa[t].why);
     g->contig_lines.clear();
     for (int t = 0; t < T; ++t) g->contig_lines.insert(g->contig_lines.end(), pa[t].contig_lines.begin(), pa[t].contig_lines.end());
+    return DUET_INGEST_OK;
+}
 
+// ... second half: callset order, numbers, and the join of the mark names against the tag dicts (parallel over candidates)
+int vcf_finish(duet_ingest *g, VcfStage &st)
+{
+    const bool timing = getenv("DUET_INGEST_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[duet_ingest] %-14s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    const int K = (int)g->contigs.size(), T = st.T;
+    std::vector<PartA> &pa = st.pa;
     // callset order: contig-major, file order inside a contig
     std::vector<const Rec *> recs;
     g->cand_ctg_off.assign(K + 1, 0);
@@ -966,6 +994,41 @@ int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
     lap("finish");
     g->parsed = true;
     return DUET_INGEST_OK;
+}
+
+}  // namespace
+
+duet_ingest::~duet_ingest() { delete (VcfStage *)stage; }
+
+int duet_ingest_parse_vcf(duet_ingest *g, const char *path, int threads)
+{
+    if (!g || !path) return DUET_INGEST_INVALID;
+    VcfStage st;
+    const int rc = vcf_begin(g, path, threads, st);
+    if (rc) { g->err = st.err; return rc; }
+    return vcf_finish(g, st);
+}
+
+int duet_ingest_parse_vcf_begin(duet_ingest *g, const char *path, int threads)
+{
+    if (!g || !path) return DUET_INGEST_INVALID;
+    delete (VcfStage *)g->stage;
+    VcfStage *st = new VcfStage;
+    g->stage = st;
+    st->rc = vcf_begin(g, path, threads, *st);
+    return st->rc;
+}
+
+int duet_ingest_parse_vcf_finish(duet_ingest *g)
+{
+    if (!g || !g->stage) return DUET_INGEST_INVALID;
+    VcfStage *st = (VcfStage *)g->stage;
+    g->stage = nullptr;
+    int rc = st->rc;
+    if (rc) g->err = st->err;
+    else rc = vcf_finish(g, *st);
+    delete st;
+    return rc;
 }
 
 int duet_ingest_get_arrays(const duet_ingest *g, duet_ingest_arrays *o)

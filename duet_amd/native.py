@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libduet_ingest.so')
 OK, UNSUPPORTED = 0, 1
 
 EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam',
-           'duet_ingest_parse_vcf', 'duet_ingest_get_arrays', 'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
+           'duet_ingest_parse_vcf', 'duet_ingest_parse_vcf_begin', 'duet_ingest_parse_vcf_finish', 'duet_ingest_get_arrays',
+           'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
            'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks', 'duet_ingest_bam_has_alignments')
 
 
@@ -58,6 +59,8 @@ def load():
         lib.duet_ingest_error.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         lib.duet_ingest_parse_vcf.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        lib.duet_ingest_parse_vcf_begin.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        lib.duet_ingest_parse_vcf_finish.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_get_arrays.argtypes = [ctypes.c_void_p, ctypes.POINTER(IngestArrays)]
         lib.duet_ingest_emit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
@@ -114,15 +117,25 @@ class NativeIngest(object):
             lib.duet_ingest_destroy(h)
             return cls(None, lib, None, why)
 
+        # the first half of the VCF parse (read, tokenise, pick the listed contigs' records) needs nothing from the BAMs: it
+        # runs on a thread of its own beside the BAM loop (ctypes releases the GIL); the join of the mark names follows
+        import threading
+        first_half = threading.Thread(target=lib.duet_ingest_parse_vcf_begin, args=(h, vcf_path.encode(), int(thread)))
+        first_half.start()
         with_bam = []
+        bam_ok = True
         for k, c in enumerate(chrom_list):
             for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
                 if os.path.exists(cand):
-                    if lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) != OK:
-                        return decline()
+                    bam_ok = lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) == OK
                     with_bam.append(k)
                     break
-        if lib.duet_ingest_parse_vcf(h, vcf_path.encode(), int(thread)) != OK:
+            if not bam_ok:
+                break
+        first_half.join()
+        if not bam_ok:
+            return decline()
+        if lib.duet_ingest_parse_vcf_finish(h) != OK:
             return decline()
         a = IngestArrays()
         if lib.duet_ingest_get_arrays(h, ctypes.byref(a)) != OK:

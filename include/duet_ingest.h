@@ -54,6 +54,12 @@ int duet_ingest_bam_has_alignments(const duet_ingest *ing, int contig);
 
 /* Parse the caller VCF (`threads` workers) and join its mark names against the tag dicts added so far. */
 int duet_ingest_parse_vcf(duet_ingest *ing, const char *vcf_path, int threads);
+/* The same in two calls, so that a caller can run the first half -- read, tokenise, pick the listed contigs' records: it
+ * touches nothing the BAM side uses -- on another thread BESIDE its duet_ingest_add_bam calls, and the second half (numbers,
+ * join of the mark names against the tag dicts) once both are done.  _begin's failure is reported by _finish (error text
+ * included), which must be called exactly once after it. */
+int duet_ingest_parse_vcf_begin(duet_ingest *ing, const char *vcf_path, int threads);
+int duet_ingest_parse_vcf_finish(duet_ingest *ing);
 int duet_ingest_get_arrays(const duet_ingest *ing, duet_ingest_arrays *out);
 
 /* Text of phased_sv.vcf: header (write_file.py:19-45; include_all_ctgs selects which ##contig lines are
