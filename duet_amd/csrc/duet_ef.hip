@@ -68,7 +68,9 @@ constexpr uint32_t kLongTiles = 256;                // ef_seed_sort: tiles whose
 constexpr uint32_t kMaxRuns = 32;                  // ef_seed_sort merges up to this many ascending runs by rank
 constexpr uint32_t kFewRuns = 4;                   // ... right away when it finds no more descents than this
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
-constexpr uint32_t kC2Quota = 32;                 // group-summary slots per classify block
+constexpr uint32_t kC2Quota = 64;                 // group-summary slots per classify block: a tile with more multi-PS candidates than this (a quarter of
+                                                  // its 256) leaves the rest to ef_finalize's walk over the marks, ~10x slower per candidate (2e6 marks spread over
+                                                  // the 24 hg19 contigs -- one read per 8 kb, 37 % multi-PS candidates -- made ef_finalize 65 us with 32 slots)
 constexpr int kC2Groups = 2;                      // voter groups kept per summary (first two seen)
 constexpr int kC2Words = 2 + 6 * kC2Groups;       // allhap, ng, then {ps, n, n1, n2, t1, t2} per group
 
@@ -871,10 +873,22 @@ __device__ __forceinline__ uint32_t nearest_ps(const uint32_t *a, uint32_t n, ui
     return dl < dh ? a[lo] : a[hi];
 }
 
-__device__ __forceinline__ uint64_t fetch_tag(const Params &p, uint32_t m)
+// f(tag) for every mark of [b, e) in list order, the marks' two dependent loads (read index, then tag) eight marks at a time:
+// one pair of round trips per eight marks instead of one per mark
+template <class F>
+__device__ __forceinline__ void for_each_tag(const Params &p, uint32_t b, uint32_t e, F f)
 {
-    const uint32_t r = p.mark_read[m];
-    return r == kEmpty ? kUntagged : p.read_tag[r];
+    for (uint32_t m0 = b; m0 < e; m0 += 8) {
+        uint32_t r[8];
+        uint64_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = p.mark_read[m0 + j < e ? m0 + j : b];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = p.read_tag[r[j] == kEmpty ? 0u : r[j]];       // (read_tag always has >= 1 readable word)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (m0 + j < e) f(r[j] == kEmpty ? kUntagged : t[j]);
+    }
 }
 
 // multi-PS vote straight from the marks (:85-105): only for candidates without a group summary
@@ -882,37 +896,33 @@ __device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *o
 {
     const uint32_t b = p.cand_off[c], e = p.cand_off[c + 1];
     uint32_t best = 0;
-    for (uint32_t m = b; m < e; ++m) {
-        const uint64_t t = fetch_tag(p, m);
-        if (t == kUntagged || tag_pc(t) > kPcMax) continue;
-        ++v.allhap;
-    }
+    for_each_tag(p, b, e, [&](uint64_t t) {
+        if (t != kUntagged && tag_pc(t) <= kPcMax) ++v.allhap;
+    });
     uint32_t done_ps = kEmpty;                                 // last group evaluated (cheap duplicate skip)
-    for (uint32_t m = b; m < e; ++m) {
-        const uint64_t t = fetch_tag(p, m);
-        if (t == kUntagged || tag_pc(t) > kPcMax) continue;
+    for_each_tag(p, b, e, [&](uint64_t t) {
+        if (t == kUntagged || tag_pc(t) > kPcMax) return;
         const uint32_t g = tag_ps(t);
-        if (g == done_ps || (g == ps && best)) continue;
-        if (!is_member(one, n_one, g)) continue;               // :91
+        if (g == done_ps || (g == ps && best)) return;
+        if (!is_member(one, n_one, g)) return;                 // :91
         // size and sums of g's group over the whole list; a later occurrence of an already
         // evaluated group reproduces the same n and cannot beat it (strict '>', :101)
         uint32_t n = 0, n1 = 0, n2 = 0;
         uint64_t s1 = 0, s2 = 0;
-        for (uint32_t j = b; j < e; ++j) {
-            const uint64_t u = fetch_tag(p, j);
-            if (u == kUntagged || tag_pc(u) > kPcMax || tag_ps(u) != g) continue;
+        for_each_tag(p, b, e, [&](uint64_t u) {
+            if (u == kUntagged || tag_pc(u) > kPcMax || tag_ps(u) != g) return;
             ++n;
             const uint32_t hap = tag_hap(u);
             if (hap == 1) { ++n1; s1 += tag_pc(u); }
             else if (hap == 2) { ++n2; s2 += tag_pc(u); }
-        }
+        });
         done_ps = g;
         if (n > best) {
             best = n; ps = g;
             v.hap1 = n1; v.hap2 = n2; v.t1 = s1; v.t2 = s2;
             v.hap0 = v.allhap - n1 - n2;                       // only with a winner (:105)
         }
-    }
+    });
 }
 
 // one candidate's part of ef_finalize (everything after the tile's seed array is staged)
