@@ -504,6 +504,12 @@ def main():
                               'torch_imported_by_parent': os.environ.get('DUET_BENCH_PARENT_TORCH') == '1'}))
         return
 
+    # rank 0 prints ONE JSON line: from here on file descriptor 1 is stderr for everything else in the process (a
+    # collective library greeting its peers, a runtime warning), and the line goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from duet_amd import _lib
 
@@ -532,8 +538,8 @@ def main():
             if rank == 0:
                 out['extra'] = {'weak_grouped_config2_per_rank': weak}
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    os.close(json_fd)
 
     if world > 1:
         dist_mod.barrier()
