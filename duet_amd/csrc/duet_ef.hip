@@ -152,8 +152,9 @@ struct Params {
     uint32_t one_cap;                 // C + K
     uint32_t *tmpbuf;                 // [C]   scratch of the out-of-LDS seed sort
     uint32_t *n_one;                  // [K]   length of contig k's seed array
-    uint32_t *c2rec;                  // [B*kC2Quota*kC2Words] group summaries of multi-PS candidates
-    uint32_t *status;                 // [0] = div-zero flag
+    uint32_t *c2rec;                  // [c2_cap][kC2Words] group summaries of multi-PS candidates: kC2Quota slots per tile, then a shared pool
+    uint32_t c2_fixed, c2_cap;        // B * kC2Quota; that + the pool's slots
+    uint32_t *status;                 // [0] = div-zero flag, [1] = pool slots handed out in this run (ef_finalize zeroes it again)
     uint8_t *out_pred;
     uint32_t *out_ps;
     uint32_t n_small;                 // K when K <= kSmallK: the contig offsets then also ride in the kernel arguments
@@ -219,12 +220,27 @@ struct TileShared {
     uint32_t seed[kCandPerBlock];
     uint32_t wcnt[kCandPerBlock / 64], wlast[kCandPerBlock / 64], wclean[kCandPerBlock / 64];
     uint32_t c2n;                             // summary slots handed out in this tile (reset by the caller)
+    uint32_t c2base;                          // first pool slot of a tile that needs more than its own kC2Quota
 };
 
-// decision + outputs of ONE candidate (the one this thread walked); returns its seed entry or kEmpty
+// a multi-PS candidate's summary: the first two voter groups
+__device__ __forceinline__ void store_summary(const Params &p, uint32_t slot, const CandState &st)
+{
+    uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
+    const uint32_t ng = (st.n_a != 0) + (st.n_b != 0);
+    rec[0] = st.nv; rec[1] = ng;
+    // ps_a / ps_b are only meaningful when n_a / n_b > 0 (ng says how many groups exist)
+    rec[2] = st.ps_a; rec[3] = st.n_a; rec[4] = st.a1; rec[5] = st.a2;
+    rec[6] = (uint32_t)st.TA1; rec[7] = (uint32_t)st.TA2;
+    rec[8] = st.ps_b; rec[9] = st.n_b; rec[10] = st.b1; rec[11] = st.b2; rec[12] = st.tb1; rec[13] = st.tb2;
+}
+
+// decision + outputs of ONE candidate (the one this thread walked); returns its seed entry or kEmpty.  c2_rank: the
+// candidate's number among the tile's multi-PS candidates with a summary (kEmpty: it is none) -- the first kC2Quota of them
+// have their slot here, the caller finds the others one in the pool.
 __device__ __forceinline__ uint32_t decide_store(const Params &p, TileShared &sh, uint32_t tile, bool live, uint32_t c,
                                                  bool active, bool divzero, const CandState &st, uint32_t deg,
-                                                 uint32_t svread, uint32_t refread)
+                                                 uint32_t svread, uint32_t refread, uint32_t &c2_rank)
 {
     uint8_t code = 0;
     uint32_t ps_out = 0;
@@ -234,7 +250,8 @@ __device__ __forceinline__ uint32_t decide_store(const Params &p, TileShared &sh
     const uint32_t n_ps = st.n_ps();
     const bool c2 = active && n_ps == 2;
     const bool c2_fast = c2 && !st.more && deg < 500000u;
-    const uint32_t rank = c2_fast ? atomicAdd(&sh.c2n, 1u) : kC2Quota;
+    const uint32_t rank = c2_fast ? atomicAdd(&sh.c2n, 1u) : kEmpty;
+    c2_rank = rank;
     if (live) {
         // the seed sets are built from every kept class-1 candidate BEFORE any decision is taken (:195-203), so a candidate
         // whose decision would divide by zero (:123) still contributes its seed -- and raises only if its contig then has one
@@ -245,17 +262,11 @@ __device__ __forceinline__ uint32_t decide_store(const Params &p, TileShared &sh
             if (c2) {
                 if (rank < kC2Quota) {
                     const uint32_t slot = tile * kC2Quota + rank;
-                    uint32_t *rec = p.c2rec + (size_t)slot * kC2Words;
-                    const uint32_t ng = (st.n_a != 0) + (st.n_b != 0);
-                    rec[0] = st.nv; rec[1] = ng;
-                    // ps_a / ps_b are only meaningful when n_a / n_b > 0 (ng says how many groups exist)
-                    rec[2] = st.ps_a; rec[3] = st.n_a; rec[4] = st.a1; rec[5] = st.a2;
-                    rec[6] = (uint32_t)st.TA1; rec[7] = (uint32_t)st.TA2;
-                    rec[8] = st.ps_b; rec[9] = st.n_b; rec[10] = st.b1; rec[11] = st.b2; rec[12] = st.tb1; rec[13] = st.tb2;
+                    store_summary(p, slot, st);
                     code = kClass2;
                     ps_out = slot;
                 } else {
-                    code = kClass2Slow;
+                    code = kClass2Slow;                                   // (until the caller finds it a pool slot)
                 }
             } else {
                 Vote v;
@@ -466,9 +477,24 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
             __syncthreads();
         }
         STAMP(0, 4);
-        const uint32_t seed = decide_store(p, sh, tile, live, c0 + j, active, divzero, st, my_e - my_b, svread, refread);
+        uint32_t c2_rank;
+        const uint32_t seed = decide_store(p, sh, tile, live, c0 + j, active, divzero, st, my_e - my_b, svread, refread, c2_rank);
         sh.seed[j] = seed;
         __syncthreads();
+        if (sh.c2n > kC2Quota) {
+            // more multi-PS candidates than the tile has slots (fragmented phasing: short phase sets against long reads): the
+            // rest get theirs from the pool, one reservation per tile.  Only such tiles pay the atomic's round trip.
+            if (tid == 0) sh.c2base = atomicAdd(&p.status[1], sh.c2n - kC2Quota);
+            __syncthreads();
+            if (live && c2_rank != kEmpty && c2_rank >= kC2Quota) {
+                const uint32_t at = sh.c2base + (c2_rank - kC2Quota);
+                if (at < p.c2_cap - p.c2_fixed) {
+                    store_summary(p, p.c2_fixed + at, st);
+                    p.out_pred[c0 + j] = kClass2;
+                    p.out_ps[c0 + j] = p.c2_fixed + at;
+                }
+            }
+        }
         seeds_tile(p, sh, tile, tid, c0 + tid, is_start);
         STAMP(0, 6);
         if (!DYN) break;
@@ -995,6 +1021,7 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
     __shared__ uint32_t s_meta[4];                             // k0, n_one[k0] or ~0 (not LDS mode), any_empty, seed base of k0
     const uint32_t tid = threadIdx.x;
     STAMP(2, 0);
+    if (blockIdx.x == 0 && tid == 0) p.status[1] = 0;          // the summary pool's counter, for the next run's ef_classify
     const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
     // (device-planned runs stride over the real tiles like ef_classify)
     for (uint32_t tile = blockIdx.x; !DYN || tile * 256u < n_cands; tile += gridDim.x) {
@@ -1095,6 +1122,9 @@ inline int reserve(duet_ctx *ctx, DevBuf &b, size_t bytes) { return duet_reserve
 // (re)build the workspace for this contig layout; a no-op when it matches the cached plan.  The rebuild is
 // ordered on `stream` (uploads from a pinned staging block, memsets, one small kernel): the device is only
 // synchronised when a buffer has to grow or the context moves to another stream.
+// group-summary slots: kC2Quota per tile and a pool of an eighth of the candidates for the tiles that need more
+size_t c2_slots(uint32_t B, uint32_t C) { return (size_t)B * kC2Quota + (C / 8u > 256u ? C / 8u : 256u); }
+
 int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
 {
     const uint32_t K = pr->n_contigs, C = pr->n_cands;
@@ -1104,7 +1134,7 @@ int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
     const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
     const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
     const size_t want[6] = {small_words * 4, C, (size_t)B * kCandPerBlock * 8, ((size_t)C + K + 1) * 4, ((size_t)C + K + 1) * 4,
-                            (size_t)B * kC2Quota * kC2Words * 4};
+                            c2_slots(B, C) * kC2Words * 4};
     DevBuf *bufs[6] = {&ctx->ws_small, &ctx->ws_start, &ctx->ws_ent, &ctx->ws_one, &ctx->ws_tmp, &ctx->ws_c2};
     bool grow = ctx->plan_stream != stream;
     for (int i = 0; i < 6; ++i) grow = grow || want[i] > bufs[i]->cap;
@@ -1310,6 +1340,8 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     for (uint32_t k = 0; k <= p.n_small && p.n_small; ++k) p.ctg_small[k] = pr->cand_ctg_off[k];
     p.onebuf = (uint32_t *)ctx->ws_one.ptr; p.tmpbuf = (uint32_t *)ctx->ws_tmp.ptr;
     p.n_one = ctx->d_n_one; p.c2rec = (uint32_t *)ctx->ws_c2.ptr; p.status = ctx->d_status;
+    p.c2_fixed = ((p.C + kCandPerBlock - 1) / kCandPerBlock) * kC2Quota;
+    p.c2_cap = (uint32_t)c2_slots((p.C + kCandPerBlock - 1) / kCandPerBlock, p.C);
     p.out_pred = out_pred; p.out_ps = out_ps;
     p.dbg = ctx->dbg;
     p.stamps = ctx->d_stamps;
@@ -1356,7 +1388,7 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
     const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
     const size_t want[6] = {small_words * 4, C, (size_t)B * kCandPerBlock * 8, ((size_t)C + K + 1) * 4, ((size_t)C + K + 1) * 4,
-                            (size_t)B * kC2Quota * kC2Words * 4};
+                            c2_slots(B, C) * kC2Words * 4};
     DevBuf *bufs[6] = {&ctx->ws_small, &ctx->ws_start, &ctx->ws_ent, &ctx->ws_one, &ctx->ws_tmp, &ctx->ws_c2};
     bool grow = ctx->plan_stream != stream;
     for (int i = 0; i < 6; ++i) grow = grow || want[i] > bufs[i]->cap;
@@ -1402,6 +1434,8 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     p.n_small = 0;
     p.onebuf = (uint32_t *)ctx->ws_one.ptr; p.tmpbuf = (uint32_t *)ctx->ws_tmp.ptr;
     p.n_one = ctx->d_n_one; p.c2rec = (uint32_t *)ctx->ws_c2.ptr; p.status = ctx->d_status;
+    p.c2_fixed = ((p.C + kCandPerBlock - 1) / kCandPerBlock) * kC2Quota;
+    p.c2_cap = (uint32_t)c2_slots((p.C + kCandPerBlock - 1) / kCandPerBlock, p.C);
     p.out_pred = out_pred; p.out_ps = out_ps;
     p.dbg = ctx->dbg;
     p.stamps = ctx->d_stamps;

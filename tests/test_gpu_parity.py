@@ -123,6 +123,19 @@ def test_multi_ps_heavy(ctx):
     check_against_c_oracle(ctx, soa)
 
 
+def test_two_ps_everywhere_summary_pool(ctx):
+    """Nearly every candidate sees exactly two phase sets: every tile needs more group-summary slots than its own 64, so the
+    shared pool is used -- and, with few candidates (a pool of 256 slots), exhausted, which leaves the rest to ef_finalize's
+    walk over the marks.  Run twice on one context: the pool's counter has to start from zero again."""
+    small = soa_fuzz.random_soa(79, n_contigs=2, cands_per_contig=(1500, 2500), reads_per_contig=(30, 60),
+                                n_ps=(2, 2), deg=(4, 16), empty_contig_rate=0, no_seed_contig_rate=0)
+    big = soa_fuzz.random_soa(80, n_contigs=3, cands_per_contig=(20000, 30000), reads_per_contig=(200, 400),
+                              n_ps=(2, 2), deg=(3, 12), empty_contig_rate=0, no_seed_contig_rate=0)
+    for soa in (small, big, small):
+        check_against_c_oracle(ctx, soa)
+        check_against_c_oracle(ctx, soa, 0, 0)
+
+
 def test_long_candidates_cross_lds_chunks(ctx):
     """Candidates with more marks than one LDS pass holds (4096) and than a whole workgroup's pass."""
     soa = soa_fuzz.random_soa(101, n_contigs=2, cands_per_contig=(300, 600), reads_per_contig=(500, 900),
