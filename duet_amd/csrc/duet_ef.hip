@@ -68,9 +68,10 @@ constexpr uint32_t kLongTiles = 256;                // ef_seed_sort: tiles whose
 constexpr uint32_t kMaxRuns = 32;                  // ef_seed_sort merges up to this many ascending runs by rank
 constexpr uint32_t kFewRuns = 4;                   // ... right away when it finds no more descents than this
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
-constexpr uint32_t kC2Quota = 64;                 // group-summary slots per classify block: a tile with more multi-PS candidates than this (a quarter of
-                                                  // its 256) leaves the rest to ef_finalize's walk over the marks, ~10x slower per candidate (2e6 marks spread over
-                                                  // the 24 hg19 contigs -- one read per 8 kb, 37 % multi-PS candidates -- made ef_finalize 65 us with 32 slots)
+constexpr uint32_t kC2Quota = 64;                 // group-summary slots of a classify tile's own; a tile with more multi-PS candidates reserves the rest from
+                                                  // a shared pool (c2_slots).  Without a slot a candidate is left to ef_finalize's walk over its marks, ~10x
+                                                  // slower: 2e6 marks over the 24 hg19 contigs -- one read per 8 kb, 37 % multi-PS candidates -- made
+                                                  // ef_finalize 65 us with 32 slots per tile and no pool
 constexpr int kC2Groups = 2;                      // voter groups kept per summary (first two seen)
 constexpr int kC2Words = 2 + 6 * kC2Groups;       // allhap, ng, then {ps, n, n1, n2, t1, t2} per group
 
