@@ -88,6 +88,28 @@ def test_declines_what_it_cannot_vouch_for(tmp_path):
         assert ing is not None and ing.handle is None and ing.why, bad
 
 
+def test_two_call_parse_reports_through_finish(tmp_path):
+    """duet_ingest_parse_vcf_begin / _finish (what NativeIngest.load runs beside the BAM loop): _finish without _begin is
+    invalid, a failed first half is reported by _finish with its error text, and a second _finish is invalid again."""
+    import ctypes
+    lib = native.load()
+    names = (ctypes.c_char_p * 1)(b'1')
+    h = lib.duet_ingest_create(1, names)
+    try:
+        assert lib.duet_ingest_parse_vcf_finish(h) != native.OK
+        missing = str(tmp_path / 'no_such.vcf').encode()
+        assert lib.duet_ingest_parse_vcf_begin(h, missing, 2) != native.OK
+        assert lib.duet_ingest_parse_vcf_finish(h) != native.OK
+        assert b'cannot read' in lib.duet_ingest_error(h)
+        assert lib.duet_ingest_parse_vcf_finish(h) != native.OK
+        vcf = tmp_path / 'empty.vcf'
+        vcf.write_text('##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n')
+        assert lib.duet_ingest_parse_vcf_begin(h, str(vcf).encode(), 2) == native.OK
+        assert lib.duet_ingest_parse_vcf_finish(h) == native.OK
+    finally:
+        lib.duet_ingest_destroy(h)
+
+
 def test_python_int_forms_accepted(tmp_path):
     home = _tiny_case(tmp_path, [REC.replace('\t100\t', '\t+1_00\t').replace('RE=5', 'RE=0_5')], SAM)
     ing = native.NativeIngest.load(home + '/sv_calling/variants.vcf', home + '/snp_phasing/', CHROMS, 1)
