@@ -137,10 +137,15 @@ struct NameTable {
             h = (h + 1) & mask;
         }
     }
-    uint32_t find_or_add(const char *s, size_t n, bool &added)
+    // room for n more names without rehashing on the way
+    void reserve(size_t n)
+    {
+        while (((size_t)count + n + 1) * 2 > slots.size()) grow();
+    }
+    uint32_t find_or_add(const char *s, size_t n, bool &added) { return find_or_add_hashed(s, n, hash(s, n), added); }
+    uint32_t find_or_add_hashed(const char *s, size_t n, uint64_t hh, bool &added)
     {
         if (((size_t)count + 1) * 2 > slots.size()) grow();
-        const uint64_t hh = hash(s, n);
         const uint32_t tag = (uint32_t)(hh >> 32);
         uint32_t h = (uint32_t)hh & mask;
         for (;;) {
@@ -357,6 +362,116 @@ bool aux_has_space(const unsigned char *b, const Aux &a)
 
 }  // namespace
 
+namespace {
+
+// What one alignment record contributes, as a pure function of its bytes (so records can be examined in parallel and
+// applied in file order afterwards): a reason to decline, or the record's tag word when the last three whitespace tokens of
+// its text line are HP / PC / PS (sv_phasing_fn.py:25-29) -- plus where its (real) CIGAR is.
+struct BamRec {
+    const char *why = nullptr;        // the native path declines the BAM
+    const char *name = nullptr;
+    uint32_t name_len = 0;
+    bool tagged = false;
+    uint64_t word = 0, hash = 0;      // hash of the name, for tagged records
+    size_t cig_at = 0;
+    uint32_t n_ops = 0;
+};
+
+void parse_bam_record(const unsigned char *b, size_t p, size_t end, BamRec &o)
+{
+    auto u32 = [&](size_t x) { return (uint32_t)(b[x] | (b[x + 1] << 8) | (b[x + 2] << 16) | ((uint32_t)b[x + 3] << 24)); };
+    auto decline = [&](const char *why) { o.why = why; };
+    const unsigned l_name = b[p + 12];
+    const unsigned n_cig = b[p + 16] | (b[p + 17] << 8);
+    const size_t l_seq = u32(p + 20);
+    size_t q = p + 36;
+    const char *name = (const char *)b + q;
+    const size_t name_len = l_name ? l_name - 1 : 0;
+    o.name = name;
+    o.name_len = (uint32_t)name_len;
+    q += l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+    if (q > end) return decline("corrupt BAM record");
+    // SAMv1 section 4.2.2: a CIGAR of more than 65535 operations is stored as the placeholder <l_seq>S<ref_len>N with
+    // the real operations in a CG:B:I tag; htslib -- hence the `samtools view` text the reference parses -- moves
+    // them back on reading and drops the tag, when the record is placed, its first stored operation soft-clips the
+    // whole read and the (first) CG tag is a B array of I / i with at least n_cigar_op values.
+    size_t cg_lo = 0, cg_hi = 0, cig_at = p + 36 + l_name;
+    uint32_t n_ops = n_cig;
+    if (n_cig && (int32_t)u32(p + 4) >= 0 && (int32_t)u32(p + 8) >= 0) {
+        const uint32_t first = u32(cig_at);
+        if ((first & 15u) == 4u && (first >> 4) == l_seq) {
+            size_t a = q;
+            while (a < end) {
+                Aux x;
+                if (!aux_step(b, a, end, x)) return decline("corrupt aux field");
+                if (x.tag[0] == 'C' && x.tag[1] == 'G') {
+                    if (x.type == 'B' && (b[x.val_off] == 'I' || b[x.val_off] == 'i')) {
+                        const uint32_t cnt = u32(x.val_off + 1);
+                        if (cnt >= n_cig && cnt < (1u << 29)) { cg_lo = a; cg_hi = x.next; cig_at = x.val_off + 5; n_ops = cnt; }
+                    }
+                    break;
+                }
+                a = x.next;
+            }
+        }
+    }
+    o.cig_at = cig_at;
+    o.n_ops = n_ops;
+    // the last three aux fields are the last three whitespace tokens of the text line -- provided there
+    // are at least three and none of them contains whitespace
+    Aux last[3];
+    int n_aux = 0;
+    while (q < end) {
+        if (cg_hi && q == cg_lo) { q = cg_hi; continue; }       // the CG tag is not printed (see above)
+        Aux a;
+        if (!aux_step(b, q, end, a)) return decline("corrupt aux field");
+        last[0] = last[1]; last[1] = last[2]; last[2] = a;
+        ++n_aux;
+        q = a.next;
+    }
+    if (n_aux < 3) {
+        // The last three tokens then reach into the mandatory columns (..., SEQ, QUAL, aux...): tok[-2] is
+        // aux[0] (2 aux fields), QUAL (1) or SEQ (0).  Such a line is skipped unless tok[-2] contains
+        // 'PC:i:', in which case upstream goes on to int() a column that is not a tag -- left to Python.
+        bool maybe = false;
+        if (n_aux == 2) {
+            const Aux &a0 = last[1];
+            maybe = (aux_is_int(a0.type) && a0.tag[0] == 'P' && a0.tag[1] == 'C') || a0.type == 'Z' || a0.type == 'H' ||
+                    aux_has_space(b, last[1]) || aux_has_space(b, last[2]);
+        } else if (n_aux == 1) {
+            static const unsigned char pat[5] = {'P' - 33, 'C' - 33, ':' - 33, 'i' - 33, ':' - 33};
+            const unsigned char *ql = b + (p + 36 + l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2);
+            maybe = l_seq >= 5 && ql[0] != 255 && memmem(ql, l_seq, pat, 5) != nullptr;
+            maybe = maybe || aux_has_space(b, last[2]);
+        }
+        if (maybe) return decline("alignment with fewer than three aux fields and a PC-like column");
+        return;
+    }
+    // 'PC:i:' in tok[-2]
+    const Aux &t2 = last[1];
+    bool hit = aux_is_int(t2.type) && t2.tag[0] == 'P' && t2.tag[1] == 'C';
+    if (!hit && (t2.type == 'Z' || t2.type == 'H')) {
+        const char *v = (const char *)b + t2.val_off;
+        if (strstr(v, "PC:i:")) return decline("string aux value containing 'PC:i:'");
+    }
+    if (hit) {
+        if (!aux_is_int(last[0].type) || !aux_is_int(last[2].type))
+            return decline("HP/PS neighbours of PC are not integers");
+        const long long hap = aux_int(b, last[0]), pc = aux_int(b, t2), ps = aux_int(b, last[2]);
+        if (pc < 0 || ps < 0 || ps > 0xFFFFFFFELL) return decline("PC/PS out of range");
+        for (size_t i = 0; i < name_len; ++i)
+            if ((unsigned char)name[i] >= 0x80) return decline("non-ASCII read name");
+        const uint64_t code = (hap == 1 || hap == 2) ? (uint64_t)hap : 3ull;
+        const uint64_t pcc = pc > (long long)kPcSat ? kPcSat : (uint64_t)pc;
+        const uint64_t word = (code << 62) | (pcc << 32) | (uint64_t)ps;
+        o.tagged = true;
+        o.word = word;
+        o.hash = NameTable::hash(name, name_len);
+    }
+}
+
+}  // namespace
+
 // header lines of phased_sv.vcf (write_file.py:19-45) appended to `out`
 static int build_header(duet_ingest *g, int include_all_ctgs, std::string &out)
 {
@@ -416,12 +531,22 @@ void duet_ingest_free(void *p) { free(p); }
 int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int threads)
 {
     if (!g || contig < 0 || contig >= (int)g->contigs.size() || !path) return DUET_INGEST_INVALID;
+    const bool timing = getenv("DUET_INGEST_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[duet_ingest] bam %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<char> file;
     if (!read_file(path, file)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
     if (file.empty()) return DUET_INGEST_OK;                       // an empty file prints nothing (no alignments)
+    lap("read");
     std::vector<unsigned char> buf;
     int rc = inflate_bgzf(g, file, buf, threads);
     if (rc) return rc;
+    lap("inflate");
     const unsigned char *b = buf.data();
     const size_t n = buf.size();
     auto u32 = [&](size_t p) { return (uint32_t)(b[p] | (b[p + 1] << 8) | (b[p + 2] << 16) | ((uint32_t)b[p + 3] << 24)); };
@@ -444,42 +569,49 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     std::vector<Seg> segs;
     uint32_t line_no = 0;
     std::vector<int64_t> dep;
+    // record boundaries first (a hop per record), then every record's contribution -- a pure function of its bytes, examined
+    // in parallel when there are many of them -- applied in file order: the first declining record decides, later lines win
+    std::vector<size_t> at;
     while (p + 4 <= n) {
         const size_t bs = u32(p), end = p + 4 + bs;
         if (end > n || bs < 32) return unsupported(g, "truncated BAM record");
-        g->bam_has_aln[contig] = 1;
-        const unsigned l_name = b[p + 12];
-        const unsigned n_cig = b[p + 16] | (b[p + 17] << 8);
-        const size_t l_seq = u32(p + 20);
-        size_t q = p + 36;
-        const char *name = (const char *)b + q;
-        const size_t name_len = l_name ? l_name - 1 : 0;
-        q += l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
-        if (q > end) return unsupported(g, "corrupt BAM record");
-        // SAMv1 section 4.2.2: a CIGAR of more than 65535 operations is stored as the placeholder <l_seq>S<ref_len>N with
-        // the real operations in a CG:B:I tag; htslib -- hence the `samtools view` text the reference parses -- moves
-        // them back on reading and drops the tag, when the record is placed, its first stored operation soft-clips the
-        // whole read and the (first) CG tag is a B array of I / i with at least n_cigar_op values.
-        size_t cg_lo = 0, cg_hi = 0, cig_at = p + 36 + l_name;
-        uint32_t n_ops = n_cig;
-        if (n_cig && (int32_t)u32(p + 4) >= 0 && (int32_t)u32(p + 8) >= 0) {
-            const uint32_t first = u32(cig_at);
-            if ((first & 15u) == 4u && (first >> 4) == l_seq) {
-                size_t a = q;
-                while (a < end) {
-                    Aux x;
-                    if (!aux_step(b, a, end, x)) return unsupported(g, "corrupt aux field");
-                    if (x.tag[0] == 'C' && x.tag[1] == 'G') {
-                        if (x.type == 'B' && (b[x.val_off] == 'I' || b[x.val_off] == 'i')) {
-                            const uint32_t cnt = u32(x.val_off + 1);
-                            if (cnt >= n_cig && cnt < (1u << 29)) { cg_lo = a; cg_hi = x.next; cig_at = x.val_off + 5; n_ops = cnt; }
-                        }
-                        break;
-                    }
-                    a = x.next;
-                }
-            }
+        at.push_back(p);
+        p = end;
+    }
+    const size_t NR = at.size();
+    if (NR) g->bam_has_aln[contig] = 1;
+    auto rec_end = [&](size_t i) { return at[i] + 4 + (size_t)u32(at[i]); };
+    std::vector<BamRec> recs;
+    const bool batch = !g->extract && NR >= 4096 && threads > 1;
+    if (batch) {
+        recs.resize(NR);
+        const int T = threads > 32 ? 32 : threads;
+        auto work = [&](int t) {
+            for (size_t i = NR * t / T, hi = NR * (t + 1) / T; i < hi; ++i) parse_bam_record(b, at[i], rec_end(i), recs[i]);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+        size_t tagged = 0;
+        for (size_t i = 0; i < NR; ++i) {
+            if (recs[i].why) return unsupported(g, recs[i].why);
+            tagged += recs[i].tagged;
         }
+        tab.reserve(tagged);
+    }
+    for (size_t ri = 0; ri < NR; ++ri) {
+        const size_t p = at[ri];
+        BamRec one;
+        if (!batch) {
+            parse_bam_record(b, p, rec_end(ri), one);
+            if (one.why) return unsupported(g, one.why);
+        }
+        const BamRec &rec = batch ? recs[ri] : one;
+        const char *name = rec.name;
+        const size_t name_len = rec.name_len;
+        const size_t cig_at = rec.cig_at;
+        const uint32_t n_ops = rec.n_ops;
         if (g->extract) {
             // SVIM-mode signatures: insertions / deletions of at least min_sv_size inside the alignment's CIGAR
             // (primary and supplementary alignments with MAPQ >= min_mapq), and the alignment's span for the depth
@@ -538,60 +670,14 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
             }
         }
         ++line_no;
-        // the last three aux fields are the last three whitespace tokens of the text line -- provided there
-        // are at least three and none of them contains whitespace
-        Aux last[3];
-        int n_aux = 0;
-        while (q < end) {
-            if (cg_hi && q == cg_lo) { q = cg_hi; continue; }       // the CG tag is not printed (see above)
-            Aux a;
-            if (!aux_step(b, q, end, a)) return unsupported(g, "corrupt aux field");
-            last[0] = last[1]; last[1] = last[2]; last[2] = a;
-            ++n_aux;
-            q = a.next;
-        }
-        if (n_aux < 3) {
-            // The last three tokens then reach into the mandatory columns (..., SEQ, QUAL, aux...): tok[-2] is
-            // aux[0] (2 aux fields), QUAL (1) or SEQ (0).  Such a line is skipped unless tok[-2] contains
-            // 'PC:i:', in which case upstream goes on to int() a column that is not a tag -- left to Python.
-            bool maybe = false;
-            if (n_aux == 2) {
-                const Aux &a0 = last[1];
-                maybe = (aux_is_int(a0.type) && a0.tag[0] == 'P' && a0.tag[1] == 'C') || a0.type == 'Z' || a0.type == 'H' ||
-                        aux_has_space(b, last[1]) || aux_has_space(b, last[2]);
-            } else if (n_aux == 1) {
-                static const unsigned char pat[5] = {'P' - 33, 'C' - 33, ':' - 33, 'i' - 33, ':' - 33};
-                const unsigned char *ql = b + (p + 36 + l_name + 4 * (size_t)n_cig + (l_seq + 1) / 2);
-                maybe = l_seq >= 5 && ql[0] != 255 && memmem(ql, l_seq, pat, 5) != nullptr;
-                maybe = maybe || aux_has_space(b, last[2]);
-            }
-            if (maybe) return unsupported(g, "alignment with fewer than three aux fields and a PC-like column");
-            p = end;
-            continue;
-        }
-        // 'PC:i:' in tok[-2]
-        const Aux &t2 = last[1];
-        bool hit = aux_is_int(t2.type) && t2.tag[0] == 'P' && t2.tag[1] == 'C';
-        if (!hit && (t2.type == 'Z' || t2.type == 'H')) {
-            const char *v = (const char *)b + t2.val_off;
-            if (strstr(v, "PC:i:")) return unsupported(g, "string aux value containing 'PC:i:'");
-        }
-        if (hit) {
-            if (!aux_is_int(last[0].type) || !aux_is_int(last[2].type))
-                return unsupported(g, "HP/PS neighbours of PC are not integers");
-            const long long hap = aux_int(b, last[0]), pc = aux_int(b, t2), ps = aux_int(b, last[2]);
-            if (pc < 0 || ps < 0 || ps > 0xFFFFFFFELL) return unsupported(g, "PC/PS out of range");
-            for (size_t i = 0; i < name_len; ++i)
-                if ((unsigned char)name[i] >= 0x80) return unsupported(g, "non-ASCII read name");
-            const uint64_t code = (hap == 1 || hap == 2) ? (uint64_t)hap : 3ull;
-            const uint64_t pcc = pc > (long long)kPcSat ? kPcSat : (uint64_t)pc;
-            const uint64_t word = (code << 62) | (pcc << 32) | (uint64_t)ps;
+        if (rec.tagged) {
+            if (batch && ri + 8 < NR && recs[ri + 8].tagged) tab.prefetch_slot(recs[ri + 8].hash);
             bool added;
-            const uint32_t idx = tab.find_or_add(name, name_len, added);
-            if (added) tags.push_back(word); else tags[idx] = word;      // later lines win (:29)
+            const uint32_t idx = tab.find_or_add_hashed(name, name_len, rec.hash, added);
+            if (added) tags.push_back(rec.word); else tags[idx] = rec.word;      // later lines win (:29)
         }
-        p = end;
     }
+    lap("records");
     if (g->extract && !segs.empty()) {
         // split-read marks (oracle/svim_oracle.py, SVIM_inter.py's insertion / deletion cases): reads in order of first
         // appearance, their segments sorted by (qs, qe, line); consecutive segments on one strand whose gaps on the read

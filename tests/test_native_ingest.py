@@ -110,6 +110,35 @@ def test_two_call_parse_reports_through_finish(tmp_path):
         lib.duet_ingest_destroy(h)
 
 
+def test_many_records_parallel_bam_path(tmp_path):
+    """A BAM of more than 4096 alignments read with several threads takes the batch path (records examined in parallel,
+    applied in file order): same arrays as the one-thread loop and as the Python ingest, and a declining record still declines."""
+    from duet_amd import bamio, synth
+    home = str(tmp_path / 'w')
+    c = synth.bench_contig('1', 6000, 400, 5, length=3000000)
+    synth.write_workdir(home, [c], dialect='cutesv', seed=1, write_sam=True)
+    vcf, sams = home + '/sv_calling/variants.vcf', home + '/snp_phasing/'
+    one = native.NativeIngest.load(vcf, sams, CHROMS, 1)
+    four = native.NativeIngest.load(vcf, sams, CHROMS, 4)
+    assert one.handle is not None and four.handle is not None
+    assert one.soa.n_reads > 4096
+    tab, soa = F.generate_callinfo(vcf, F.read_hap_bam(sams, 4, False), False)
+    for field, _ in engine.EfSoA.FIELDS:
+        assert np.array_equal(getattr(one.soa, field), getattr(four.soa, field)), field
+        assert np.array_equal(getattr(four.soa, field), getattr(soa, field)), field
+    one.close()
+    four.close()
+    # the same alignments with a read whose PC is negative somewhere in the middle: declined by both paths
+    lines = synth.sam_lines(c)
+    k = next(i for i, l in enumerate(lines) if i > 5000 and 'PC:i:' in l)
+    import re
+    lines[k] = re.sub(r'PC:i:\d+', 'PC:i:-7', lines[k])
+    bamio.write_bam_from_sam_lines(sams + 'chr1.bam', [('chr1', 3000000)], lines)
+    for t in (1, 4):
+        ing = native.NativeIngest.load(vcf, sams, CHROMS, t)
+        assert ing is not None and ing.handle is None and 'PC/PS out of range' in ing.why, (t, ing.why)
+
+
 def test_python_int_forms_accepted(tmp_path):
     home = _tiny_case(tmp_path, [REC.replace('\t100\t', '\t+1_00\t').replace('RE=5', 'RE=0_5')], SAM)
     ing = native.NativeIngest.load(home + '/sv_calling/variants.vcf', home + '/snp_phasing/', CHROMS, 1)
