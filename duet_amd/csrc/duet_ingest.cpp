@@ -78,10 +78,11 @@ struct NameTable {
     std::vector<uint64_t> slots;      // (hash32 << 32) | (arena offset + 1), 0 = empty
     uint32_t count = 0, mask = 0;
 
+    static constexpr uint64_t kFnvBasis = 1469598103934665603ull, kFnvPrime = 1099511628211ull;
     static uint64_t hash(const char *s, size_t n)
     {
-        uint64_t h = 1469598103934665603ull;
-        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 1099511628211ull; }
+        uint64_t h = kFnvBasis;
+        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= kFnvPrime; }
         return h ^ (h >> 29);
     }
     void grow()
@@ -752,12 +753,15 @@ void scan_info(Span info, InfoHits &h)
 {
     size_t i = 0;
     while (i <= info.n) {
-        size_t j = i;
+        // the item's end and the '=' signs inside it, by memchr: most of an INFO column is the list of read names, which a
+        // byte-by-byte loop walked at a byte per step (a third of the ingest's second phase)
+        const char *semi = i < info.n ? (const char *)memchr(info.p + i, ';', info.n - i) : nullptr;
+        const size_t j = semi ? (size_t)(semi - info.p) : info.n;
         bool len_ = false, type_ = false, supp_ = false, names_ = false;
-        for (; j < info.n && info.p[j] != ';'; ++j) {
-            if (info.p[j] != '=') continue;
-            const char *it = info.p + i;
-            const size_t e = j - i;
+        const char *it = info.p + i;
+        for (const char *eq = i < j ? (const char *)memchr(it, '=', j - i) : nullptr; eq;
+             eq = eq + 1 < info.p + j ? (const char *)memchr(eq + 1, '=', (size_t)(info.p + j - (eq + 1))) : nullptr) {
+            const size_t e = (size_t)(eq - it);
             if (ends_with(it, e, "SVLEN=", 6)) len_ = true;
             if (ends_with(it, e, "SVTYPE=", 7)) type_ = true;
             if (ends_with(it, e, "SUPPORT=", 8) || ends_with(it, e, "SR=", 3) || ends_with(it, e, "RE=", 3)) supp_ = true;
@@ -998,9 +1002,10 @@ int vcf_finish(duet_ingest *g, VcfStage &st)
                     int nb = 0;
                     while (nb < 32) {
                         size_t j = i;
-                        while (j < sn && s[j] != ',') ++j;
+                        uint64_t fnv = NameTable::kFnvBasis;           // (NameTable::hash, folded into the scan for the comma)
+                        for (; j < sn && s[j] != ','; ++j) { fnv ^= (unsigned char)s[j]; fnv *= NameTable::kFnvPrime; }
                         nm[nb] = Span{s + i, j - i};
-                        hh[nb] = NameTable::hash(s + i, j - i);
+                        hh[nb] = fnv ^ (fnv >> 29);
                         tab.prefetch_slot(hh[nb]);
                         ++nb;
                         if (j >= sn) { more = false; break; }
