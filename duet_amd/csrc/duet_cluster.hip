@@ -66,15 +66,18 @@ struct ClParams {
     const uint64_t *skeys;                            // the sorted keys (contig | type | centre)
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
-    float inv_norm, t_lo[3], t_hi[3];                 // fast pass: 1/normalizer; max_dist / {1, 2, 4} * (1 -/+ 1e-5) in binary32
-    uint32_t fast;                                    // 0: parameters outside the fast pass's vetted range, everything goes to the exact pass
+    float inv_norm, t_lo[1], t_hi[1];                 // fast pass: 1/normalizer; max_dist * (1 -/+ 1e-5) in binary32
+    uint32_t fast;                                    // 0: parameters outside the fast pass's vetted range, everything goes to the exact linkage
+    uint32_t box;                                     // 0: no bounding-box test (tests: every partition through the pair loops)
+    double invn, scale;                               // exact linkage: 1 / normalizer, 2^26 / max_dist (oracle/cluster_oracle.c, rule 3)
+    uint32_t mergeable;                               // max_dist >= 0
+    uint32_t tps;                                     // scan tiles per work-list shard (kShards shards of consecutive tiles)
     // fused SVIM-mode pipeline (all null otherwise): cl_emit also writes the columns ef_classify reads
     const uint32_t *sv_mark_in, *sv_depth, *sv_depth_off;
     uint32_t sv_depth_bin;
     uint32_t *sv_mark_out, *sv_svread, *sv_refread;
     uint8_t *sv_gt;
-    uint8_t *label8;                                  // [M] per sorted position: its cluster's smallest member (row inside the partition)
-    uint8_t *comp8;                                   // [M] rows left to the exact pass: smallest row of their component; else 0xFF
+    uint4 *srec;                                      // [M] per sorted position of a partition the box test left open: (pos, span, read index, mark index)
     uint4 *e_rec;                                     // [M] cluster c of the partition that starts at s, at s + c: (rank | end << 8, floor mean pos, floor mean span, -)
     uint32_t *pc;                                     // [P] clusters per partition
     const uint32_t *cbase;                            // [P] first candidate of each partition
@@ -249,11 +252,12 @@ __device__ __forceinline__ PartSum part_block_exscan(const PartSum &mine, uint32
     return before;
 }
 
-__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero14)
+__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero, uint32_t nzero)
 {
     __shared__ PartSum s_w[kScanThreads / 64 + 1];
     const uint32_t tid = threadIdx.x;
-    if (zero14 && blockIdx.x == 0 && tid < 14) zero14[tid] = 0;         // the work-list counters of the kernels that follow
+    if (zero && blockIdx.x == 0)
+        for (uint32_t i = tid; i < nzero; i += kScanThreads) zero[i] = 0;     // the work-list counters of the kernels that follow
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     PartSum acc{kNoHead, 0, 0};
     bool head[kScanItems];
@@ -304,10 +308,13 @@ __global__ __launch_bounds__(1024) void part_spine(PartSum *tiles, uint32_t nb, 
 // position's partition id -- nobody downstream needs it since cl_emit walks partitions
 template <bool SELF>
 __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, uint32_t n, uint32_t pm, const PartSum *tiles, uint32_t *pid,
-                                                           uint32_t *part_start, uint32_t *n_parts)
+                                                           uint32_t *part_start, uint32_t *n_parts, uint32_t *tile_first /* [tiles + 1]: the first
+                                                           partition that starts in each tile (cl_box owns a tile's partitions) */)
 {
     __shared__ PartSum s_w[kScanThreads / 64 + 1];
     __shared__ PartSum s_c[kScanThreads / 64];
+    __shared__ uint32_t s_first;
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     bool head[kScanItems];
@@ -342,6 +349,8 @@ __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, ui
     // (st.s counts the natural partitions between the starts of everything before; position 0 is itself a start, so nothing
     // lies in front of the first one)
     uint32_t H = st.f == kNoHead ? 0u : st.l, P = st.f == kNoHead ? 0u : st.s;
+    uint32_t last = 0xFFFFFFFFu;
+    bool seen = false;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
         const uint32_t i = base + j;
@@ -353,139 +362,67 @@ __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, ui
         const uint32_t d = i - H, q = d < pm ? 0u : d / pm;
         const bool starts = d == q * pm;
         if (pid) pid[i] = P + q;
-        if (starts) part_start[P + q] = i;
+        if (starts) {
+            part_start[P + q] = i;
+            if (!seen) atomicMin(&s_first, P + q);
+            seen = true;
+        }
         if (i == n - 1) {
             part_start[P + q + 1] = n;
             *n_parts = P + q + 1;
+            last = P + q + 1;
         }
     }
+    __syncthreads();
+    // (a tile holds kScanTile positions and a partition at most 128: every full tile has starts; the last tile may have none)
+    if (last != 0xFFFFFFFFu) {
+        tile_first[blockIdx.x + 1] = last;
+        if (s_first == 0xFFFFFFFFu) tile_first[blockIdx.x] = last;
+    }
+    if (tid == 0 && s_first != 0xFFFFFFFFu) tile_first[blockIdx.x] = s_first;
 }
 
 // ---------------------------------------------------------------------------------------------
-// partitions
+// partitions: the box test and the work lists
 // ---------------------------------------------------------------------------------------------
 
 // work lists by partition size (which agglomeration kernel variant takes it); list order is irrelevant --
-// every partition writes to its own fixed output range -- so a (wave-aggregated) atomic append is fine
+// every partition writes to its own fixed output range -- so a (wave-aggregated) atomic append is fine.
+// A list is kept in kShards pieces, one per run of consecutive scan tiles, each with its own counter (ten thousand workgroups
+// adding to ONE counter queue up behind each other: 40 ns apiece, 0.4 ms at 2e7 marks); the piece of a shard starts at the
+// shard's first position -- it has room, a shard cannot hold more partitions than positions.
 constexpr int kClasses = 5;
-__device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 3 : 4))); }
-
-__global__ __launch_bounds__(1024) void cl_classes(const ClParams p, uint32_t *lists /* [kClasses][M] */, uint32_t *counts /* [kClasses] */)
-{
-    __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
-    // (the partitions' number lives on the device: the grid is a fraction of its bound -- the marks -- and strides)
-    const uint32_t n_parts = *p.n_parts;
-    for (uint32_t tile = blockIdx.x; tile * blockDim.x < n_parts; tile += gridDim.x) {
-        if (threadIdx.x < kClasses) s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t part = tile * blockDim.x + threadIdx.x;
-        const bool live = part < n_parts;
-        const int cls = live ? size_class(p.part_start[part + 1] - p.part_start[part]) : -1;
-        const uint32_t lane = threadIdx.x & 63u;
-        uint32_t at = 0;
-#pragma unroll
-        for (int c = 0; c < kClasses; ++c) {
-            const unsigned long long m = __ballot(cls == c);
-            if (!m) continue;
-            uint32_t base = 0;
-            if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&s_cnt[c], (uint32_t)__popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1, 64);
-            if (cls == c) at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+constexpr int kShards = 64;
+struct WorkList {
+    const uint32_t *items;          // the class's list, [M]
+    const uint32_t *pref;           // (LDS) pref[s] = items in the shards before s, pref[kShards] = all
+    uint32_t shard_span;            // positions per shard
+    __device__ __forceinline__ uint32_t size() const { return pref[kShards]; }
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const
+    {
+        uint32_t lo = 0, hi = kShards;                     // pref[lo] <= i < pref[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pref[mid] <= i) lo = mid; else hi = mid;
         }
-        __syncthreads();
-        if (threadIdx.x < kClasses && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
-        __syncthreads();
-        if (cls >= 0) lists[(size_t)cls * p.M + s_base[cls] + at] = part;
-        __syncthreads();                                     // s_cnt / s_base are reused
+        return items[(size_t)lo * shard_span + (i - pref[lo])];
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// agglomeration
-// ---------------------------------------------------------------------------------------------
-//
-// GROUP lanes of a wavefront work on one component of up to GROUP * R marks; lane sl owns the rows
-// sl, sl + GROUP, ... of the component's distance matrix, whose upper triangle lives in LDS.  A wave carries
-// 64 / GROUP components in lockstep; control flow is wave-uniform and groups that have nothing to do in a phase
-// are predicated off.
-//
-// The oracle's merge step is "global argmin over the active upper triangle, ties to the smallest (row, col)".
-// Here every row caches (rmin, rarg) = its minimum over the active columns to its right and the smallest
-// column that attains it, so the global argmin is a butterfly over one value per row.  Invariant:
-//     rmin <= the row's true minimum;  if the row is not marked stale, (rmin, rarg) is exact.
-// A merge (a, b) changes column a and removes column b.  A row k < a folds the new d(k, a) into its cache when
-// that keeps it exact, and is marked stale when its cached column went away; row a's new minimum is a butterfly
-// over the values the other rows just computed.  A stale row is rescanned (cooperatively: one LDS read per
-// lane + a butterfly) only when the argmin picks it -- its rmin is still a lower bound, so rows whose bound
-// never becomes the smallest are never rescanned.  The picked pair is the oracle's: the smallest row index
-// among the rows with the smallest bound, exact once clean, and any row before it has a larger bound.
-
-constexpr uint32_t kNoCol = 0xFFFFu;
-
-// Minimum of a 32-bit value over each group of GROUP consecutive lanes, delivered to every lane of the group.
-// Inside a 16-lane row the steps are DPP lane permutes fused into v_min_u32 (pairs, quads, halves, row: each step
-// combines two sets that are already uniform); across rows the four row minima go through SGPRs.
-#define DUET_DPP_MIN(v, ctrl) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true))
-template <int GROUP>
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
+};
+// one wavefront: the running sums of a class's kShards counters into LDS
+__device__ __forceinline__ void worklist_prefix(const uint32_t *counts, uint32_t *pref /* LDS [kShards + 1] */)
 {
-    if (GROUP >= 2) DUET_DPP_MIN(v, 0xB1);        // quad_perm [1,0,3,2]
-    if (GROUP >= 4) DUET_DPP_MIN(v, 0x4E);        // quad_perm [2,3,0,1]
-    if (GROUP >= 8) DUET_DPP_MIN(v, 0x141);       // row_half_mirror
-    if (GROUP >= 16) DUET_DPP_MIN(v, 0x140);      // row_mirror
-    if (GROUP >= 32) {
-        const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
-        const uint32_t r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
-        const uint32_t lo = min(r0, r1), hi = min(r2, r3);
-        v = GROUP == 64 ? min(lo, hi) : (threadIdx.x < 32 ? lo : hi);
-    }
-    return v;
-}
-
-// minimum of the candidates val[r] (column r * GROUP + sl; non-negative binary64, whose bit patterns order like
-// unsigned integers) over the group, and the smallest column attaining it
-template <int GROUP, int R>
-__device__ __forceinline__ void group_argmin(const double (&val)[R], uint32_t sub, double &gval, uint32_t &gcol)
-{
-    double m = val[0];
+    static_assert(kShards == 64, "one lane per shard");
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t x = counts[lane];
 #pragma unroll
-    for (int r = 1; r < R; ++r) m = val[r] < m ? val[r] : m;
-    const uint32_t hi = (uint32_t)__double2hiint(m), lo = (uint32_t)__double2loint(m);
-    const uint32_t mh = group_min_u32<GROUP>(hi);
-    uint32_t ml;
-    if (GROUP == 64) {
-        // one group per wave: when a single lane holds the smallest high word (the usual case: two distances share their top
-        // 32 bits only when they agree to 1e-6) its low word is the answer -- one reduction chain instead of two
-        const unsigned long long top = __ballot(hi == mh);
-        if (__popcll(top) == 1) ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)__ffsll((long long)top) - 1);
-        else ml = group_min_u32<GROUP>(hi == mh ? lo : 0xFFFFFFFFu);
-    } else {
-        ml = group_min_u32<GROUP>(hi == mh ? lo : 0xFFFFFFFFu);
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
     }
-    m = __hiloint2double((int)mh, (int)ml);
-    gval = m;
-    gcol = kNoCol;
-    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
-#pragma unroll
-    for (int r = R - 1; r >= 0; --r) {
-        const unsigned long long bal = (__ballot(val[r] == m) >> (sub * GROUP)) & gm;
-        if (bal) gcol = (uint32_t)r * GROUP + (uint32_t)__ffsll((long long)bal) - 1u;
-    }
+    pref[lane + 1] = x;
+    if (lane == 0) pref[0] = 0;
 }
-
-__device__ __forceinline__ double sp_distance(uint32_t pi, uint32_t spi, uint32_t pj, uint32_t spj, double normalizer)
-{
-    const uint64_t si = pi, ei = (uint64_t)pi + spi, ci = centre_of(pi, spi);
-    const uint64_t sj = pj, ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
-    uint64_t m = si > sj ? si - sj : sj - si;
-    const uint64_t m2 = ei > ej ? ei - ej : ej - ei, m3 = ci > cj ? ci - cj : cj - ci;
-    m = m2 < m ? m2 : m;
-    m = m3 < m ? m3 : m;
-    const uint32_t smax = spi > spj ? spi : spj, sdif = spi > spj ? spi - spj : spj - spi;
-    const double dp = (double)m / normalizer;
-    const double ds = smax ? (double)sdif / (double)smax : 0.0;
-    return dp + ds;
-}
+__device__ __forceinline__ int size_class(uint32_t n) { return n <= 8 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 3 : 4))); }
 
 // index (into the caller's arrays) of the mark at sorted position i
 __device__ __forceinline__ uint32_t mark_at(const ClParams &p, uint32_t i)
@@ -504,250 +441,155 @@ __device__ __forceinline__ uint3 load_rec(const ClParams &p, uint32_t a)
     return make_uint3(q.x, q.y, 0u);
 }
 
-// Work item: one connected component of a partition's threshold graph (list entry = partition, then
-// root row | rows << 8), gathered in row order from the partition through comp8; writes label8 for its rows.
-// NCAP = the most rows a unit can have (<= GROUP * R): with the default part_max of 100 the triangle of a >64-row unit
-// takes 39.6 KB instead of 65 KB, i.e. four wavefronts per CU -- one per SIMD -- instead of two.
-template <int GROUP, int R, int NCAP = GROUP * R>
-struct ExactSmem {
-    static constexpr int SUBS = 64 / GROUP, NMAX = NCAP;
-    double d[SUBS][NMAX * (NMAX - 1) / 2];                   // upper triangle, row by row
-    uint32_t pos[SUBS][NMAX], span[SUBS][NMAX];
-    uint8_t row[SUBS][NMAX];
-};
+// Fixed point of the rule (oracle/cluster_oracle.c, rule 3): the threshold is 2^26
+constexpr uint64_t kQOne = 1ull << 26;
+constexpr double kQCap = 2199023255552.0;          // 2^41
 
-template <int GROUP, int R, bool WHOLE = false, int NCAP = GROUP * R>
-__device__ __forceinline__ void exact_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
+// cl_box: one workgroup per scan tile (kScanTile sorted positions); it owns the partitions that START in its tile.
+// A partition whose bounding box already proves that every pair of its marks is closer than max_dist,
+//     min(range of pos, range of end, range of centre) / normalizer + (1 - min span / max span) <= max_dist * (1 - 1e-5)
+// (every pair distance is bounded by this expression term by term), is ONE cluster: all its pairs are within the threshold, so
+// average linkage keeps merging until one cluster is left.  On SV-like data that is the common case (a partition = the marks of
+// one SV): such partitions are finished here -- their marks keep their sorted order, one cluster record -- and never see
+// a pair loop.  The others go on the work lists by size class.
+constexpr int kBoxThreads = 256;
+constexpr int kBoxHalo = 128;                      // a partition has at most 128 marks: the last one of a tile ends within the halo
+__global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const uint32_t *tile_first, uint32_t *lists /* [kClasses][M] */,
+                                                      uint32_t *counts /* [kClasses][kShards] */)
 {
-    static_assert(NCAP <= GROUP * R && NCAP <= 128, "");
-    constexpr int NMAX = NCAP;
-    ExactSmem<GROUP, R, NCAP> &X = *reinterpret_cast<ExactSmem<GROUP, R, NCAP> *>(smem);
-    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
-    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
-    double *D = X.d[sub];
-    const double inf = __builtin_inf();
-    // d(i, j), i < j, in the upper triangle: half the LDS of a square matrix, so twice the waves per CU
-    auto tri = [](uint32_t i, uint32_t j) -> uint32_t { return i * (2u * NMAX - i - 1u) / 2u + (j - i - 1u); };
+    __shared__ uint32_t s_pos[kScanTile + kBoxHalo], s_span[kScanTile + kBoxHalo];
+    __shared__ uint32_t s_ps[kScanTile + 2];               // starts of the tile's partitions (+ the end of the last one)
+    __shared__ uint8_t s_done[kScanTile];                  // per partition of the tile: finished here
+    __shared__ uint16_t s_pix[kScanTile + kBoxHalo];       // per position: its partition (index within the tile's partitions)
+    __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t t0 = blockIdx.x * kScanTile, shard = blockIdx.x / p.tps;
+    const uint32_t p_lo = tile_first[blockIdx.x], p_hi = tile_first[blockIdx.x + 1], np = p_hi - p_lo;
+    if (tid < kClasses) s_cnt[tid] = 0;
+    for (uint32_t j = tid; j <= np; j += kBoxThreads) s_ps[j] = p.part_start[p_lo + j];
+    // the marks' (pos, span), gathered through the sort permutation; each thread keeps its eight positions' mark indices
+    // (and read indices) for the stores at the end.  Two rounds of loads, each round's loads side by side (the branches on the
+    // layout are hoisted: with them inside, every position waited for its own two round trips in turn -- 30 us per tile)
+    uint32_t mk[kScanItems + 1], rd[kScanItems + 1], ps_[kScanItems + 1], sp_[kScanItems + 1];
     {
-        const uint32_t li = base + sub;
-        const bool has = li < L;
-        // WHOLE: the list holds partitions (one word each) and the item is the whole partition
-        const uint32_t part = has ? (WHOLE ? list[li] : list[2 * (size_t)li]) : 0u;
-        const uint32_t item = has && !WHOLE ? list[2 * (size_t)li + 1] : 0u;
-        const uint32_t s = has ? p.part_start[part] : 0u;
-        const uint32_t np = has ? p.part_start[part + 1] - s : 0u;       // rows of the partition
-        const uint32_t root = item & 0xFFu, n = WHOLE ? np : (has ? item >> 8 : 0u);     // n = rows of the component
-        __syncthreads();
-        // gather the component's rows, in row order
-        uint32_t filled = 0;
-        uint32_t np_max = np;
+        uint32_t at[kScanItems + 1];
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) np_max = max(np_max, (uint32_t)__shfl_xor((int)np_max, d, 64));
-        for (uint32_t k0 = 0; k0 < np_max; k0 += GROUP) {
-            const uint32_t row = k0 + sl;
-            const bool mem = row < np && (WHOLE || p.comp8[s + row] == root);
-            const unsigned long long bal = (__ballot(mem) >> (sub * GROUP)) & gm;
-            if (mem) {
-                const uint32_t ci = filled + (uint32_t)__popcll(bal & ((1ull << sl) - 1ull));
-                const uint32_t a = mark_at(p, s + row);
-                const uint3 q = load_rec(p, a);
-                X.pos[sub][ci] = q.x;
-                X.span[sub][ci] = q.y;
-                X.row[sub][ci] = (uint8_t)row;
+        for (int j = 0; j < kScanItems; ++j) at[j] = min(t0 + j * kBoxThreads + tid, p.M - 1u);
+        at[kScanItems] = min(t0 + kScanTile + min(tid, (uint32_t)kBoxHalo - 1u), p.M - 1u);      // the halo (threads < kBoxHalo)
+        if (p.idx_packed) {
+#pragma unroll
+            for (int j = 0; j <= kScanItems; ++j) mk[j] = (uint32_t)(p.skeys[at[j]] >> p.key_bits);
+        } else {
+#pragma unroll
+            for (int j = 0; j <= kScanItems; ++j) mk[j] = p.sorted[at[j]];
+        }
+        if (p.rec4) {
+#pragma unroll
+            for (int j = 0; j <= kScanItems; ++j) {
+                const uint4 q = p.rec4[mk[j]];
+                ps_[j] = q.x; sp_[j] = q.y; rd[j] = q.z;
             }
-            filled += (uint32_t)__popcll(bal);
+        } else {
+#pragma unroll
+            for (int j = 0; j <= kScanItems; ++j) {
+                const uint2 q = p.ps[mk[j]];
+                ps_[j] = q.x; sp_[j] = q.y; rd[j] = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            const uint32_t i = t0 + j * kBoxThreads + tid;
+            if (i < p.M) { s_pos[i - t0] = ps_[j]; s_span[i - t0] = sp_[j]; }
+        }
+        if (tid < kBoxHalo && t0 + kScanTile + tid < p.M) { s_pos[kScanTile + tid] = ps_[kScanItems]; s_span[kScanTile + tid] = sp_[kScanItems]; }
+    }
+    __syncthreads();
+    // one thread per partition
+    for (uint32_t j0 = 0; j0 < np; j0 += kBoxThreads) {
+        const uint32_t j = j0 + tid;
+        const bool live = j < np;
+        int cls = -1;
+        if (live) {
+            const uint32_t s = s_ps[j], e = s_ps[j + 1], n = e - s;
+            uint32_t plo = ~0u, phi = 0, elo = ~0u, ehi = 0, clo = ~0u, chi = 0, slo = ~0u, shi = 0;
+            uint64_t sum_p = 0, sum_s = 0;
+            bool bad = false;
+            for (uint32_t i = s - t0; i < e - t0; ++i) {
+                s_pix[i] = (uint16_t)j;
+                const uint32_t ps = s_pos[i], sp = s_span[i], en = ps + sp, ce = ps + (sp >> 1);
+                bad = bad || en < ps;                        // end does not fit 32 bits: leave it to the exact path
+                plo = min(plo, ps); phi = max(phi, ps);
+                elo = min(elo, en); ehi = max(ehi, en);
+                clo = min(clo, ce); chi = max(chi, ce);
+                slo = min(slo, sp); shi = max(shi, sp);
+                sum_p += ps;
+                sum_s += sp;
+            }
+            const uint32_t r = min(min(phi - plo, ehi - elo), chi - clo);
+            const float u = (float)r * p.inv_norm + (float)(shi - slo) * __builtin_amdgcn_rcpf((float)max(shi, 1u));
+            const bool one = n < 2 || (p.fast && p.box && !bad && u <= p.t_lo[0]);
+            s_done[j] = one ? 1 : 0;
+            if (one) {
+                // (floor means: see emit_prep)
+                p.e_rec[s] = make_uint4(0u | (n << 8), (uint32_t)((double)sum_p / (double)n), (uint32_t)((double)sum_s / (double)n), 0u);
+                p.pc[p_lo + j] = 1;
+            } else {
+                cls = size_class(n);
+            }
+        }
+        // append the others to their class lists (wave-aggregated)
+        uint32_t at = 0;
+#pragma unroll
+        for (int c = 0; c < kClasses; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (!m) continue;
+            uint32_t base = 0;
+            if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&s_cnt[c], (uint32_t)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1, 64);
+            if (cls == c) at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         }
         __syncthreads();
-        // every unordered pair once: row k takes the columns k+1 .. k+n/2 (mod n); for even n the distance-n/2
-        // pairs only from the lower half of the rows
-        const uint32_t half = n >> 1;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t k = sl + r * GROUP;
-            if (k < n) {
-                const uint32_t pk = X.pos[sub][k], spk = X.span[sub][k];
-                const uint32_t tmax = (!(n & 1u) && k >= half) ? half - 1 : half;
-                for (uint32_t t = 1; t <= tmax; ++t) {
-                    uint32_t j = k + t;
-                    j = j >= n ? j - n : j;
-                    const double v = sp_distance(pk, spk, X.pos[sub][j], X.span[sub][j], p.normalizer);
-                    D[k < j ? tri(k, j) : tri(j, k)] = v;
-                }
-            }
-        }
+        if (tid < kClasses && s_cnt[tid]) s_base[tid] = shard * p.tps * kScanTile + atomicAdd(&counts[tid * kShards + shard], s_cnt[tid]);
         __syncthreads();
-        double rmin[R];
-        uint32_t rarg[R], lab[R], csize[R];
-        bool alive[R], stale[R];
+        if (cls >= 0) lists[(size_t)cls * p.M + s_base[cls] + at] = p_lo + j;
+        __syncthreads();
+        if (tid < kClasses) s_cnt[tid] = 0;
+        __syncthreads();
+    }
+    // the finished partitions' marks keep their sorted order; the marks of the others are laid out in sorted order for the
+    // agglomeration kernels, which then read their rows side by side instead of gathering them again.  (Positions before the
+    // tile's first start belong to the previous tile's last partition: its block handles them as its halo.)
+    const uint32_t first = np ? s_ps[0] : 0xFFFFFFFFu, end = np ? s_ps[np] : 0u;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t k = sl + r * GROUP;
-            csize[r] = 1;
-            rmin[r] = inf;
-            rarg[r] = kNoCol;
-            lab[r] = k;
-            alive[r] = k < n;
-            stale[r] = false;
-            for (uint32_t j = k + 1; j < n; ++j) {
-                const double v = D[tri(k, j)];
-                if (v < rmin[r]) { rmin[r] = v; rarg[r] = j; }
-            }
-        }
-        bool done = n < 2;
-        // every iteration merges or cleans a stale row, so the loop ends by itself; the bound is a safety net
-        for (uint32_t iter = 0; iter < (uint32_t)NMAX * NMAX; ++iter) {
-            double cand[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) cand[r] = alive[r] ? rmin[r] : inf;
-            double gval;
-            uint32_t g;
-            group_argmin<GROUP, R>(cand, sub, gval, g);
-            const bool act = !done && gval <= p.max_dist && g != kNoCol;      // distances are finite: inf = no pair left
-            done = done || !act;
-            if (!__ballot(act)) break;
-            // the picked row's cache, from its owner lane
-            uint32_t mine = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if ((uint32_t)r == g / GROUP) mine = rarg[r] | (stale[r] ? 0x80000000u : 0u);
-            // (one group per wave: the owner lane is uniform -- a lane read instead of a trip through the LDS crossbar)
-            const uint32_t info = GROUP == 64 ? (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(g == kNoCol ? 0u : g % GROUP))
-                                              : (uint32_t)__shfl(mine, act ? (int)(sub * GROUP + g % GROUP) : (int)lane, 64);
-            const bool do_rescan = act && (info >> 31);
-            const bool do_merge = act && !(info >> 31);
-            if (__ballot(do_rescan)) {
-                double cv[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t k = sl + r * GROUP;
-                    cv[r] = (do_rescan && alive[r] && k > g) ? D[tri(g, k)] : inf;
-                }
-                double nv;
-                uint32_t nc;
-                group_argmin<GROUP, R>(cv, sub, nv, nc);
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (do_rescan && sl + r * GROUP == g) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; }
-            }
-            if (__ballot(do_merge)) {
-                const uint32_t a = g, b = info & 0xFFFFu;
-                // cluster sizes live with their rows' lanes (csize[r] of the lane that owns the row): a lane read per merge
-                // instead of two LDS round trips at the head of the merge's dependent chain
-                uint32_t za = 0, zb = 0;
-                if (GROUP == 64) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t va = (uint32_t)__builtin_amdgcn_readlane((int)csize[r], (int)(a % GROUP));
-                        const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)csize[r], (int)(b % GROUP));
-                        za = (uint32_t)r == a / GROUP ? va : za;
-                        zb = (uint32_t)r == b / GROUP ? vb : zb;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t va = (uint32_t)__shfl((int)csize[r], do_merge ? (int)(sub * GROUP + a % GROUP) : (int)lane, 64);
-                        const uint32_t vb = (uint32_t)__shfl((int)csize[r], do_merge ? (int)(sub * GROUP + b % GROUP) : (int)lane, 64);
-                        za = (uint32_t)r == a / GROUP ? va : za;
-                        zb = (uint32_t)r == b / GROUP ? vb : zb;
-                    }
-                }
-                const double na = (double)za, nb = (double)zb;
-                double cv[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t k = sl + r * GROUP;
-                    const bool act = do_merge && alive[r] && k != a && k != b;
-                    const bool ka = k < a;
-                    double v = inf;
-                    if (act) {
-                        const uint32_t ia = ka ? tri(k, a) : tri(a, k);
-                        const double da = D[ia], db = D[k < b ? tri(k, b) : tri(b, k)];
-                        v = (na * da + nb * db) / (na + nb);
-                        D[ia] = v;
-                    }
-                    // the row's cached minimum, as selects (no divergent control flow behind the division)
-                    const bool upd = act && ka, hit = rarg[r] == a || rarg[r] == b;
-                    const bool lt = upd && v < rmin[r], eq = upd && v == rmin[r];
-                    const bool take = lt || (eq && !stale[r] && (hit || a < rarg[r]));
-                    const bool spoil = (upd && !lt && !eq && hit) || (act && !ka && k < b && rarg[r] == b);
-                    rmin[r] = lt ? v : rmin[r];
-                    rarg[r] = take ? a : rarg[r];
-                    stale[r] = lt ? false : (spoil ? true : stale[r]);
-                    cv[r] = (act && !ka) ? v : inf;
-                    if (do_merge && lab[r] == b) lab[r] = a;
-                }
-                double nv;
-                uint32_t nc;
-                group_argmin<GROUP, R>(cv, sub, nv, nc);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t k = sl + r * GROUP;
-                    if (do_merge && k == a) { rmin[r] = nv; rarg[r] = nv < inf ? nc : kNoCol; stale[r] = false; csize[r] = za + zb; }
-                    if (do_merge && k == b) alive[r] = false;
-                }
-            }
-            __syncthreads();
-        }
-        // the component's clusters, named after their smallest row of the partition
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t k = sl + r * GROUP;
-            if (k < n) p.label8[s + X.row[sub][k]] = X.row[sub][lab[r]];
+    for (int j = 0; j <= kScanItems; ++j) {
+        const uint32_t i = j < kScanItems ? t0 + j * kBoxThreads + tid : t0 + kScanTile + tid;
+        if ((j == kScanItems && tid >= kBoxHalo) || i < first || i >= end) continue;
+        if (s_done[s_pix[i - t0]]) {
+            p.order[i] = mk[j];
+            if (p.sv_mark_out) p.sv_mark_out[i] = rd[j];
+        } else {
+            p.srec[i] = make_uint4(ps_[j], sp_[j], rd[j], mk[j]);
         }
     }
 }
 
-// components of up to 64 rows, every size class in one launch (largest first).  For small inputs the partitions of more
-// than 64 marks do not go through the fast pass at all: one wavefront would spend ~100 us on one of them there, as long
-// as the exact agglomeration takes, so cl_exact_big<true> takes them whole, on a side stream, while the fast pass handles
-// the rest.  For large inputs there can be very many of them and throughput counts: the fast pass (20 waves per CU
-// instead of 2) settles what it can first, cl_exact_big<false> gets the components it leaves.
-__global__ __launch_bounds__(64) void cl_exact_small(const ClParams p, const uint32_t *lists, const uint32_t *cnts)
-{
-    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 1>)];
-    static_assert(sizeof(ExactSmem<64, 1>) >= sizeof(ExactSmem<32, 1>) && sizeof(ExactSmem<64, 1>) >= sizeof(ExactSmem<16, 1>), "");
-    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2];
-    const uint32_t b2 = c2, b1 = b2 + (c1 + 1) / 2, b0 = b1 + (c0 + 3) / 4;
-    const size_t M = p.M;
-    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
-        if (vb < b2) exact_unit<64, 1>(p, lists + 2 * M, c2, vb, smem);
-        else if (vb < b1) exact_unit<32, 1>(p, lists + 1 * M, c1, (vb - b2) * 2, smem);
-        else exact_unit<16, 1>(p, lists, c0, (vb - b1) * 4, smem);
-    }
-}
-
-template <bool WHOLE, int NCAP>
-__global__ __launch_bounds__(64) void cl_exact_big(const ClParams p, const uint32_t *list, const uint32_t *count)
-{
-    __shared__ __align__(16) unsigned char smem[sizeof(ExactSmem<64, 2, NCAP>)];
-    static_assert(sizeof(ExactSmem<64, 2, 100>) <= 40960, "four units per CU");
-    const uint32_t L = *count;
-    for (uint32_t vb = blockIdx.x; vb < L; vb += gridDim.x) exact_unit<64, 2, WHOLE, NCAP>(p, list, L, vb, smem);
-}
-
 // ---------------------------------------------------------------------------------------------
-// agglomeration, fast path: partitions whose clusters can be read off the threshold graph
+// agglomeration
 // ---------------------------------------------------------------------------------------------
-//
-// What stage A0 emits depends only on the FINAL clusters of a partition (clusters by smallest member, members
-// in sorted order, floor means), not on the order of the merges.  Two facts about average linkage pin them down
-// without running it (u = 2^-53; a Lance-Williams step rounds 3 times, a merge tree is at most 127 deep, so a
-// computed cluster distance lies within (1 +/- 4.3e-14) of the range of the pair distances it averages):
-//   * marks in different connected components of the graph {d(i,j) <= max_dist * (1 + 9e-6)} are never merged:
-//     every cross distance the oracle ever computes stays above max_dist;
-//   * a component in which EVERY pair has d <= max_dist * (1 - 9e-6) ends as exactly one cluster: while two of
-//     its clusters remain, their computed distance is below max_dist, so the oracle keeps merging.
-// The fast pass evaluates d in binary32 (relative error < 4e-7, hence the 1e-5 guard band around max_dist), builds each
-// mark's closed neighbourhood as a bit mask, and accepts the partition when no pair falls inside the guard
-// band and every neighbourhood equals the neighbourhood of its smallest member (<=> every component is a
-// clique).  Everything else -- about one partition in a few hundred on SV-like data, nearly all on random data
-// -- gets the exact binary64 agglomeration (exact_unit), component by component.  Both paths produce
-// the oracle's clusters; tests/test_gpu_cluster.py and tools/stress.py cover both.
+
+// |a - b| in ONE instruction (__usad compiles to min, max, sub)
+__device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 template <int NW>
 struct BitSet {
     uint64_t w[NW];
     __device__ __forceinline__ void clear() { for (int i = 0; i < NW; ++i) w[i] = 0; }
+    __device__ __forceinline__ bool any() const { uint64_t x = 0; for (int i = 0; i < NW; ++i) x |= w[i]; return x != 0; }
     __device__ __forceinline__ uint32_t count() const { uint32_t c = 0; for (int i = 0; i < NW; ++i) c += __popcll(w[i]); return c; }
     __device__ __forceinline__ uint32_t count_below(uint32_t k) const      // set bits at positions < k
     {
@@ -765,6 +607,12 @@ struct BitSet {
             if (w[i]) return 64u * i + (uint32_t)__ffsll((long long)w[i]) - 1u;
         return 64u * (NW - 1) + (uint32_t)__ffsll((long long)w[NW - 1]) - 1u;
     }
+    __device__ __forceinline__ uint32_t pop_first()                        // ... and clears it
+    {
+        const uint32_t f = first();
+        for (int i = 0; i < NW; ++i) w[i] &= (NW == 1 || (f >> 6) == (uint32_t)i) ? ~(1ull << (f & 63u)) : ~0ull;
+        return f;
+    }
     // (no dynamically indexed w[]: that would put the set in scratch memory)
     __device__ __forceinline__ bool test(uint32_t j) const
     {
@@ -776,15 +624,30 @@ struct BitSet {
     {
         for (int i = 0; i < NW; ++i) w[i] |= (c && (NW == 1 || (j >> 6) == (uint32_t)i)) ? 1ull << (j & 63u) : 0ull;
     }
+    __device__ __forceinline__ void keep_above(uint32_t j)                 // drop the positions <= j
+    {
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t lo = 64u * i;
+            const uint64_t m = j >= lo + 63u ? 0ull : (j >= lo ? ~0ull << (j - lo + 1u) : ~0ull);
+            w[i] &= m;
+        }
+    }
     __device__ __forceinline__ bool equals(const BitSet &o) const { bool e = true; for (int i = 0; i < NW; ++i) e = e && w[i] == o.w[i]; return e; }
 };
 
-// |a - b| in ONE instruction (__usad compiles to min, max, sub)
-__device__ __forceinline__ uint32_t absdiff_u32(uint32_t a, uint32_t b)
+// bit set over a group's rows from one predicate per (lane, r): row sl + r * GROUP
+template <int GROUP, int R, int NW>
+__device__ __forceinline__ BitSet<NW> group_ballot(const bool (&pred)[R], uint32_t sub)
 {
-    uint32_t d;
-    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
-    return d;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    BitSet<NW> b;
+    b.clear();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long v = (__ballot(pred[r]) >> (sub * GROUP)) & gm;
+        b.w[(r * GROUP) >> 6] |= v << ((r * GROUP) & 63);
+    }
+    return b;
 }
 
 // What cl_emit needs, per mark: its place in the partition's output, and at each cluster's smallest member the
@@ -865,116 +728,488 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
     if (sl == 0) p.pc[part] = heads.count();
 }
 
-// work lists the fast pass leaves behind: per size class of the components (<= 16 / 32 / 64 / 128 rows) the
-// components for cl_exact (two words each), per size class of the partitions the partitions for cl_rank
-struct ClWork {
-    uint32_t *comp_list;      // [4][M]
-    uint32_t *comp_count;     // [4]
-    uint32_t *rank_list;      // [kClasses][M]
-    uint32_t *rank_count;     // [kClasses]
-    uint32_t *why;            // diagnostics (DUET_CL_DEBUG): why the whole-partition test gave up, or null
+// ---------------------------------------------------------------------------------------------
+// exact average linkage, round by round
+// ---------------------------------------------------------------------------------------------
+//
+// The rule (oracle/cluster_oracle.c, rule 4) is the serial one: merge the closest pair of clusters, ties to the smallest
+// (first, second) index pair, while its mean is within the threshold.  Cluster distances are exact means of integers
+// (sums of member-pair distances over n_a n_b), so they do not depend on the order of the merges, and average linkage is
+// reducible: merging two clusters never brings the result closer to a third one than the nearer of the two was.
+// Two clusters that are each other's nearest neighbour (nearest = smallest mean, ties to the smallest index) are therefore
+// merged with each other by the serial rule, whatever it does elsewhere first -- nothing can come between them (a third
+// cluster merging elsewhere only moves away), and the serial rule cannot stop before their mean, which is within the
+// threshold, has been used.  So ALL mutual nearest-neighbour pairs of a round merge at once; the sums of the new clusters
+// are sums of the old ones; a dozen rounds settle a partition of a hundred marks where the serial rule takes ninety-nine
+// dependent steps.  Marks with the same (pos, span) have distance 0 and go first, as one group.
+// tools/linkage_proto.py compares the two evaluations on the CPU, partition by partition.
+//
+// GROUP lanes of a wavefront work on one partition of up to GROUP * R rows; lane sl owns rows sl, sl + GROUP, ...
+// The sums live in the upper triangle of a matrix in LDS.
+template <int GROUP, int R, int NCAP>
+struct LinkSmem {
+    static constexpr int SUBS = 64 / GROUP, NMAX = NCAP, NW = NMAX > 64 ? 2 : 1, NT = NMAX * (NMAX - 1) / 2;
+    double S[SUBS][NT + 2];                                  // upper triangle, row by row: exact integers (every sum stays <= 2^53);
+                                                             // [NT] = "nothing there" (beyond any sum), [NT + 1] scratch / zero
+    double inv[SUBS][NMAX];
+    uint32_t pos[SUBS][NMAX], span[SUBS][NMAX];
+    uint8_t size[SUBS][NMAX], nn[SUBS][NMAX], rep[SUBS][NMAX];
+    uint8_t alist[SUBS][NMAX + 4], asize[SUBS][NMAX + 4];   // the clusters that are left, ascending, and their sizes (read four at a time)
+    uint8_t mdst[SUBS][NMAX], msrc[SUBS][NMAX];             // this round's merges
 };
 
-constexpr int kLevels = 3;              // thresholds max_dist, max_dist / 2, max_dist / 4
-
-// Average linkage over m <= KA "atoms" (clusters already known to form first), every lane of the group running
-// the same steps on the group's LDS scratch: D[a * KA + b] (a < b) the atoms' average distances, sz their sizes,
-// lab[a] the atom that a's cluster is named after (its smallest atom).  Returns false when a decision -- which
-// pair is closest, whether it is within max_dist -- is not safe against a 1e-4 relative error of D.
-template <int KA>
-__device__ __forceinline__ bool atoms_linkage(uint32_t m, double *D, double *sz, uint32_t *lab, double max_dist)
+// rule 3 of oracle/cluster_oracle.c, the result as a binary64 integer
+__device__ __forceinline__ double quantise(double d, double scale)
 {
-    uint32_t alive = m >= 32 ? ~0u : (1u << m) - 1u;
-    for (uint32_t step = 0; step + 1 < m; ++step) {
-        double d1 = __builtin_inf(), d2 = __builtin_inf();
-        uint32_t a1 = 0, b1 = 1;
-        for (uint32_t a = 0; a + 1 < m; ++a) {
-            if (!((alive >> a) & 1u)) continue;
-            for (uint32_t b = a + 1; b < m; ++b) {
-                if (!((alive >> b) & 1u)) continue;
-                const double v = D[a * KA + b];
-                if (v < d1) { d2 = d1; d1 = v; a1 = a; b1 = b; }
-                else if (v < d2) d2 = v;
-            }
-        }
-        if (!(d2 > d1 * (1.0 + 1e-4))) return false;                       // a near-tie for the closest pair
-        if (!(fabs(d1 - max_dist) > 1e-4 * max_dist)) return false;         // too close to the threshold to call
-        if (d1 > max_dist) break;
-        const double na = sz[a1], nb = sz[b1];
-        for (uint32_t c = 0; c < m; ++c) {
-            if (!((alive >> c) & 1u) || c == a1 || c == b1) continue;
-            const uint32_t ia = c < a1 ? c * KA + a1 : a1 * KA + c, ib = c < b1 ? c * KA + b1 : b1 * KA + c;
-            D[ia] = (na * D[ia] + nb * D[ib]) / (na + nb);
-        }
-        sz[a1] = na + nb;
-        alive &= ~(1u << b1);
-        for (uint32_t c = 0; c < m; ++c)
-            if (lab[c] == b1) lab[c] = a1;
-    }
-    return true;
+    double t = __builtin_rint(d * scale);
+    t = !(t < kQCap) ? kQCap : t;
+    t = t < 1.0 ? 1.0 : t;
+    return d == 0.0 ? 0.0 : t;
 }
 
-template <int GROUP, int R, int KA>
+// Sums beyond 2^38 cannot be within the threshold (mean <= 2^26 over at most 64 x 64 member pairs) and their mean exceeds that
+// of every pair that is: they count as "nothing there", and for the others s * n (n <= 128) stays below 2^53, so the rational
+// comparison s1 / n1 < s2 / n2 is two exact binary64 products
+constexpr double kFar = 274877906944.0;                    // 2^38
+constexpr double kNothing = 1152921504606846976.0;         // 2^60
+
+// rows of the partition -> F[r]: the final cluster of each of this lane's rows (groups with go == false keep the
+// collective operations company).  pk / spk: this lane's rows' (pos, span); wide: some end position needs 33 bits.
+template <int GROUP, int R, int NCAP, int NW>
+__device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n, uint32_t sub, uint32_t sl, const uint32_t (&pk)[R],
+                                          const uint32_t (&spk)[R], bool wide, LinkSmem<GROUP, R, NCAP> &X, uint64_t (*s_mask)[NW],
+                                          BitSet<NW> (&F)[R])
+{
+    constexpr int NMAX = NCAP, NT = NMAX * (NMAX - 1) / 2;
+    static_assert(NW == (NMAX > 64 ? 2 : 1), "");
+    double *S = X.S[sub];
+    // entry {i, j}, i < j, sits at rowbase(i) + j
+    auto rowbase = [](uint32_t i) -> int { return (int)(__umul24(i, 2u * NMAX - i - 1u) >> 1) - (int)i - 1; };
+    auto at = [&](uint32_t a, uint32_t b) -> int { return a < b ? rowbase(a) + (int)b : rowbase(b) + (int)a; };
+    const uint32_t nn_ = go ? n : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        if (k < nn_) {
+            X.pos[sub][k] = pk[r];
+            X.span[sub][k] = spk[r];
+            X.inv[sub][k] = spk[r] ? 1.0 / (double)spk[r] : 0.0;
+            X.size[sub][k] = 1;
+            X.alist[sub][k] = (uint8_t)k;
+            X.asize[sub][k] = 1;
+        }
+    }
+    if (sl == 0) S[NT] = kNothing;
+    __syncthreads();
+    // every unordered pair once: row k takes the columns k+1 .. k+n/2 (mod n); for even n the distance-n/2
+    // pairs only from the lower half of the rows
+    {
+        const uint32_t half = nn_ >> 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t k = sl + r * GROUP;
+            if (k < nn_) {
+                const double ik = X.inv[sub][k];
+                const uint32_t tmax = (!(nn_ & 1u) && k >= half) ? half - 1 : half;
+                const uint32_t ek32 = pk[r] + spk[r], ck32 = pk[r] + (spk[r] >> 1);
+                const uint64_t ek = (uint64_t)pk[r] + spk[r], ck = centre_of(pk[r], spk[r]);
+                for (uint32_t t = 1; t <= tmax; ++t) {
+                    uint32_t j = k + t;
+                    j = j >= nn_ ? j - nn_ : j;
+                    const uint32_t pj = X.pos[sub][j], spj = X.span[sub][j];
+                    uint32_t m;
+                    if (!wide) {
+                        m = min(min(absdiff_u32(pk[r], pj), absdiff_u32(ek32, pj + spj)), absdiff_u32(ck32, pj + (spj >> 1)));
+                    } else {
+                        const uint64_t ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
+                        const uint64_t m2 = ek > ej ? ek - ej : ej - ek, m3 = ck > cj ? ck - cj : cj - ck;
+                        const uint64_t mm = m2 < m3 ? m2 : m3;
+                        m = absdiff_u32(pk[r], pj);
+                        m = mm < (uint64_t)m ? (uint32_t)mm : m;
+                    }
+                    const uint32_t sdif = absdiff_u32(spk[r], spj);
+                    const double inv = spk[r] > spj ? ik : X.inv[sub][j];        // 1 / the larger span (the same number when they are equal)
+                    const double dp = (double)m * p.invn, ds = (double)sdif * inv;
+                    S[at(k, j)] = quantise(dp + ds, p.scale);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // state: this lane's rows' roots (every row) and, for the clusters they name, alive / size in LDS + the group's alive set
+    uint32_t root[R];
+    bool alive[R];
+    int rb_me[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        root[r] = sl + r * GROUP;
+        alive[r] = sl + r * GROUP < nn_;
+        rb_me[r] = rowbase(sl + r * GROUP);
+    }
+    BitSet<NW> live = group_ballot<GROUP, R, NW>(alive, sub);
+    uint32_t na = nn_;                                       // clusters left in the group
+    // this round's merges, one after the other, each one on every lane's own entries: {i, dst} += {i, src} -- sums of
+    // integers, any order gives the same matrix; a row dies once, so all the rounds together take fewer than n of these steps
+    auto merge_round = [&](const BitSet<NW> &dead, const bool (&dies)[R], const uint32_t (&into)[R]) {
+        const uint32_t nd = dead.count();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            if (dies[r]) {
+                const uint32_t at_ = dead.count_below(me);
+                X.mdst[sub][at_] = (uint8_t)into[r];
+                X.msrc[sub][at_] = (uint8_t)me;
+            }
+            if (alive[r]) X.rep[sub][me] = (uint8_t)(dies[r] ? into[r] : me);
+        }
+        __syncthreads();
+        uint32_t nd_max = nd;
+#pragma unroll
+        for (int d = 32; d >= GROUP && d > 0; d >>= 1) nd_max = max(nd_max, (uint32_t)__shfl_xor((int)nd_max, d, 64));
+        for (uint32_t t = 0; t < nd_max; ++t) {
+            const bool on = t < nd;
+            const uint32_t dst = X.mdst[sub][on ? t : 0u], src = X.msrc[sub][on ? t : 0u];
+            const int rb_d = rowbase(dst), rb_s = rowbase(src);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t me = sl + r * GROUP;
+                const bool mine = on && alive[r] && me != dst && me != src;
+                const int i_d = me < dst ? rb_me[r] + (int)dst : rb_d + (int)me;
+                const int i_s = me < src ? rb_me[r] + (int)src : rb_s + (int)me;
+                const double v = S[mine ? i_d : NT + 1] + S[mine ? i_s : NT + 1];
+                S[mine ? i_d : NT + 1] = v;
+            }
+            if (on && sl == 0) X.size[sub][dst] = (uint8_t)((uint32_t)X.size[sub][dst] + (uint32_t)X.size[sub][src]);
+            __syncthreads();
+        }
+        // every row follows its cluster; the clusters that are left, ascending, with their sizes
+        BitSet<NW> after = live;
+        for (int i = 0; i < NW; ++i) after.w[i] &= ~dead.w[i];
+        const bool any_dead = dead.any();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (sl + r * GROUP < nn_) root[r] = X.rep[sub][root[r]];
+            alive[r] = alive[r] && !dies[r] && any_dead;     // (a group without a merge in a round is finished: its state no longer changes)
+        }
+        live = after;
+        na = after.count();
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            if (alive[r]) {
+                const uint32_t at_ = after.count_below(me);
+                X.alist[sub][at_] = (uint8_t)me;
+                X.asize[sub][at_] = X.size[sub][me];
+            }
+        }
+        __syncthreads();
+    };
+    uint32_t n_all = nn_;
+#pragma unroll
+    for (int d = 32; d >= GROUP && d > 0; d >>= 1) n_all = max(n_all, (uint32_t)__shfl_xor((int)n_all, d, 64));
+    if (p.mergeable) {
+        // Tight groups first.  A connected component of the graph {q <= threshold / 2} (or / 4) in which every pair is that
+        // close is a cluster of the serial rule: while two of its clusters are left their mean is at most that level, and the
+        // mean of anything of it with anything outside exceeds the level (no pair across is that close), so the rule finishes the
+        // component before it touches its surroundings.  Exact integers: no guard band.  On SV-like data this takes the marks
+        // of one SV in one step (identical marks included) and leaves a handful of clusters to the rounds below.
+        BitSet<NW> g1[R], g2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { g1[r].clear(); g2[r].clear(); }
+        constexpr double kHalf = (double)(kQOne / 2), kQuarter = (double)(kQOne / 4);
+        for (uint32_t k = 0; k < n_all; ++k) {
+            const int rb_k = rowbase(k);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t me = sl + r * GROUP;
+                int idx = me < k ? rb_me[r] + (int)k : rb_k + (int)me;
+                idx = (me == k || k >= nn_ || !alive[r]) ? NT : idx;
+                const double sv = S[idx];
+                g1[r].set_if(sv <= kHalf, k);
+                g2[r].set_if(sv <= kQuarter, k);
+            }
+        }
+        bool dies[R];
+        uint32_t into[R];
+        bool ok1[R], ok2[R];
+        auto clique_rows = [&](BitSet<NW> (&g)[R], bool (&ok)[R]) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t me = sl + r * GROUP;
+                g[r].set_if(alive[r], me);
+                if (alive[r])
+                    for (int i = 0; i < NW; ++i) s_mask[me][i] = g[r].w[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                ok[r] = false;
+                if (alive[r]) {
+                    const uint32_t f = g[r].first();
+                    BitSet<NW> o;
+                    for (int i = 0; i < NW; ++i) o.w[i] = s_mask[f][i];
+                    ok[r] = o.equals(g[r]);
+                }
+            }
+            // a row's component is a clique <=> the row and all its neighbours have the neighbourhood of their smallest member
+            const BitSet<NW> pass = group_ballot<GROUP, R, NW>(ok, sub);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bool c = ok[r];
+                for (int i = 0; i < NW; ++i) c = c && (g[r].w[i] & ~pass.w[i]) == 0ull;
+                ok[r] = c;
+            }
+        };
+        clique_rows(g1, ok1);
+        clique_rows(g2, ok2);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            const uint32_t f = ok1[r] ? g1[r].first() : (ok2[r] ? g2[r].first() : me);
+            dies[r] = alive[r] && f != me;
+            into[r] = f;
+        }
+        const BitSet<NW> dead = group_ballot<GROUP, R, NW>(dies, sub);
+        if (__ballot(dead.any())) {
+            // the groups' sums.  Group after group (all lanes of a partition walk the same list of heads and members):
+            // every row outside the group adds up its entries to the group's members and leaves the sum at the group's head --
+            // {i, head} = sum over j in the group of {i, j}.  A row of an EARLIER group finds at {i, j} what j collected
+            // for i's group, so after the last group {head_g, head_h} holds every member pair of g x h.  One pass over a row's
+            // entries instead of one dependent read-add-write per dying row.
+            bool head[R];
+            BitSet<NW> mine[R];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t me = sl + r * GROUP;
+                mine[r] = ok1[r] ? g1[r] : g2[r];
+                head[r] = alive[r] && into[r] == me && (ok1[r] || ok2[r]) && mine[r].count() > 1u;
+                if (head[r])
+                    for (int i = 0; i < NW; ++i) s_mask[me][i] = mine[r].w[i];
+                if (alive[r]) X.rep[sub][me] = (uint8_t)into[r];
+            }
+            BitSet<NW> heads = group_ballot<GROUP, R, NW>(head, sub);
+            if (sl == 0) S[NT + 1] = 0.0;
+            __syncthreads();
+            uint32_t nh_max = heads.count();
+#pragma unroll
+            for (int d = 32; d >= GROUP && d > 0; d >>= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d, 64));
+            for (uint32_t t = 0; t < nh_max; ++t) {
+                const bool on = heads.any();
+                const uint32_t h = on ? heads.pop_first() : 0u;
+                BitSet<NW> mem;
+                for (int i = 0; i < NW; ++i) mem.w[i] = on ? s_mask[h][i] : 0ull;
+                double acc[R];
+                bool out[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[r] = 0.0;
+                    out[r] = alive[r] && on && !mem.test(sl + r * GROUP);
+                }
+                const uint32_t cnt = mem.count();
+                uint32_t cnt_max = cnt;
+#pragma unroll
+                for (int d = 32; d >= GROUP && d > 0; d >>= 1) cnt_max = max(cnt_max, (uint32_t)__shfl_xor((int)cnt_max, d, 64));
+                for (uint32_t c = 0; c < cnt_max; ++c) {
+                    const bool more = mem.any();
+                    const uint32_t j = more ? mem.pop_first() : 0u;
+                    const int rb_j = rowbase(j);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t me = sl + r * GROUP;
+                        const int idx = me < j ? rb_me[r] + (int)j : rb_j + (int)me;
+                        acc[r] += S[(more && out[r]) ? idx : NT + 1];
+                    }
+                }
+                __syncthreads();                             // (every lane has read before anybody writes a head's column)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t me = sl + r * GROUP;
+                    if (out[r]) S[me < h ? rb_me[r] + (int)h : rowbase(h) + (int)me] = acc[r];
+                }
+                if (on && sl == 0) X.size[sub][h] = (uint8_t)cnt;
+                __syncthreads();
+            }
+            // every row follows its group; the clusters that are left, ascending, with their sizes
+            BitSet<NW> after = live;
+            for (int i = 0; i < NW; ++i) after.w[i] &= ~dead.w[i];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (sl + r * GROUP < nn_) root[r] = X.rep[sub][root[r]];
+                alive[r] = alive[r] && !dies[r];
+            }
+            live = after;
+            na = after.count();
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t me = sl + r * GROUP;
+                if (alive[r]) {
+                    const uint32_t at_ = after.count_below(me);
+                    X.alist[sub][at_] = (uint8_t)me;
+                    X.asize[sub][at_] = X.size[sub][me];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t round = 0; round < 2u * NMAX && p.mergeable; ++round) {
+        // nearest neighbour of every cluster: smallest mean, ties to the smallest index (the list is ascending).  All lanes of
+        // a group walk the same list; lane `me` looks at entry {me, k}
+        double bs[R], bn[R];
+        uint32_t bk[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { bs[r] = kNothing; bn[r] = 1.0; bk[r] = 0xFFu; }
+        uint32_t na_max = na;
+#pragma unroll
+        for (int d = 32; d >= GROUP && d > 0; d >>= 1) na_max = max(na_max, (uint32_t)__shfl_xor((int)na_max, d, 64));
+        for (uint32_t t = 0; t < na_max; t += 4) {
+            const uint32_t ks = *reinterpret_cast<const uint32_t *>(&X.alist[sub][t < NMAX ? t : 0u]);
+            const uint32_t ns = *reinterpret_cast<const uint32_t *>(&X.asize[sub][t < NMAX ? t : 0u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = (ks >> (8 * u)) & 0xFFu;
+                const double nk = (double)((ns >> (8 * u)) & 0xFFu);
+                const int rb_k = rowbase(k);
+                const bool in = t + u < na;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t me = sl + r * GROUP;
+                    int idx = me < k ? rb_me[r] + (int)k : rb_k + (int)me;
+                    idx = (me == k || !in || !alive[r]) ? NT : idx;
+                    double sv = S[idx];
+                    sv = sv <= kFar ? sv : kNothing;
+                    const bool better = sv * bn[r] < bs[r] * nk;
+                    bs[r] = better ? sv : bs[r];
+                    bn[r] = better ? nk : bn[r];
+                    bk[r] = better ? k : bk[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            if (alive[r]) {
+                const bool within = bs[r] <= (double)kQOne * (bn[r] * (double)X.size[sub][me]);
+                bk[r] = within ? bk[r] : 0xFFu;
+                X.nn[sub][me] = (uint8_t)bk[r];
+            }
+        }
+        __syncthreads();
+        // mutual nearest neighbours: the larger index goes into the smaller
+        bool dies[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP, k = bk[r];
+            dies[r] = alive[r] && k < me && X.nn[sub][k < NMAX ? k : 0u] == me;        // (k = 0xFF: nobody)
+        }
+        const BitSet<NW> dead = group_ballot<GROUP, R, NW>(dies, sub);
+        if (!__ballot(dead.any())) break;
+        merge_round(dead, dies, bk);
+    }
+    // the clusters as bit sets: every row adds its bit at its root
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        if (k < nn_)
+            for (int i = 0; i < NW; ++i) s_mask[k][i] = 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        if (k < nn_) atomicOr((unsigned long long *)&s_mask[root[r]][NW == 1 ? 0 : (k >> 6)], 1ull << (k & 63u));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        if (k < nn_)
+            for (int i = 0; i < NW; ++i) F[r].w[i] = s_mask[root[r]][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// agglomeration, fast path: partitions whose clusters can be read off the threshold graph
+// ---------------------------------------------------------------------------------------------
+//
+// What stage A0 emits depends only on the FINAL clusters of a partition (clusters by smallest member, members
+// in sorted order, floor means).  Two facts about average linkage over exact means pin them down without running it:
+//   * marks in different connected components of the graph {d(i,j) <= max_dist} are never merged: the mean of cross
+//     distances that all exceed the threshold exceeds it;
+//   * a component in which EVERY pair has d <= max_dist ends as exactly one cluster: while two of its clusters remain,
+//     their mean is within the threshold, so the rule keeps merging.
+// The fast pass evaluates d in binary32 (relative error < 4e-7; the fixed point's own step is 1.5e-8 of the threshold:
+// hence the 1e-5 guard band around max_dist), builds each mark's closed neighbourhood as a bit mask, and accepts the
+// partition when no pair falls inside the guard band and every neighbourhood equals the neighbourhood of its smallest
+// member (<=> every component is a clique).  Everything else gets the exact linkage (link_unit).  Both paths produce
+// the oracle's clusters; tests/test_gpu_cluster.py and tools/stress.py cover both.
+
+template <int GROUP, int R>
 struct FastSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
     uint4 ps[SUBS][NMAX];                                    // (pos, span, end, centre): one 16-byte broadcast read per pair
     uint64_t mask[SUBS][NMAX][NW];
-    double D[SUBS][KA][KA], sz[SUBS][KA];
-    uint32_t csz[SUBS][NMAX];                                // rows per component, at the component's smallest row
     unsigned long long sum[SUBS][NMAX][2];
-    uint32_t lab[SUBS][KA], aroot[SUBS][KA];
-    uint8_t atom[SUBS][NMAX];
 };
 
+// what a unit does: the threshold graph first and the exact linkage, in the same wavefront, for what that does not
+// settle -- or the exact linkage right away (the partitions of more than 64 marks: nearly none of them is a set of cliques)
+enum { kFastThenLink = 1, kLinkOnly = 2 };
+
 // one wave's worth of partitions (64 / GROUP of them, list[base ...]) of one size class
-template <int GROUP, int R, int KA>
-__device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, const ClWork &work,
-                                          unsigned char *smem)
+template <int GROUP, int R, int NCAP, int MODE>
+__device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &list, uint32_t base, unsigned char *smem_fast,
+                                          unsigned char *smem_link)
 {
     constexpr int NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
-    static_assert(NMAX <= 128 && (R == 1 || (GROUP * R) % 64 == 0 || GROUP * R <= 64), "unsupported shape");
-    FastSmem<GROUP, R, KA> &S = *reinterpret_cast<FastSmem<GROUP, R, KA> *>(smem);
+    static_assert(NMAX <= 128 && NCAP <= NMAX && (R == 1 || (GROUP * R) % 64 == 0 || GROUP * R <= 64), "unsupported shape");
+    FastSmem<GROUP, R> &S = *reinterpret_cast<FastSmem<GROUP, R> *>(smem_fast);
     const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
     constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     auto group_any = [&](bool x) -> bool { return ((__ballot(x) >> (sub * GROUP)) & gm) != 0ull; };
-    {
-        const uint32_t li = base + sub;
-        const bool has = li < L;
-        const uint32_t part = has ? list[li] : 0u;
-        const uint32_t s = has ? p.part_start[part] : 0u;
-        const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
-        __syncthreads();
-        uint32_t pk[R], spk[R], ek[R], ck[R], mk[R], rd[R];
-        bool bad = false;
+    const uint32_t li = base + sub;
+    const bool has = li < list.size();
+    const uint32_t part = has ? list[li] : 0u;
+    const uint32_t s = has ? p.part_start[part] : 0u;
+    const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+    __syncthreads();
+    uint32_t pk[R], spk[R], ek[R], ck[R], mk[R], rd[R];
+    bool bad = false;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t k = sl + r * GROUP;
-            pk[r] = spk[r] = mk[r] = rd[r] = 0;
-            if (k < n) {
-                mk[r] = mark_at(p, s + k);
-                const uint3 q = load_rec(p, mk[r]);
-                pk[r] = q.x;
-                spk[r] = q.y;
-                rd[r] = q.z;
-            }
-            ek[r] = pk[r] + spk[r];
-            ck[r] = pk[r] + (spk[r] >> 1);
-            if (k < n) S.ps[sub][k] = make_uint4(pk[r], spk[r], ek[r], ck[r]);
-            bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits: leave it to the exact path
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        pk[r] = spk[r] = mk[r] = rd[r] = 0;
+        if (k < n) {
+            const uint4 q = p.srec[s + k];
+            pk[r] = q.x;
+            spk[r] = q.y;
+            rd[r] = q.z;
+            mk[r] = q.w;
         }
-        __syncthreads();
-        // closed neighbourhoods at the thresholds; amb: some pair sits inside a threshold's guard band.  Level 0
-        // (max_dist itself) for everybody; the finer levels only where level 0 does not settle the partition.
-        BitSet<NW> N[kLevels][R];
-        bool amb[kLevels], amb0r[R];
+        ek[r] = pk[r] + spk[r];
+        ck[r] = pk[r] + (spk[r] >> 1);
+        if (k < n) S.ps[sub][k] = make_uint4(pk[r], spk[r], ek[r], ck[r]);
+        bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits: leave it to the exact path
+    }
+    __syncthreads();
+    BitSet<NW> F[R];                                     // the final cluster of each of this lane's marks
+    bool solved = n < 2;
 #pragma unroll
-        for (int r = 0; r < R; ++r) amb0r[r] = false;
+    for (int r = 0; r < R; ++r) {
+        F[r].clear();
+        F[r].set_if(sl + r * GROUP < n, sl + r * GROUP);
+    }
+    if (MODE != kLinkOnly) {
+        // closed neighbourhoods at the threshold; amb: some pair sits inside the guard band
+        BitSet<NW> N0[R];
+        bool amb = false;
 #pragma unroll
-        for (int l = 0; l < kLevels; ++l) {
-            amb[l] = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) N[l][r].clear();
-        }
+        for (int r = 0; r < R; ++r) N0[r].clear();
         // (32 columns at a time: the bits of one mask word are collected in one register, two instructions per pair)
         auto level0 = [&](auto wc) {
             constexpr uint32_t W = decltype(wc)::value;
@@ -991,12 +1226,12 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
                     const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
                     const float dp = (float)m * p.inv_norm;
                     const bool e_hi = fs <= (p.t_hi[0] - dp) * fm, e_lo = fs <= (p.t_lo[0] - dp) * fm;
-                    amb0r[r] = amb0r[r] || e_hi != e_lo;
+                    amb = amb || e_hi != e_lo;
                     acc[r] |= (e_hi ? 1u : 0u) << (j - 32u * W);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r) N[0][r].w[W >> 1] |= (uint64_t)acc[r] << (32u * (W & 1u));
+            for (int r = 0; r < R; ++r) N0[r].w[W >> 1] |= (uint64_t)acc[r] << (32u * (W & 1u));
         };
         level0(std::integral_constant<uint32_t, 0>{});
         if constexpr (NMAX > 32) level0(std::integral_constant<uint32_t, 1>{});
@@ -1005,394 +1240,86 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const uint32_t *lis
             level0(std::integral_constant<uint32_t, 3>{});
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            N[0][r].set_if(sl + r * GROUP < n, sl + r * GROUP);
-            amb[0] = amb[0] || amb0r[r];
-        }
-        // every component of a level's graph is a clique <=> each mark's neighbourhood equals that of its
-        // smallest member; leaves the level's masks in s_mask
-        auto cliques = [&](const BitSet<NW> (&Nl)[R]) -> bool {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                if (k < n)
-                    for (int i = 0; i < NW; ++i) S.mask[sub][k][i] = Nl[r].w[i];
-            }
-            __syncthreads();
-            bool differs = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                if (k < n) {
-                    const uint32_t f = Nl[r].first();
-                    BitSet<NW> o;
-                    for (int i = 0; i < NW; ++i) o.w[i] = S.mask[sub][f][i];
-                    differs = differs || !o.equals(Nl[r]);
-                }
-            }
-            return !group_any(differs);
-        };
-        const bool unfit = group_any(bad) || !p.fast;
-        BitSet<NW> F[R];                                     // the final cluster of each of this lane's marks
-#pragma unroll
-        for (int r = 0; r < R; ++r) F[r] = N[0][r];
-        const bool amb0 = group_any(amb[0]), cl0 = cliques(N[0]);       // collective: every lane takes part
-        bool solved = n < 2 || (!unfit && !amb0 && cl0);
-        const bool want2 = has && !solved && !unfit;
-        if (work.why && want2 && sl == 0) atomicAdd(&work.why[(GROUP == 64 ? (R == 2 ? 0 : 4) : 8) + 3], 1u);     // level 0 did not settle it
-        if (__ballot(want2)) {
-            // atoms: the cliques of the finest usable level -- they are complete clusters before anything else
-            // happens (every pair inside is closer than every pair across), so what remains is average linkage over
-            // the atoms, decided from binary32 estimates of their average distances when that is safe
-            const uint32_t nw = want2 ? n : 0u;
-            auto finer = [&](auto wc) {
-                constexpr uint32_t W = decltype(wc)::value;
-                const uint32_t j1 = min(nw, 32u * (W + 1u));
-                uint32_t acc[kLevels][R];
-#pragma unroll
-                for (int l = 1; l < kLevels; ++l)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) acc[l][r] = 0;
-                for (uint32_t j = 32u * W; j < j1; ++j) {
-                    const uint4 q = S.ps[sub][j];
-                    const uint32_t ej = q.z, cj = q.w;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
-                        const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
-                        const float dp = (float)m * p.inv_norm;
-#pragma unroll
-                        for (int l = 1; l < kLevels; ++l) {
-                            const bool e_hi = fs <= (p.t_hi[l] - dp) * fm, e_lo = fs <= (p.t_lo[l] - dp) * fm;
-                            amb[l] = amb[l] || e_hi != e_lo;
-                            acc[l][r] |= (e_hi ? 1u : 0u) << (j - 32u * W);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int l = 1; l < kLevels; ++l)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) N[l][r].w[W >> 1] |= (uint64_t)acc[l][r] << (32u * (W & 1u));
-            };
-            finer(std::integral_constant<uint32_t, 0>{});
-            if constexpr (NMAX > 32) finer(std::integral_constant<uint32_t, 1>{});
-            if constexpr (NMAX > 64) {
-                finer(std::integral_constant<uint32_t, 2>{});
-                finer(std::integral_constant<uint32_t, 3>{});
-            }
-#pragma unroll
-            for (int l = 1; l < kLevels; ++l)
-#pragma unroll
-                for (int r = 0; r < R; ++r) N[l][r].set_if(want2 && sl + r * GROUP < n, sl + r * GROUP);
-            const bool amb2 = group_any(amb[2]), cl2 = cliques(N[2]);
-            const bool amb1 = group_any(amb[1]), cl1 = cliques(N[1]);
-            const bool ok2 = !amb2 && cl2, ok1 = !amb1 && cl1;
-            bool two = want2 && (ok1 || ok2);
-            if (work.why && want2 && !two && sl == 0) atomicAdd(&work.why[GROUP == 64 ? (R == 2 ? 0 : 4) : 8], 1u);       // no clean level
-            BitSet<NW> A[R];
-            uint32_t ra[R], ai[R];
-            BitSet<NW> heads;
-            heads.clear();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                A[r] = ok1 ? N[1][r] : N[2][r];
-                ra[r] = A[r].first();
-                const unsigned long long b = (__ballot(two && sl + r * GROUP < n && ra[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
-                heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
-            }
-            const uint32_t m = heads.count();
-            if (work.why && two && m > (uint32_t)KA && sl == 0) atomicAdd(&work.why[(GROUP == 64 ? (R == 2 ? 0 : 4) : 8) + 1], 1u);   // too many atoms
-            two = two && m <= (uint32_t)KA;
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                ai[r] = two ? heads.count_below(ra[r]) : 0u;
-                if (two && k < n) {
-                    for (int i = 0; i < NW; ++i) S.mask[sub][k][i] = A[r].w[i];      // the chosen level's atoms
-                    S.atom[sub][k] = (uint8_t)ai[r];
-                    if (ra[r] == k) {
-                        S.aroot[sub][ai[r]] = k;
-                        S.sz[sub][ai[r]] = (double)A[r].count();
-                        S.lab[sub][ai[r]] = ai[r];
-                    }
-                }
-            }
-            if (two)
-                for (uint32_t e = sl; e < (uint32_t)(KA * KA); e += GROUP) S.D[sub][e / KA][e % KA] = 0.0;
-            __syncthreads();
-            if (__ballot(two)) {
-                // Row k's distances to the columns of one atom, summed while consecutive columns stay in that atom and
-                // then added to the atom pair's total in LDS (rows are in centre order, atoms mostly contiguous runs:
-                // about one flush per atom instead of a select per atom for every column; any order is correct)
-                float cur[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) cur[r] = 0.f;
-                const uint32_t n2 = two ? n : 0u;
-                uint32_t prev = n2 ? (uint32_t)S.atom[sub][0] : 0u;
-                auto flush = [&](uint32_t b) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (sl + r * GROUP < n && b != ai[r]) atomicAdd(&S.D[sub][ai[r]][b], (double)cur[r]);
-                        cur[r] = 0.f;
-                    }
-                };
-                for (uint32_t j = 0; j < n2; ++j) {
-                    const uint4 q = S.ps[sub][j];
-                    const uint32_t aj = S.atom[sub][j];
-                    const uint32_t ej = q.z, cj = q.w;
-                    if (aj != prev) {
-                        flush(prev);
-                        prev = aj;
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t mm = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], ej)), absdiff_u32(ck[r], cj));
-                        const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
-                        cur[r] += (float)mm * p.inv_norm + fs * __builtin_amdgcn_rcpf(fm);
-                    }
-                }
-                if (n2) flush(prev);
-                __syncthreads();
-                if (two) {
-                    // averages into the upper triangle (lanes share the pairs), then every lane of the group
-                    // runs the linkage on them (all lanes write the same values)
-                    for (uint32_t e = sl; e < m * m; e += GROUP) {
-                        const uint32_t a = e / m, b = e % m;
-                        if (a < b) S.D[sub][a][b] = (S.D[sub][a][b] + S.D[sub][b][a]) / (2.0 * S.sz[sub][a] * S.sz[sub][b]);
-                    }
-                }
-                __syncthreads();
-                bool okl = false;
-                if (two) okl = atoms_linkage<KA>(m, &S.D[sub][0][0], S.sz[sub], S.lab[sub], p.max_dist);
-                __syncthreads();
-                if (work.why && two && !okl && sl == 0) atomicAdd(&work.why[(GROUP == 64 ? (R == 2 ? 0 : 4) : 8) + 2], 1u);       // a decision too close
-                if (two && okl) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t mine = S.lab[sub][ai[r]];
-                        F[r].clear();
-                        for (uint32_t b = 0; b < m; ++b)
-                            if (S.lab[sub][b] == mine)
-                                for (int i = 0; i < NW; ++i) F[r].w[i] |= S.mask[sub][S.aroot[sub][b]][i];
-                    }
-                    solved = true;
-                }
-            }
-        }
-        if (__ballot(has && !solved)) {
-            // Not settled as a whole: settle it component by component.  A row is clean when it and all its
-            // neighbours (level 0) have guard-band-free neighbourhoods equal to that of their smallest member: its
-            // component is then a clique and one cluster.  The other rows are labelled with the smallest row of their
-            // component (min-label propagation over the neighbourhoods) and handed to cl_exact component by
-            // component; cl_rank finishes the partition once every row has its label.
-            const bool todo = has && !solved;
-            __syncthreads();
-            BitSet<NW> pass;
-            pass.clear();
-            bool clean[R];
-            // s_mask may hold another level by now: put level 0 back, then test the rows
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                if (todo && k < n)
-                    for (int i = 0; i < NW; ++i) S.mask[sub][k][i] = N[0][r].w[i];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                bool ok = todo && !unfit && k < n && !amb0r[r];
-                if (ok) {
-                    const uint32_t f = N[0][r].first();
-                    BitSet<NW> o;
-                    for (int i = 0; i < NW; ++i) o.w[i] = S.mask[sub][f][i];
-                    ok = o.equals(N[0][r]);
-                }
-                const unsigned long long b = (__ballot(ok) >> (sub * GROUP)) & gm;
-                pass.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
-            }
-            uint32_t lab[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                bool c = todo && !unfit && k < n;
-                for (int i = 0; i < NW; ++i) c = c && (N[0][r].w[i] & ~pass.w[i]) == 0ull;
-                clean[r] = c;
-                lab[r] = unfit ? 0u : k;                     // unfit: the masks mean nothing, the partition is one component
-                if (todo && k < n) { S.atom[sub][k] = (uint8_t)lab[r]; S.csz[sub][k] = 0; }
-            }
-            __syncthreads();
-            for (;;) {
-                bool changed = false;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t k = sl + r * GROUP;
-                    if (todo && !unfit && k < n && !clean[r]) {
-                        uint32_t m = lab[r];
-                        for (int i = 0; i < NW; ++i) {
-                            uint64_t w = N[0][r].w[i];
-                            while (w) {
-                                const uint32_t j = 64u * i + (uint32_t)__ffsll((long long)w) - 1u;
-                                w &= w - 1ull;
-                                m = min(m, (uint32_t)S.atom[sub][j]);
-                            }
-                        }
-                        changed = changed || m != lab[r];
-                        lab[r] = m;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (todo && sl + r * GROUP < n && !clean[r]) S.atom[sub][sl + r * GROUP] = (uint8_t)lab[r];
-                __syncthreads();
-                if (!__ballot(changed)) break;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (todo && sl + r * GROUP < n && !clean[r]) atomicAdd(&S.csz[sub][lab[r]], 1u);
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t k = sl + r * GROUP;
-                if (todo && k < n) {
-                    p.label8[s + k] = clean[r] ? (uint8_t)N[0][r].first() : (uint8_t)0xFF;
-                    p.comp8[s + k] = clean[r] ? (uint8_t)0xFF : (uint8_t)lab[r];
-                    if (!clean[r] && lab[r] == k) {
-                        const uint32_t m = S.csz[sub][k];
-                        const uint32_t hc = m <= 16 ? 0u : (m <= 32 ? 1u : (m <= 64 ? 2u : 3u));
-                        const uint32_t at = atomicAdd(&work.comp_count[hc], 1u);
-                        work.comp_list[(size_t)hc * p.M + 2 * (size_t)at] = part;
-                        work.comp_list[(size_t)hc * p.M + 2 * (size_t)at + 1] = k | (m << 8);
-                    }
-                }
-            }
-            if (todo && sl == 0) {
-                const int rc = size_class(n);
-                work.rank_list[(size_t)rc * p.M + atomicAdd(&work.rank_count[rc], 1u)] = part;
-            }
-        }
-        emit_prep<GROUP, R, NW, NMAX>(p, has && solved, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
-    }
-}
-
-// every size class in one launch, largest partitions first (they are the longest chains): a virtual block is one
-// wave's worth of partitions of one class
-constexpr size_t kFastSmemBytes = sizeof(FastSmem<64, 1, 8>) > sizeof(FastSmem<8, 1, 4>) ? sizeof(FastSmem<64, 1, 8>) : sizeof(FastSmem<8, 1, 4>);
-static_assert(kFastSmemBytes >= sizeof(FastSmem<32, 1, 4>) && kFastSmemBytes >= sizeof(FastSmem<16, 1, 4>), "shared scratch too small");
-
-// one size class per launch: what large inputs use (the fused kernel needs the registers of all five variants at
-// once, which halves the occupancy; with millions of partitions per class there is nothing to gain from fusing)
-template <int GROUP, int R, int KA>
-__global__ __launch_bounds__(64) void cl_fast_one(const ClParams p, const uint32_t *list, const uint32_t *count, const ClWork work)
-{
-    __shared__ __align__(16) unsigned char smem[sizeof(FastSmem<GROUP, R, KA>)];
-    const uint32_t L = *count;
-    for (uint32_t base = blockIdx.x * (64 / GROUP); base < L; base += gridDim.x * (64 / GROUP))
-        fast_unit<GROUP, R, KA>(p, list, L, base, work, smem);
-}
-
-__global__ __launch_bounds__(64, 4) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const ClWork work)
-{
-    __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
-    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3];
-    const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
-    const size_t M = p.M;
-    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
-        if (vb < b3) fast_unit<64, 1, 8>(p, lists + 3 * M, c3, vb, work, smem);
-        else if (vb < b2) fast_unit<32, 1, 4>(p, lists + 2 * M, c2, (vb - b3) * 2, work, smem);
-        else if (vb < b1) fast_unit<16, 1, 4>(p, lists + 1 * M, c1, (vb - b2) * 4, work, smem);
-        else fast_unit<8, 1, 4>(p, lists, c0, (vb - b1) * 8, work, smem);
-    }
-}
-
-// Partitions the fast pass did not settle as a whole, after cl_exact: every row has its label; group the rows by
-// label and finish like the fast pass does.
-template <int GROUP, int R>
-struct RankSmem {
-    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
-    uint2 ps[SUBS][NMAX];
-    uint64_t mask[SUBS][NMAX][NW];
-    unsigned long long sum[SUBS][NMAX][2];
-};
-
-template <int GROUP, int R>
-__device__ __forceinline__ void rank_unit(const ClParams &p, const uint32_t *list, uint32_t L, uint32_t base, unsigned char *smem)
-{
-    constexpr int NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
-    RankSmem<GROUP, R> &S = *reinterpret_cast<RankSmem<GROUP, R> *>(smem);
-    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
-    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
-    {
-        const uint32_t li = base + sub;
-        const bool has = li < L;
-        const uint32_t part = has ? list[li] : 0u;
-        const uint32_t s = has ? p.part_start[part] : 0u;
-        const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+        for (int r = 0; r < R; ++r) N0[r].set_if(sl + r * GROUP < n, sl + r * GROUP);
+        // every component of the graph is a clique <=> each mark's neighbourhood equals that of its smallest member
         __syncthreads();
-        uint32_t lab[R], mk[R], rd[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t k = sl + r * GROUP;
-            lab[r] = 0xFFFFu;
-            mk[r] = rd[r] = 0;
-            if (k < n) {
-                mk[r] = mark_at(p, s + k);
-                const uint3 q = load_rec(p, mk[r]);
-                S.ps[sub][k] = make_uint2(q.x, q.y);
-                rd[r] = q.z;
-                lab[r] = p.label8[s + k];
-            }
+            if (k < n)
+                for (int i = 0; i < NW; ++i) S.mask[sub][k][i] = N0[r].w[i];
         }
-        BitSet<NW> heads, F[R];
-        heads.clear();
+        __syncthreads();
+        bool differs = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            F[r].clear();
-            const unsigned long long b = (__ballot(lab[r] == sl + r * GROUP) >> (sub * GROUP)) & gm;
-            heads.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
-        }
-        // one round per cluster head of any group of the wave (wave-uniform trip count: ballots inside)
-        BitSet<NW> left = heads;
-        for (;;) {
-            bool any = false;
-            for (int i = 0; i < NW; ++i) any = any || left.w[i] != 0ull;
-            if (!__ballot(any)) break;
-            const uint32_t h = any ? left.first() : 0xFFFFFFu;
-            BitSet<NW> mh;
-            mh.clear();
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const unsigned long long b = (__ballot(any && lab[r] == h) >> (sub * GROUP)) & gm;
-                mh.w[(r * GROUP) >> 6] |= b << ((r * GROUP) & 63);
+            const uint32_t k = sl + r * GROUP;
+            if (k < n) {
+                const uint32_t f = N0[r].first();
+                BitSet<NW> o;
+                for (int i = 0; i < NW; ++i) o.w[i] = S.mask[sub][f][i];
+                differs = differs || !o.equals(N0[r]);
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (any && lab[r] == h) F[r] = mh;
-            if (any)
-                for (int i = 0; i < NW; ++i) left.w[i] &= (h >> 6) == (uint32_t)i ? ~(1ull << (h & 63u)) : ~0ull;
         }
-        emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
+        const bool unfit = group_any(bad) || !p.fast;
+        const bool amb0 = group_any(amb), cl0 = !group_any(differs);       // collective: every lane takes part
+        if (n >= 2 && !unfit && !amb0 && cl0) {
+            solved = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) F[r] = N0[r];
+        }
     }
+    const bool need = has && !solved;
+    if (__ballot(need)) {
+        LinkSmem<GROUP, R, NCAP> &X = *reinterpret_cast<LinkSmem<GROUP, R, NCAP> *>(smem_link);
+        link_unit<GROUP, R, NCAP, NW>(p, need, n, sub, sl, pk, spk, group_any(bad), X, S.mask[sub], F);
+    }
+    emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
 }
 
-// (the partitions of more than 64 marks -- all of them went to the exact pass -- come straight from their class list)
-__global__ __launch_bounds__(64) void cl_rank_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts, const uint32_t *big_list,
-                                                  const uint32_t *big_count)
+// one size class per launch: what large inputs use (the fused kernel needs the registers and the LDS of all variants at
+// once; with millions of partitions per class there is nothing to gain from fusing)
+template <int GROUP, int R, int NCAP, int MODE>
+__global__ __launch_bounds__(64) void cl_fast_one(const ClParams p, const uint32_t *items, const uint32_t *counts /* [kShards] */)
 {
-    __shared__ __align__(16) unsigned char smem[sizeof(RankSmem<64, 2>)];
-    const uint32_t c0 = cnts[0], c1 = cnts[1], c2 = cnts[2], c3 = cnts[3], c4 = *big_count;
-    const uint32_t b4 = c4, b3 = b4 + c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    __shared__ __align__(16) unsigned char smem[sizeof(FastSmem<GROUP, R>)];
+    __shared__ __align__(16) unsigned char smem_link[sizeof(LinkSmem<GROUP, R, NCAP>)];
+    __shared__ uint32_t s_pref[kShards + 1];
+    worklist_prefix(counts, s_pref);
+    __syncthreads();
+    const WorkList list{items, s_pref, p.tps * kScanTile};
+    const uint32_t L = list.size();
+    for (uint32_t base = blockIdx.x * (64 / GROUP); base < L; base += gridDim.x * (64 / GROUP))
+        fast_unit<GROUP, R, NCAP, MODE>(p, list, base, smem, smem_link);
+}
+
+// the classes of up to 64 marks in one launch, largest partitions first (they are the longest chains): a virtual block is
+// one wave's worth of partitions of one class.  (The partitions of more than 64 marks have their own launch beside it:
+// the triangle of a hundred rows is 40 KB of LDS, which would keep this kernel's occupancy down for everybody.)
+constexpr size_t kFastSmemBytes = sizeof(FastSmem<64, 1>) > sizeof(FastSmem<8, 1>) ? sizeof(FastSmem<64, 1>) : sizeof(FastSmem<8, 1>);
+static_assert(kFastSmemBytes >= sizeof(FastSmem<32, 1>) && kFastSmemBytes >= sizeof(FastSmem<16, 1>), "shared scratch too small");
+constexpr size_t kLinkSmemBytes = sizeof(LinkSmem<64, 1, 64>);
+static_assert(kLinkSmemBytes >= sizeof(LinkSmem<32, 1, 32>) && kLinkSmemBytes >= sizeof(LinkSmem<16, 1, 16>) &&
+              kLinkSmemBytes >= sizeof(LinkSmem<8, 1, 8>), "shared scratch too small");
+
+__global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts /* [kClasses][kShards] */)
+{
+    __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
+    __shared__ __align__(16) unsigned char smem_link[kLinkSmemBytes];
+    __shared__ uint32_t s_pref[4][kShards + 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) worklist_prefix(cnts + c * kShards, s_pref[c]);
+    __syncthreads();
     const size_t M = p.M;
+    const uint32_t span = p.tps * kScanTile;
+    const WorkList l0{lists, s_pref[0], span}, l1{lists + M, s_pref[1], span}, l2{lists + 2 * M, s_pref[2], span}, l3{lists + 3 * M, s_pref[3], span};
+    const uint32_t c0 = l0.size(), c1 = l1.size(), c2 = l2.size(), c3 = l3.size();
+    const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
     for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
-        if (vb < b4) rank_unit<64, 2>(p, big_list, c4, vb, smem);
-        else if (vb < b3) rank_unit<64, 1>(p, lists + 3 * M, c3, vb - b4, smem);
-        else if (vb < b2) rank_unit<32, 1>(p, lists + 2 * M, c2, (vb - b3) * 2, smem);
-        else if (vb < b1) rank_unit<16, 1>(p, lists + 1 * M, c1, (vb - b2) * 4, smem);
-        else rank_unit<8, 1>(p, lists, c0, (vb - b1) * 8, smem);
+        if (vb < b3) fast_unit<64, 1, 64, kFastThenLink>(p, l3, vb, smem, smem_link);
+        else if (vb < b2) fast_unit<32, 1, 32, kFastThenLink>(p, l2, (vb - b3) * 2, smem, smem_link);
+        else if (vb < b1) fast_unit<16, 1, 16, kFastThenLink>(p, l1, (vb - b2) * 4, smem, smem_link);
+        else fast_unit<8, 1, 8, kFastThenLink>(p, l0, (vb - b1) * 8, smem, smem_link);
     }
 }
 
@@ -1516,16 +1443,17 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t nb_sc = (M + kScanTile - 1) / kScanTile;
     const uint32_t nb_rx = (M + kRxTile - 1) / kRxTile;
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
-    const size_t sizes[14] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
-                              ((size_t)M + 1) * 4, ((size_t)M + 1) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 128, (size_t)M * 4 * (2 * kClasses + 4), ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8)};
+    const size_t sizes[15] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
+                              ((size_t)nb_sc + 1) * sizeof(PartSum), ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
+                              ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + kClasses * kShards), (size_t)M * 4 * kClasses, ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8), (size_t)M * 16};
     int rc;
-    for (int i = 0; i < 14; ++i)
+    for (int i = 0; i < 15; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
     uint64_t *keysA = (uint64_t *)ctx->cl_ws[0].ptr, *keysB = (uint64_t *)ctx->cl_ws[1].ptr;
     uint32_t *valsA = (uint32_t *)ctx->cl_ws[2].ptr, *valsB = (uint32_t *)ctx->cl_ws[3].ptr;
     uint32_t *hist = (uint32_t *)ctx->cl_ws[4].ptr;
-    uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr;
+    uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr;             // the partition scan's tile summaries
+    uint32_t *tile_first = (uint32_t *)ctx->cl_ws[6].ptr;       // [tiles + 1] first partition starting in each scan tile
     uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
     uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
     uint32_t *cbase = (uint32_t *)ctx->cl_ws[13].ptr + (M + 1);      // (the first M + 1 words hold label8 / comp8)
@@ -1586,103 +1514,68 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     {
         const LoadHead heads{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)};
         PartSum *tiles = (PartSum *)tmpA;                         // 3 words per 2048 marks
-        hipLaunchKernelGGL(part_reduce, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 2);
+        hipLaunchKernelGGL(part_reduce, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(kClasses * kShards));
         if (nb_sc <= kSelfSpine && !big_sort) {
             hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
-                               part_start, scal);
+                               part_start, scal, tile_first);
         } else {
             hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
             hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
-                               part_start, scal);
+                               part_start, scal, tile_first);
         }
     }
     p.part_start = part_start; p.n_parts = scal; p.pc = pc;
     p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
+    p.srec = (uint4 *)ctx->cl_ws[14].ptr;
     const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
-    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M] partitions by size class, then the work lists
-    uint32_t *cnts = scal + 2;
-    ClWork work;
-    work.comp_list = lists + (size_t)kClasses * M;               // [4][M]
-    work.rank_list = work.comp_list + 4 * (size_t)M;             // [kClasses][M]
-    work.comp_count = scal + 7;
-    work.rank_count = scal + 11;
-    work.why = nullptr;
-    if (getenv("DUET_CL_DEBUG")) {
-        work.why = scal + 16;
-        HIP_TRY(ctx, hipMemsetAsync(work.why, 0, 64, st));
-    }
-    p.label8 = (uint8_t *)ctx->cl_ws[13].ptr;
-    p.comp8 = p.label8 + M;
+    uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M] partitions by size class, each list in kShards pieces
+    uint32_t *cnts = scal + 64;                                  // [kClasses][kShards]
+    p.tps = (nb_sc + kShards - 1) / kShards;
     p.inv_norm = (float)(1.0 / pr->normalizer);
-    for (int l = 0; l < 3; ++l) {
-        p.t_lo[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 - 1e-5));
-        p.t_hi[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 + 1e-5));
-    }
-    p.fast = (pr->max_dist >= 0 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
+    p.t_lo[0] = (float)(pr->max_dist * (1.0 - 1e-5));
+    p.t_hi[0] = (float)(pr->max_dist * (1.0 + 1e-5));
+    p.fast = (pr->max_dist >= 1e-6 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
-    // launches over the partitions, whose number only the device knows: an eighth of the bound (SV-like data: ~10 marks per
-    // partition), at least 256 workgroups, striding
-    const uint32_t g_parts = std::min((M + 1023u) / 1024u, std::max(256u, (M + 1023u) / 1024u / 8u));
-    hipLaunchKernelGGL(cl_classes, dim3(g_parts), dim3(1024), 0, st, p, lists, cnts);
-    const uint32_t gridw = M < 32768u ? M : 32768u;
+    p.box = (ctx->dbg & DUET_DBG_CLUSTER_NOBOX) ? 0u : 1u;
+    p.invn = 1.0 / pr->normalizer;
+    p.scale = (double)kQOne / pr->max_dist;
+    p.mergeable = pr->max_dist >= 0 ? 1u : 0u;
+    // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
+    hipLaunchKernelGGL(cl_box, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
+    const uint32_t gridw = std::min(32768u, std::max(1024u, M / 256u));     // (a wavefront per virtual block, striding)
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
     const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
+    const uint32_t *l4 = lists + 4 * (size_t)M, *c4 = cnts + 4 * kShards;
+    // the partitions of more than 64 marks on the side stream: few, long chains
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+    if (cap100) hipLaunchKernelGGL((cl_fast_one<64, 2, 100, kLinkOnly>), dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p, l4, c4);
+    else hipLaunchKernelGGL((cl_fast_one<64, 2, 128, kLinkOnly>), dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p, l4, c4);
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
     if (small) {
-        // partitions of more than 64 marks go whole to the exact pass right away, beside the fast pass over the other size
-        // classes (one launch) and the exact pass over what that leaves.  The two chains take about as long as each other; the
-        // whole-partition chain stays on the CALLER's stream and the other one goes to the side stream: a cross-stream event
-        // that is already signalled when its waiter arrives costs nothing, one that is not costs ~13 us after the signal --
-        // so the stream that goes on afterwards should be the one that finishes last, and on SV-like data that is this chain.
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(cap100 ? cl_exact_big<true, 100> : cl_exact_big<true, 128>), dim3(grid < 4096u ? grid : 4096u),
-                           dim3(64), 0, st, p, (const uint32_t *)(lists + 4 * (size_t)M), (const uint32_t *)(cnts + 4));
-        hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)lists, (const uint32_t *)cnts, work);
-        hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)work.comp_list,
-                           (const uint32_t *)work.comp_count);
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+        // one launch for the classes of up to 64 marks
+        hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
     } else {
-        // the side stream takes the partitions of more than 64 marks (few, long chains: a launch of their own would leave most
-        // of the chip idle) and then the components of more than 64 rows they leave; beside them one launch per size class
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-        hipLaunchKernelGGL((cl_fast_one<64, 2, 16>), dim3(grid), dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(lists + 4 * (size_t)M),
-                           (const uint32_t *)(cnts + 4), work);
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], ctx->cl_side[0]));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(cap100 ? cl_exact_big<false, 100> : cl_exact_big<false, 128>), dim3(grid < 4096u ? grid : 4096u),
-                           dim3(64), 0, ctx->cl_side[0], p, (const uint32_t *)(work.comp_list + 3 * (size_t)M),
-                           (const uint32_t *)(work.comp_count + 3));
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
-        hipLaunchKernelGGL((cl_fast_one<64, 1, 8>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M),
-                           (const uint32_t *)(cnts + 3), work);
-        hipLaunchKernelGGL((cl_fast_one<32, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M),
-                           (const uint32_t *)(cnts + 2), work);
-        hipLaunchKernelGGL((cl_fast_one<16, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M),
-                           (const uint32_t *)(cnts + 1), work);
-        hipLaunchKernelGGL((cl_fast_one<8, 1, 4>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)(cnts + 0), work);
-        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[1], 0));        // cl_exact_small also takes what the >64 class left
-        hipLaunchKernelGGL(cl_exact_small, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.comp_list,
-                           (const uint32_t *)work.comp_count);
+        // one launch per size class (the registers and the LDS each variant needs, not the largest one's)
+        hipLaunchKernelGGL((cl_fast_one<64, 1, 64, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M), (const uint32_t *)(cnts + 3 * kShards));
+        hipLaunchKernelGGL((cl_fast_one<32, 1, 32, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M), (const uint32_t *)(cnts + 2 * kShards));
+        hipLaunchKernelGGL((cl_fast_one<16, 1, 16, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M), (const uint32_t *)(cnts + 1 * kShards));
+        hipLaunchKernelGGL((cl_fast_one<8, 1, 8, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
     }
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
-    // ranks: the partitions of more than 64 marks come from their class list (small: all of them) or from the fast pass's
-    // list of unsettled ones
-    hipLaunchKernelGGL(cl_rank_all, dim3(grid), dim3(64), 0, st, p, (const uint32_t *)work.rank_list,
-                       (const uint32_t *)work.rank_count,
-                       (const uint32_t *)(small ? lists + 4 * (size_t)M : work.rank_list + 4 * (size_t)M),
-                       (const uint32_t *)(small ? cnts + 4 : work.rank_count + 4));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
     p.cbase = cbase;
     hipLaunchKernelGGL(cl_emit, dim3(std::min(g256.x, std::max(1024u, g256.x / 8u))), b256, 0, st, p);
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
-        uint32_t h[32];
+        uint32_t h[64 + kClasses * kShards];
         HIP_TRY(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        fprintf(stderr, "[duet_cluster] parts %u classes %u %u %u %u %u components %u %u %u %u partitions to rank %u %u %u %u %u\n", h[0], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
-        fprintf(stderr, "[duet_cluster] gave up (no clean level / too many atoms / decision too close): >64: %u %u %u  33..64: %u %u %u  <=32: %u %u %u;  "
-                        "not settled by level 0: %u %u %u\n",
-                h[16], h[17], h[18], h[20], h[21], h[22], h[24], h[25], h[26], h[19], h[23], h[27]);
+        uint32_t c[kClasses] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < kClasses; ++k)
+            for (int sh = 0; sh < kShards; ++sh) c[k] += h[64 + k * kShards + sh];
+        fprintf(stderr, "[duet_cluster] parts %u; past the box test, by size class: %u %u %u %u %u\n", h[0], c[0], c[1], c[2], c[3], c[4]);
     }
     return DUET_OK;
 }

@@ -134,12 +134,13 @@ DUET_API int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *prob, uint8_
 DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 
 /* Diagnostics: low bits ablate E/F kernel phases (tools/ablate.py); DUET_DBG_CLUSTER_EXACT sends every A0
- * partition through the exact binary64 agglomeration instead of the threshold-graph fast path (the outputs are
+ * partition through the exact linkage instead of the bounding-box / threshold-graph fast paths (the outputs are
  * identical; tests use it to exercise both).  0 in production. */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */
 #define DUET_DBG_CLUSTER_PAIRS 0x400u   /* A0: sort (key, mark index) pairs even when the index fits the key's spare bits */
+#define DUET_DBG_CLUSTER_NOBOX 0x800u   /* A0: no bounding-box test: every partition goes through the threshold-graph pair loops */
 DUET_API int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags);
 
 /* Debug/inspection: copy contig k's sorted seed-PS array of the LAST run to `out` (capacity `cap`),

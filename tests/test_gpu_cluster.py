@@ -22,9 +22,11 @@ def ctx():
 
 def check(ctx, marks, **kw):
     want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
-    # hints on/off (sort key width), threshold-graph fast path on/off (DUET_DBG_CLUSTER_EXACT = 0x100)
-    # ... the launch structure of large inputs (DUET_DBG_CLUSTER_LARGE = 0x200), the pair sort (DUET_DBG_CLUSTER_PAIRS = 0x400)
-    for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600)):
+    # hints on/off (sort key width), fast paths on/off (DUET_DBG_CLUSTER_EXACT = 0x100: everything through the exact linkage)
+    # ... the launch structure of large inputs (DUET_DBG_CLUSTER_LARGE = 0x200), the pair sort (DUET_DBG_CLUSTER_PAIRS = 0x400),
+    # no bounding-box test (DUET_DBG_CLUSTER_NOBOX = 0x800: every partition through the threshold-graph pair loops)
+    for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600), (True, 0x800),
+                       (True, 0xA00), (True, 0x300)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
