@@ -142,16 +142,21 @@ def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None and a.size else ctypes.c_void_p(0)
 
 
+CONTEXTS_CREATED = 0            # > 0: this process has initialised HIP (duet_amd/launch.py refuses to start ranks from it)
+
+
 class Context(object):
     """One duet_ctx on one HIP device."""
 
     def __init__(self, device_id=0):
+        global CONTEXTS_CREATED
         self.lib = load()
         self.handle = self.lib.duet_ctx_create(int(device_id))
         if not self.handle:
             raise DuetLibraryError('duet_ctx_create(%d) failed: %s' % (
                 device_id, self.lib.duet_last_error(None).decode('utf-8', 'replace')))
         self.device_id = int(device_id)
+        CONTEXTS_CREATED += 1
 
     def close(self):
         if getattr(self, 'handle', None):

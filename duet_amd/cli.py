@@ -24,7 +24,7 @@ def pipeline(a):
             (stages.snp_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.min_allele_frequency, a.thread, a.include_all_ctgs)),
             (stages.snp_phasing, (a.OUTPUT, a.REFERENCE, a.BAM, a.thread)),
             (sv_phasing_from_bams, (a.OUTPUT, a.sv_min_size, a.min_support_read, a.thread, a.include_all_ctgs,
-                                    a.cluster_max_distance, a.device)),
+                                    a.cluster_max_distance, a.device, a.gpus)),
         )
     return (
         (stages.snp_calling, (a.OUTPUT, a.REFERENCE, a.BAM, a.min_allele_frequency, a.thread, a.include_all_ctgs)),
@@ -43,6 +43,11 @@ def main(argv):
     began = time.time()
     logging.info(_BAR + ' DUET STARTED ' + _BAR)
     todo = pipeline(a)
+    if a.gpus > 1:
+        # N devices and the library, checked in a child BEFORE the external stages run (hours of Clair3 / WhatsHap should
+        # not end in "no GPU"); this process stays GPU-free -- it starts the ranks later (duet_amd/launch.py)
+        from duet_amd import launch
+        launch.probe_devices(1 if os.environ.get('DUET_ONE_GPU') == '1' else a.gpus)
     for fn, args in todo[:-1]:
         fn(*args)
     if a.gpus <= 1:

@@ -199,6 +199,8 @@ struct duet_ingest {
     std::string err;
     // VCF
     std::vector<char> vcf;
+    std::string vcf_path;                          // what `vcf` holds (duet_ingest_vcf_precount reads it first, parse reuses it)
+    std::vector<uint8_t> skip;                     // per contig: its records are another rank's (duet_ingest_set_owned); empty = none
     std::vector<Span> contig_lines;               // first tokens containing '##contig=<ID='
     std::vector<uint32_t> cand_ctg_off, read_off, cand_pos, cand_svlen, cand_svread, cand_refread, cand_off, mark_read;
     std::vector<uint8_t> cand_gt_ok, cand_plus;   // cand_plus: svtype is exactly INS or DUP (sign rule, :225)
@@ -803,7 +805,10 @@ int vcf_begin(duet_ingest *g, const char *path, int threads, VcfStage &st)
     };
     g->threads = threads > 0 ? threads : 1;
     if (g->alias) return decline("contig list names a contig twice");
-    if (!read_file(path, g->vcf)) { st.err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+    if (g->vcf_path != path || g->vcf.empty()) {
+        if (!read_file(path, g->vcf)) { st.err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+        g->vcf_path = path;
+    }
     const char *d = g->vcf.data();
     const size_t n = g->vcf.size();
     if (n && memchr(d, 0, n)) return decline("NUL byte in the VCF");
@@ -854,23 +859,33 @@ int vcf_begin(duet_ingest *g, const char *path, int threads, VcfStage &st)
             Rec r;
             int nt = 0;
             size_t i = p;
-            while (i < e) {
-                while (i < e && is_py_space((unsigned char)d[i])) ++i;
-                if (i >= e) break;
-                size_t j = i;
-                while (j < e && !is_py_space((unsigned char)d[j])) ++j;
-                if (nt < 10) r.tok[nt] = Span{d + i, j - i};
-                ++nt;
-                i = j;
-            }
-            if (nt == 0) {   // a blank line raises IndexError upstream (read_file.py:30)
+            // the first token decides what the line is; only a listed contig's record needs the other nine
+            while (i < e && is_py_space((unsigned char)d[i])) ++i;
+            if (i >= e) {    // a blank line raises IndexError upstream (read_file.py:30)
                 o.why = "blank line in the VCF";
                 return;
+            }
+            {
+                size_t j = i;
+                while (j < e && !is_py_space((unsigned char)d[j])) ++j;
+                r.tok[0] = Span{d + i, j - i};
+                nt = 1;
+                i = j;
             }
             if (contains(r.tok[0], "##contig=<ID=")) o.contig_lines.push_back(r.tok[0]);
             key.assign(r.tok[0].p, r.tok[0].n);
             auto it = g->owner.find(key);
             if (it != g->owner.end()) {
+                if (!g->skip.empty() && g->skip[it->second]) continue;     // another rank's contig: that rank vouches for the record
+                while (i < e) {
+                    while (i < e && is_py_space((unsigned char)d[i])) ++i;
+                    if (i >= e) break;
+                    size_t j = i;
+                    while (j < e && !is_py_space((unsigned char)d[j])) ++j;
+                    if (nt < 10) r.tok[nt] = Span{d + i, j - i};
+                    ++nt;
+                    i = j;
+                }
                 if (nt < 10) { o.why = "record with fewer than 10 columns"; return; }
                 // an 11th token shifts upstream's appended columns (read_file.py:37): TypeError in generate_callinfo
                 if (nt > 10) { o.why = "record with more than 10 columns"; return; }
@@ -1142,19 +1157,20 @@ int duet_ingest_get_arrays(const duet_ingest *g, duet_ingest_arrays *o)
     return DUET_INGEST_OK;
 }
 
-int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, int include_all_ctgs, char **text,
-                     uint64_t *len)
+// slot of a candidate's CHROM text: 2 * contig + (0: spelled chr<name>, 1: spelled <name>)
+static inline uint32_t text_slot(const duet_ingest *g, uint32_t contig, const Span &chrom)
 {
-    if (!g || !g->parsed || !text || !len) return DUET_INGEST_INVALID;
-    const size_t C = g->cand_pos.size();
-    if (C && (!pred || !ps)) return DUET_INGEST_INVALID;
-    std::string out;
-    out.reserve(4096 + C * 48);
-    if (include_all_ctgs >= 0) {
-        const int hrc = build_header(g, include_all_ctgs, out);
-        if (hrc) return hrc;
-    }
+    const std::string &nm = g->contigs[contig];
+    return 2u * contig + ((chrom.n == nm.size() && memcmp(chrom.p, nm.data(), nm.size()) == 0) ? 1u : 0u);
+}
 
+// rows of every candidate with pred != 0, sorted as upstream sorts them (:206-229).  id_base == null: numbered 1, 2, ... ;
+// else the rows of CHROM-text slot s are numbered id_base[s], id_base[s] + 1, ... (a rank of a sharded run numbers its
+// blocks as the whole call set would) and slot_off / slot_len receive each slot's byte range in `out`.
+static int emit_rows(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, const uint64_t *id_base, std::string &out,
+                     uint64_t *slot_off, uint64_t *slot_len)
+{
+    const size_t C = g->cand_pos.size();
     // emission order (:206-228): contig, PS-class 0/1/2, file order; candidates are already contig-major
     std::vector<uint32_t> idx;
     std::vector<uint8_t> cls;
@@ -1197,8 +1213,19 @@ int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, in
     static const char *const kHp[4] = {"", "1|0", "0|1", "1|1"};
     char num[64];
     uint64_t row = 0;
+    uint32_t cur_slot = 0xFFFFFFFFu;
+    if (slot_off) for (int i = 0; i < 2 * K; ++i) { slot_off[i] = 0; slot_len[i] = 0; }
     for (uint32_t oi : ord) {
         const uint32_t c = idx[oi];
+        if (id_base) {
+            const uint32_t sl = text_slot(g, ctg_of[oi], g->c_chrom[c]);
+            if (sl != cur_slot) {
+                if (cur_slot != 0xFFFFFFFFu && slot_off) slot_len[cur_slot] = out.size() - slot_off[cur_slot];
+                cur_slot = sl;
+                row = id_base[sl] - 1;
+                if (slot_off) slot_off[sl] = out.size();
+            }
+        }
         ++row;
         out.append(g->c_chrom[c].p, g->c_chrom[c].n);
         int w = snprintf(num, sizeof(num), "\t%u\tDuet.%llu\t", g->cand_pos[c], (unsigned long long)row);
@@ -1214,12 +1241,112 @@ int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, in
         w = snprintf(num, sizeof(num), ">\tHP:PS\t%s:%u\n", kHp[pred[c] & 3], ps[c]);
         out.append(num, w);
     }
+    if (id_base && cur_slot != 0xFFFFFFFFu && slot_off) slot_len[cur_slot] = out.size() - slot_off[cur_slot];
+    return DUET_INGEST_OK;
+}
+
+static int hand_over(const std::string &out, char **text, uint64_t *len)
+{
     char *buf = (char *)malloc(out.size() + 1);
     if (!buf) return DUET_INGEST_INVALID;
     memcpy(buf, out.data(), out.size());
     buf[out.size()] = 0;
     *text = buf;
     *len = out.size();
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_emit(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, int include_all_ctgs, char **text,
+                     uint64_t *len)
+{
+    if (!g || !g->parsed || !text || !len) return DUET_INGEST_INVALID;
+    const size_t C = g->cand_pos.size();
+    if (C && (!pred || !ps)) return DUET_INGEST_INVALID;
+    std::string out;
+    out.reserve(4096 + C * 48);
+    if (include_all_ctgs >= 0) {
+        const int hrc = build_header(g, include_all_ctgs, out);
+        if (hrc) return hrc;
+    }
+    const int rc = emit_rows(g, pred, ps, nullptr, out, nullptr, nullptr);
+    if (rc) return rc;
+    return hand_over(out, text, len);
+}
+
+int duet_ingest_count_kept(duet_ingest *g, const uint8_t *pred, uint64_t *kept)
+{
+    if (!g || !g->parsed || !kept) return DUET_INGEST_INVALID;
+    const size_t C = g->cand_pos.size();
+    if (C && !pred) return DUET_INGEST_INVALID;
+    const int K = (int)g->contigs.size();
+    for (int i = 0; i < 2 * K; ++i) kept[i] = 0;
+    int k = 0;
+    for (size_t c = 0; c < C; ++c) {
+        while (k < K && c >= g->cand_ctg_off[k + 1]) ++k;
+        if (pred[c]) ++kept[text_slot(g, (uint32_t)k, g->c_chrom[c])];
+    }
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_emit_blocks(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, const uint64_t *id_base, char **text,
+                            uint64_t *len, uint64_t *slot_off, uint64_t *slot_len)
+{
+    if (!g || !g->parsed || !text || !len || !id_base || !slot_off || !slot_len) return DUET_INGEST_INVALID;
+    const size_t C = g->cand_pos.size();
+    if (C && (!pred || !ps)) return DUET_INGEST_INVALID;
+    std::string out;
+    out.reserve(64 + C * 48);
+    const int rc = emit_rows(g, pred, ps, id_base, out, slot_off, slot_len);
+    if (rc) return rc;
+    return hand_over(out, text, len);
+}
+
+int duet_ingest_set_owned(duet_ingest *g, const uint8_t *owned)
+{
+    if (!g || g->parsed) return DUET_INGEST_INVALID;
+    g->skip.clear();
+    if (owned) {
+        g->skip.resize(g->contigs.size());
+        for (size_t k = 0; k < g->contigs.size(); ++k) g->skip[k] = owned[k] ? 0 : 1;
+    }
+    return DUET_INGEST_OK;
+}
+
+int duet_ingest_vcf_precount(duet_ingest *g, const char *path, uint64_t *n_records, uint64_t *n_bytes)
+{
+    if (!g || !path || !n_records || !n_bytes) return DUET_INGEST_INVALID;
+    if (g->vcf_path != path || g->vcf.empty()) {
+        if (!read_file(path, g->vcf)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+        g->vcf_path = path;
+    }
+    const char *d = g->vcf.data();
+    const size_t n = g->vcf.size();
+    const size_t K = g->contigs.size();
+    for (size_t k = 0; k < K; ++k) { n_records[k] = 0; n_bytes[k] = 0; }
+    const bool has_cr = n && memchr(d, '\r', n);
+    std::string key;
+    size_t p = 0;
+    while (p < n) {
+        size_t e;
+        if (!has_cr) {
+            const char *q = (const char *)memchr(d + p, '\n', n - p);
+            e = q ? (size_t)(q - d) : n;
+        } else {
+            e = p;
+            while (e < n && d[e] != '\n' && d[e] != '\r') ++e;
+        }
+        size_t i = p;
+        while (i < e && is_py_space((unsigned char)d[i])) ++i;
+        size_t j = i;
+        while (j < e && !is_py_space((unsigned char)d[j])) ++j;
+        if (j > i && d[i] != '#') {
+            key.assign(d + i, j - i);
+            auto it = g->owner.find(key);
+            if (it != g->owner.end()) { ++n_records[it->second]; n_bytes[it->second] += e - p; }
+        }
+        p = e + 1;
+        if (has_cr && e < n && d[e] == '\r' && p < n && d[p] == '\n') ++p;
+    }
     return DUET_INGEST_OK;
 }
 

@@ -47,6 +47,35 @@ def rank_env(rank, world, port, base=None, extra=None):
     return env
 
 
+def assert_gpu_untouched():
+    """The ranks are started from a parent that holds no GPU: a process that has initialised HIP and then forks children
+    which initialise it again is what this module exists to avoid.  Raises RuntimeError otherwise."""
+    torch = sys.modules.get('torch')
+    if torch is not None and torch.cuda.is_initialized():
+        raise RuntimeError('spawn_ranks: this process has initialised the GPU (torch.cuda); start the ranks from a fresh interpreter')
+    lib = sys.modules.get('duet_amd._lib')
+    if lib is not None and getattr(lib, 'CONTEXTS_CREATED', 0) > 0:
+        raise RuntimeError('spawn_ranks: this process has created a duet context on a GPU; start the ranks from a fresh interpreter')
+
+
+def probe_devices(n, timeout=300):
+    """A fresh interpreter creates a context on each of the first n devices (library present, n gfx950 devices visible):
+    what `duet --gpus N` checks before the external stages run, with the parent staying GPU-free.  -> None, or raises
+    RuntimeError with the child's message."""
+    code = ('import sys\nfrom duet_amd import _lib\nfor i in range(%d):\n    _lib.Context(i).close()\n' % int(n))
+    env = dict(os.environ)
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env['PYTHONPATH'] = os.pathsep.join([here] + ([env['PYTHONPATH']] if env.get('PYTHONPATH') else []))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    try:
+        p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        raise RuntimeError('device probe did not finish within %d s' % timeout)
+    if p.returncode != 0:
+        tail = p.stderr.decode('utf-8', 'replace').strip().splitlines()[-1:]
+        raise RuntimeError('device probe failed for %d GPUs: %s' % (n, tail[0] if tail else 'exit code %d' % p.returncode))
+
+
 def spawn_ranks(n, argv, extra_env=None, timeout=None, quiet_ranks=True):
     """Run `sys.executable argv...` as n ranks.  Rank 0 inherits stdout; the other ranks' stdout goes to stderr when
     quiet_ranks (a rank-0-prints-one-line contract stays intact even if a library chats on another rank).
@@ -55,6 +84,7 @@ def spawn_ranks(n, argv, extra_env=None, timeout=None, quiet_ranks=True):
     n = int(n)
     if n < 1:
         raise ValueError('need at least one rank')
+    assert_gpu_untouched()
     port = free_port()
     procs = []
     for r in range(n):

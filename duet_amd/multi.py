@@ -1,23 +1,29 @@
-# coding=utf-8
 """Step E/F over the N GPUs of one node: contigs shard, one all-gather reassembles the call set.
 
 Every quantity of step E/F is per contig (tag dicts sv_phasing_fn.py:15-18, join :47, seed sets :195-203,
 decisions :206-212), so nothing crosses contigs before the final sort (:229).  `sv_phasing_sharded` -- reached
 through `sv_phasing(..., gpus=N)` / `duet --gpus N` -- starts one process per GPU from the (GPU-untouched) calling
 process (duet_amd/launch.py).  Every rank
-  1. reads the inputs with the native ingest (the same deterministic arrays on every rank; no broadcast needed),
-  2. assigns contigs to ranks longest-processing-time-first on mark counts (duet_amd/dist.py) and keeps its own,
+  1. counts the caller VCF's records and line bytes per listed contig (one memchr pass, the same numbers on every rank)
+     and assigns contigs to ranks longest-processing-time-first on the line bytes (duet_amd/dist.py): the assignment and
+     every rank's candidate count are known before anything is parsed,
+  2. reads ITS contigs only -- their BAMs, their records (native ingest with an ownership mask) --,
   3. runs ef_classify -> ef_seed_sort -> ef_finalize on its shard (libduet_ef.so, no data-path exchange),
-  4. contributes its block `ps u32[n_max] | pred u8[n_max] | status` to ONE all_gather_into_tensor (RCCL over xGMI
-     under backend "nccl"),
-and rank 0 puts the records back into callset order, orders and formats the rows (on its device,
-duet_rows_run_device) and appends them to the phased_sv.vcf whose header it wrote first.
+  4. contributes its block `ps u32[n_max] | pred u8[n_max] | status | rows kept per CHROM text` to ONE
+     all_gather_into_tensor (RCCL over xGMI under backend "nccl"),
+  5. numbers and formats the rows of its own contigs (it alone holds their REF / ALT texts): a CHROM text belongs to one
+     contig, the file is the text blocks in byte order (sv_phasing_fn.py:229 sorts CHROM as text first), and the gathered
+     counts tell every rank where its blocks' numbering starts; the blocks go to a part file beside the output,
+and the parent appends the blocks, in the order of their texts, to the phased_sv.vcf whose header rank 0 wrote first.
 
 DUET_ONE_GPU=1 is a plumbing mode for a box with a single GPU: every rank uses device 0 and the collective goes
 through gloo.  Exit codes of a rank: 0 ok, 3 the native ingest declined the input (the caller falls back to the
 single-process Python path, which raises what upstream raises), 5 division by zero (sv_phasing_fn.py:123).
+DUET_RDZV_TIMEOUT (seconds, default 300) bounds the rendezvous and the collective, DUET_RANK_TIMEOUT (default 3600) the
+whole run of the ranks: on expiry the children are killed and the call fails -- it never hangs.
 """
 
+import json
 import logging
 import os
 import sys
@@ -29,7 +35,15 @@ from duet_amd import launch
 
 RC_DECLINED = 3
 RC_DIV_ZERO = 5
-TRAILER = 16                      # bytes after the records: status u32 + padding
+STATUS_BYTES = 16                 # status u32 + padding, in front of the per-text counts
+
+
+def trailer_bytes(n_contigs):
+    """Bytes behind the records of a block: status word (+ padding), then rows kept per CHROM-text slot (u64[2K])."""
+    return STATUS_BYTES + 16 * int(n_contigs)
+
+
+TRAILER = STATUS_BYTES            # (kept for callers that only carry the status word: bench.py)
 
 
 def hip_compute(device_id):
@@ -40,7 +54,8 @@ def hip_compute(device_id):
 
     def compute(sub, svlen_thres, suppread_thres, n_max):
         import torch
-        dp = DeviceProblem(sub, svlen_thres, suppread_thres, device='cuda:%d' % device_id, n_cands_max=n_max, trailer=TRAILER)
+        dp = DeviceProblem(sub, svlen_thres, suppread_thres, device='cuda:%d' % device_id, n_cands_max=n_max,
+                           trailer=trailer_bytes(sub.n_contigs))
         status = 0
         if sub.n_cands:
             stream = dp.run(ctx)
@@ -56,13 +71,36 @@ def hip_compute(device_id):
     return compute
 
 
-def block_from_arrays(pred, ps, n_max):
+def block_from_arrays(pred, ps, n_max, n_contigs=0):
     """Host (pred, ps) -> the record block as a CPU torch tensor (used by the CPU tests' stand-in compute)."""
     import torch
-    block = np.zeros(D.record_bytes(n_max) + TRAILER, dtype=np.uint8)
+    block = np.zeros(D.record_bytes(n_max) + trailer_bytes(n_contigs), dtype=np.uint8)
     block[:4 * len(ps)] = np.ascontiguousarray(ps, dtype=np.uint32).view(np.uint8)
     block[4 * n_max:4 * n_max + len(pred)] = pred
     return torch.from_numpy(block)
+
+
+def part_path(home, rank):
+    return os.path.join(home, 'phased_sv.vcf.part%d' % rank)
+
+
+def text_order(chrom_list):
+    """CHROM-text slots (2 * contig + spelling) in the byte order of their texts: the order of their blocks in the file."""
+    texts = []
+    for k, c in enumerate(chrom_list):
+        texts.append((('chr' + c).encode('utf-8'), 2 * k))
+        texts.append((c.encode('utf-8'), 2 * k + 1))
+    return [slot for _, slot in sorted(texts)]
+
+
+def plan_shards(caller_vcf, chrom_list, world):
+    """-> (owned[rank] = ascending contig indices, records per contig) or None (no native library / unreadable VCF)."""
+    from duet_amd.native import NativeIngest
+    pre = NativeIngest.precount(caller_vcf, chrom_list)
+    if pre is None:
+        return None
+    n_rec, n_bytes = pre
+    return D.lpt_assign(n_bytes, world), n_rec
 
 
 def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, rank, world, compute, backend,
@@ -70,52 +108,101 @@ def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, rank,
     """What one rank does once the process group exists.  -> exit code."""
     import torch
     from duet_amd import sv_phasing as S
+    from duet_amd.native import NativeIngest
+    from duet_amd.read_file import init_chrom_list
     caller_vcf = home + '/sv_calling/variants.vcf'
     out_vcf = home + '/phased_sv.vcf'
-    ing, chrom_list = S.load_native(home, max(1, int(thread) // world), include_all_ctgs, caller_vcf, log=(rank == 0))
-    if ing is None:
+    if os.path.exists(part_path(home, rank)):
+        os.remove(part_path(home, rank))
+    chrom_list = init_chrom_list(include_all_ctgs, home)
+    if os.environ.get('DUET_NATIVE_INGEST') == '0' or os.environ.get('DUET_USE_SAMTOOLS') == '1':
+        return RC_DECLINED
+    plan = plan_shards(caller_vcf, chrom_list, world)
+    if plan is None:
+        return RC_DECLINED
+    owned, n_rec = plan
+    sizes = [int(sum(int(n_rec[k]) for k in o)) for o in owned]
+    n_max = max(max(sizes), 1)
+    ing = NativeIngest.load(caller_vcf, home + '/snp_phasing/', chrom_list, max(1, int(thread) // world), owned=owned[rank])
+    if ing is None or ing.handle is None:
+        if rank == 0 and ing is not None:
+            logging.info('native ingest declined (%s); using the Python path' % ing.why)
         return RC_DECLINED
     try:
         soa = ing.soa
+        K = soa.n_contigs
+        if soa.n_cands != sizes[rank]:
+            raise RuntimeError('rank %d parsed %d candidates, the pre-count said %d' % (rank, soa.n_cands, sizes[rank]))
         if rank == 0:
             S.write_header(ing, include_all_ctgs, out_vcf)
-            S.log_ingest(ing, chrom_list)
+            logging.info('extract SNP signatures')
+            logging.info('extract SV signatures')
+            logging.info('  (%d ranks, contigs per rank: %s)' % (world, ' '.join(str(len(o)) for o in owned)))
             logging.info('integrate read weight information')
             logging.info('calculate read weight statistics')
             logging.info('predict SV haplotypes in the callset')
-        owned = D.lpt_assign(D.contig_mark_counts(soa), world)
-        sizes = D.shard_sizes(soa, owned)
-        n_max = max(max(sizes), 1)
-        sub = D.shard_soa(soa, owned[rank])
-        block, status = compute(sub, svlen_thres, suppread_thres, n_max)
+        block, status = compute(soa, svlen_thres, suppread_thres, n_max)
         rb = D.record_bytes(n_max)
-        block[rb:rb + 4] = torch.from_numpy(np.array([status], dtype=np.uint32).view(np.uint8)).to(block.device)
+        tb = trailer_bytes(K)
+        if block.numel() != rb + tb:
+            raise RuntimeError('record block of %d bytes, expected %d' % (block.numel(), rb + tb))
+        mine = block.cpu().numpy()
+        pred, ps = D.unpack_block(mine, n_max, soa.n_cands)
+        kept = ing.count_kept(pred) if status == 0 else np.zeros(2 * K, dtype=np.int64)
+        trailer = np.zeros(tb, dtype=np.uint8)
+        trailer[:4] = np.array([status], dtype=np.uint32).view(np.uint8)
+        trailer[STATUS_BYTES:] = kept.astype(np.uint64).view(np.uint8)
+        block[rb:] = torch.from_numpy(trailer).to(block.device)
         if backend == 'gloo' and block.device.type != 'cpu':
             block = block.cpu()
         gathered = D.allgather_records(block, world)                    # the ONE collective of the path
-        if rank != 0:
-            return 0
         g = gathered.cpu().numpy()
+        total = np.zeros(2 * K, dtype=np.int64)
         for r in range(world):
             if int(g[r, rb:rb + 4].view(np.uint32)[0]) == RC_DIV_ZERO:
                 return RC_DIV_ZERO
-        pred, ps = D.merge_results(soa, owned, [D.unpack_block(g[r], n_max, sizes[r]) for r in range(world)])
-        rows = None
-        if device_rows_ctx is not None and os.environ.get('DUET_DEVICE_ROWS') != '0' and soa.n_cands:
-            rows = ing.rows()
-        if rows is not None:
-            from duet_amd.devmem import DeviceProblem, device_rows
-            full = DeviceProblem(soa, svlen_thres, suppread_thres, device='cuda:%d' % device_id)
-            full.load_results(pred, ps)
-            body = device_rows(device_rows_ctx, full, rows)[0]
-        else:
-            body = ing.emit_rows(pred, ps)
-        logging.info('write phased callset into .vcf file')
-        with open(out_vcf, 'ab') as out:
+            total += g[r, rb + STATUS_BYTES:rb + tb].view(np.uint64).astype(np.int64)
+        # where each CHROM text's rows start counting: after the rows of every text that sorts before it
+        id_base = np.ones(2 * K, dtype=np.int64)
+        run = 1
+        for slot in text_order(chrom_list):
+            id_base[slot] = run
+            run += int(total[slot])
+        body, off, ln = ing.emit_blocks(pred, ps, id_base)
+        with open(part_path(home, rank) + '.tmp', 'wb') as out:
             out.write(body)
+        with open(part_path(home, rank) + '.json', 'w') as out:
+            json.dump(dict(off=[int(x) for x in off], len=[int(x) for x in ln]), out)
+        os.replace(part_path(home, rank) + '.tmp', part_path(home, rank))
         return 0
     finally:
         ing.close()
+
+
+def assemble(home, include_all_ctgs, world):
+    """Append the ranks' blocks to phased_sv.vcf (which holds the header) in the byte order of their CHROM texts, and remove
+    the part files.  Run by the parent once every rank has exited with 0."""
+    from duet_amd.read_file import init_chrom_list
+    chrom_list = init_chrom_list(include_all_ctgs, home)
+    parts = []
+    for r in range(world):
+        with open(part_path(home, r) + '.json') as f:
+            parts.append((json.load(f), part_path(home, r)))
+    logging.info('write phased callset into .vcf file')
+    with open(home + '/phased_sv.vcf', 'ab') as out:
+        files = [open(path, 'rb') for _, path in parts]
+        try:
+            for slot in text_order(chrom_list):
+                for (meta, _), f in zip(parts, files):
+                    if meta['len'][slot]:
+                        f.seek(meta['off'][slot])
+                        out.write(f.read(meta['len'][slot]))
+        finally:
+            for f in files:
+                f.close()
+    for _, path in parts:
+        os.remove(path)
+        os.remove(path + '.json')
 
 
 def rank_main(argv):
@@ -132,10 +219,12 @@ def rank_main(argv):
         add_stream_logging(home)
     torch.cuda.set_device(device_id)
     backend = 'gloo' if one_gpu else 'nccl'
+    import datetime
+    limit = datetime.timedelta(seconds=float(os.environ.get('DUET_RDZV_TIMEOUT', '300')))
     if one_gpu:
-        td.init_process_group('gloo', rank=rank, world_size=world)
+        td.init_process_group('gloo', rank=rank, world_size=world, timeout=limit)
     else:
-        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device_id))
+        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device_id), timeout=limit)
     try:
         compute = hip_compute(device_id)               # raises when libduet_ef.so / the GPU is missing: no fallback
         return rank_body(home, svlen_thres, suppread_thres, thread, all_ctgs, rank, world, compute, backend,
@@ -158,7 +247,7 @@ def sv_phasing_sharded(home, svlen_thres, suppread_thres, thread, include_all_ct
         env['DUET_RANK_LOG'] = '1'
     if extra_env:
         env.update(extra_env)
-    rc = launch.spawn_ranks(gpus, argv, extra_env=env)
+    rc = launch.spawn_ranks(gpus, argv, extra_env=env, timeout=float(os.environ.get('DUET_RANK_TIMEOUT', '3600')))
     for h in logging.getLogger().handlers:              # rank 0 appended to the log file: go on behind its lines
         if isinstance(h, logging.FileHandler) and h.stream is not None:
             h.acquire()
@@ -167,7 +256,14 @@ def sv_phasing_sharded(home, svlen_thres, suppread_thres, thread, include_all_ct
             finally:
                 h.release()
     if rc == 0:
+        assemble(home, include_all_ctgs, int(gpus))
         return True
+    for r in range(int(gpus)):                          # whatever a failed run left behind
+        for path in (part_path(home, r), part_path(home, r) + '.json', part_path(home, r) + '.tmp'):
+            if os.path.exists(path):
+                os.remove(path)
+    if rc == 124:
+        raise RuntimeError('multi-GPU SV phasing: the ranks did not finish within DUET_RANK_TIMEOUT; they were killed')
     if rc == RC_DECLINED:
         logging.info('native ingest declined the input; using the single-process Python path')
         return False

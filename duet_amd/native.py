@@ -19,7 +19,8 @@ OK, UNSUPPORTED = 0, 1
 EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam',
            'duet_ingest_parse_vcf', 'duet_ingest_parse_vcf_begin', 'duet_ingest_parse_vcf_finish', 'duet_ingest_get_arrays',
            'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
-           'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks', 'duet_ingest_bam_has_alignments')
+           'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks', 'duet_ingest_bam_has_alignments',
+           'duet_ingest_vcf_precount', 'duet_ingest_set_owned', 'duet_ingest_count_kept', 'duet_ingest_emit_blocks')
 
 
 class IngestArrays(ctypes.Structure):
@@ -72,6 +73,12 @@ def load():
         lib.duet_ingest_free.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_free.restype = None
         lib.duet_ingest_bam_has_alignments.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.duet_ingest_vcf_precount.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.duet_ingest_set_owned.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.duet_ingest_count_kept.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.duet_ingest_emit_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64),
+                                                ctypes.c_void_p, ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -100,10 +107,32 @@ class NativeIngest(object):
         sv = [(yes if off[k + 1] > off[k] else no) + c for k, c in enumerate(chrom_list)]
         return snp, sv
 
+    @staticmethod
+    def precount(vcf_path, chrom_list):
+        """Records and line bytes of every listed contig in the caller VCF (one memchr pass, nothing tokenised).
+        -> (n_records int64[K], n_bytes int64[K]) or None when the library is missing / the file cannot be read."""
+        lib = load()
+        if lib is None:
+            return None
+        names = (ctypes.c_char_p * len(chrom_list))(*[c.encode('utf-8') for c in chrom_list])
+        h = lib.duet_ingest_create(len(chrom_list), names)
+        if not h:
+            return None
+        try:
+            rec = np.zeros(max(len(chrom_list), 1), dtype=np.uint64)
+            byt = np.zeros(max(len(chrom_list), 1), dtype=np.uint64)
+            if lib.duet_ingest_vcf_precount(h, vcf_path.encode(), rec.ctypes.data, byt.ctypes.data) != OK:
+                return None
+            return rec[:len(chrom_list)].astype(np.int64), byt[:len(chrom_list)].astype(np.int64)
+        finally:
+            lib.duet_ingest_destroy(h)
+
     @classmethod
-    def load(cls, vcf_path, sam_home, chrom_list, thread=4):
+    def load(cls, vcf_path, sam_home, chrom_list, thread=4, owned=None):
         """-> NativeIngest, or None when the native library is missing / declines the input (reason logged by
-        the caller through .why of the returned tuple)."""
+        the caller through .why of the returned tuple).  owned (sharded runs): the contig indices this rank reads --
+        the other listed contigs' BAMs are not opened and their records are dropped at their first token (their rank
+        vouches for them); header lines and the contig list stay complete."""
         lib = load()
         if lib is None:
             return None
@@ -117,22 +146,35 @@ class NativeIngest(object):
             lib.duet_ingest_destroy(h)
             return cls(None, lib, None, why)
 
+        mine = None
+        if owned is not None:
+            mine = np.zeros(max(len(chrom_list), 1), dtype=np.uint8)
+            mine[list(owned)] = 1
+            if lib.duet_ingest_set_owned(h, mine.ctypes.data) != OK:
+                return decline()
         # the first half of the VCF parse (read, tokenise, pick the listed contigs' records) needs nothing from the BAMs: it
-        # runs on a thread of its own beside the BAM loop (ctypes releases the GIL); the join of the mark names follows
+        # runs on a thread of its own beside the BAM loop (ctypes releases the GIL); the join of the mark names follows.
+        # The two halves share the thread budget, so that `thread` stays an upper bound.
         import threading
-        first_half = threading.Thread(target=lib.duet_ingest_parse_vcf_begin, args=(h, vcf_path.encode(), int(thread)))
+        t_vcf = max(1, int(thread) // 2)
+        t_bam = max(1, int(thread) - t_vcf)
+        first_half = threading.Thread(target=lib.duet_ingest_parse_vcf_begin, args=(h, vcf_path.encode(), t_vcf))
         first_half.start()
         with_bam = []
         bam_ok = True
-        for k, c in enumerate(chrom_list):
-            for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
-                if os.path.exists(cand):
-                    bam_ok = lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) == OK
-                    with_bam.append(k)
+        try:
+            for k, c in enumerate(chrom_list):
+                if mine is not None and not mine[k]:
+                    continue
+                for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
+                    if os.path.exists(cand):
+                        bam_ok = lib.duet_ingest_add_bam(h, k, cand.encode(), t_bam) == OK
+                        with_bam.append(k)
+                        break
+                if not bam_ok:
                     break
-            if not bam_ok:
-                break
-        first_half.join()
+        finally:
+            first_half.join()                       # (also on an exception: nobody else owns the handle it works on)
         if not bam_ok:
             return decline()
         if lib.duet_ingest_parse_vcf_finish(h) != OK:
@@ -149,7 +191,7 @@ class NativeIngest(object):
         return cls(h, lib, soa, bam_contigs=with_bam)
 
     @classmethod
-    def extract(cls, sam_home, chrom_list, thread=4, min_sv_size=40, min_mapq=20, depth_bin=1000):
+    def extract(cls, sam_home, chrom_list, thread=4, min_sv_size=40, min_mapq=20, depth_bin=1000, only=None):
         """SVIM mode: the haplotagged BAMs alone -> raw SV marks (CIGAR insertions / deletions), tag tables, binned depth.
         -> (NativeIngest, dict(contig, type, pos, span, read, read_tag, read_off, depth, depth_off, depth_bin)) with
         numpy COPIES of the arrays, or (None, reason)."""
@@ -169,6 +211,8 @@ class NativeIngest(object):
         if lib.duet_ingest_set_extraction(h, 1, int(min_sv_size), int(min_mapq), int(depth_bin)) != OK:
             return decline()
         for k, c in enumerate(chrom_list):
+            if only is not None and k not in only:
+                continue                            # (sharded runs: another rank's contig)
             for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
                 if os.path.exists(cand):
                     if lib.duet_ingest_add_bam(h, k, cand.encode(), int(thread)) != OK:
@@ -200,6 +244,35 @@ class NativeIngest(object):
             raise RuntimeError('duet_ingest_emit: ' + self.lib.duet_ingest_error(self.handle).decode('utf-8', 'replace'))
         try:
             return ctypes.string_at(text.value, n.value)
+        finally:
+            self.lib.duet_ingest_free(text)
+
+    def count_kept(self, pred):
+        """Rows (pred != 0) per CHROM-text slot, slot = 2 * contig + (0: chr<name>, 1: <name>) -> int64[2K]"""
+        K = self.soa.n_contigs
+        pred = np.ascontiguousarray(pred, dtype=np.uint8)
+        kept = np.zeros(max(2 * K, 1), dtype=np.uint64)
+        if self.lib.duet_ingest_count_kept(self.handle, pred.ctypes.data, kept.ctypes.data) != OK:
+            raise RuntimeError('duet_ingest_count_kept failed')
+        return kept[:2 * K].astype(np.int64)
+
+    def emit_blocks(self, pred, ps, id_base):
+        """This ingest's rows with the rows of slot s numbered id_base[s], id_base[s] + 1, ...
+        -> (bytes, slot_off int64[2K], slot_len int64[2K])"""
+        K = self.soa.n_contigs
+        pred = np.ascontiguousarray(pred, dtype=np.uint8)
+        ps = np.ascontiguousarray(ps, dtype=np.uint32)
+        base = np.ascontiguousarray(id_base, dtype=np.uint64)
+        off = np.zeros(max(2 * K, 1), dtype=np.uint64)
+        ln = np.zeros(max(2 * K, 1), dtype=np.uint64)
+        text = ctypes.c_void_p()
+        n = ctypes.c_uint64()
+        rc = self.lib.duet_ingest_emit_blocks(self.handle, pred.ctypes.data, ps.ctypes.data, base.ctypes.data,
+                                              ctypes.byref(text), ctypes.byref(n), off.ctypes.data, ln.ctypes.data)
+        if rc != OK:
+            raise RuntimeError('duet_ingest_emit_blocks: ' + self.lib.duet_ingest_error(self.handle).decode('utf-8', 'replace'))
+        try:
+            return ctypes.string_at(text.value, n.value), off[:2 * K].astype(np.int64), ln[:2 * K].astype(np.int64)
         finally:
             self.lib.duet_ingest_free(text)
 

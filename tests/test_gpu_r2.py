@@ -130,38 +130,57 @@ def test_device_argument_reaches_the_context(tmp_path):
         sv_phasing(home, params['svlen_thres'], params['suppread_thres'], 4, False, device=n)
 
 
+def fresh_interpreter(code, env_extra=None, timeout=900):
+    """Run `code` in a NEW python process (the sharded entries start their ranks from a parent that holds no GPU:
+    duet_amd/launch.py refuses anything else, and this pytest process holds one).  -> CompletedProcess"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['PYTHONPATH'] = os.pathsep.join([repo] + ([env['PYTHONPATH']] if env.get('PYTHONPATH') else []))
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
 @pytest.mark.parametrize('gpus', [2, 3])
-def test_sharded_product_entry_with_the_real_kernels(tmp_path, gpus, caplog):
-    """sv_phasing(..., gpus=N): one process per rank started from this (GPU-holding, but not re-exec'ed) process, contigs
-    LPT-sharded, the three kernels per rank, ONE all-gather, rank 0 writes the file.  This box has one GPU, so the ranks
-    share device 0 and the collective goes through gloo (DUET_ONE_GPU=1: plumbing mode)."""
-    os.environ['DUET_ONE_GPU'] = '1'
-    try:
-        for name, src, params in H.full_cases()[:4] + H.full_cases()[6:8]:
-            home = str(tmp_path / name)
-            shutil.copytree(src, home)
-            os.remove(os.path.join(home, 'phased_sv.vcf'))
-            materialise_bams(home)
-            sv_phasing(home, params['svlen_thres'], params['suppread_thres'], 4, False, gpus=gpus)
-            with open(os.path.join(src, 'phased_sv.vcf'), 'rb') as f:
-                want = f.read()
-            with open(os.path.join(home, 'phased_sv.vcf'), 'rb') as f:
-                assert f.read() == want, name
-    finally:
-        del os.environ['DUET_ONE_GPU']
+def test_sharded_product_entry_with_the_real_kernels(tmp_path, gpus):
+    """sv_phasing(..., gpus=N) from a fresh interpreter: one process per rank, contigs LPT-sharded on the caller VCF's line
+    bytes, every rank reads its own contigs only, the three kernels per rank, ONE all-gather, every rank formats its rows, the
+    parent assembles the file.  This box has one GPU, so the ranks share device 0 and the collective goes through gloo
+    (DUET_ONE_GPU=1: plumbing mode).  cuteSV, Sniffles AND SVIM dialects."""
+    for name, src, params in H.full_cases()[:4] + H.full_cases()[6:]:
+        home = str(tmp_path / name)
+        shutil.copytree(src, home)
+        os.remove(os.path.join(home, 'phased_sv.vcf'))
+        materialise_bams(home)
+        r = fresh_interpreter('from duet_amd.sv_phasing import sv_phasing\nsv_phasing(%r, %d, %d, 4, False, gpus=%d)\n' % (
+            home, params['svlen_thres'], params['suppread_thres'], gpus), {'DUET_ONE_GPU': '1'})
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        with open(os.path.join(src, 'phased_sv.vcf'), 'rb') as f:
+            want = f.read()
+        with open(os.path.join(home, 'phased_sv.vcf'), 'rb') as f:
+            assert f.read() == want, name
+        assert not [n for n in os.listdir(home) if 'part' in n]
+
+
+def test_sharded_entry_refuses_a_gpu_holding_parent(tmp_path):
+    name, src, params = H.full_cases()[0]
+    home = str(tmp_path / name)
+    shutil.copytree(src, home)
+    materialise_bams(home)
+    engine.default_context(0)
+    with pytest.raises(RuntimeError, match='fresh interpreter'):
+        sv_phasing(home, params['svlen_thres'], params['suppread_thres'], 4, False, gpus=2)
 
 
 def test_sharded_division_by_zero(tmp_path):
-    os.environ['DUET_ONE_GPU'] = '1'
-    try:
-        home = _divzero_home(tmp_path)
-        with pytest.raises(ZeroDivisionError):
-            multi.sv_phasing_sharded(home, 50, 0, 4, False, 2)
-        p = [x for x in H.seeded_r2_plan() if x['kind'] == 'divzero'][0]
-        with open(home + '/phased_sv.vcf') as f:
-            assert f.read() == p['file_left_behind']
-    finally:
-        del os.environ['DUET_ONE_GPU']
+    home = _divzero_home(tmp_path)
+    r = fresh_interpreter('from duet_amd import multi\ntry:\n    multi.sv_phasing_sharded(%r, 50, 0, 4, False, 2)\n'
+                          'except ZeroDivisionError:\n    print("ZERODIV")\n' % home, {'DUET_ONE_GPU': '1'})
+    assert r.returncode == 0 and b'ZERODIV' in r.stdout, r.stderr.decode()[-2000:]
+    p = [x for x in H.seeded_r2_plan() if x['kind'] == 'divzero'][0]
+    with open(home + '/phased_sv.vcf') as f:
+        assert f.read() == p['file_left_behind']
 
 
 def test_log_lines_follow_upstream(tmp_path, caplog):

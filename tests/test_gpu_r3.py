@@ -1,0 +1,76 @@
+# coding=utf-8
+"""-m gpu, round 3: BASELINE configs[3] / [4] at their real SHAPE (24 contigs, 2e7 marks) in the dialects those
+configurations produce, pinned to the unmodified reference by tests/golden/make_golden_r3.py; the sharded entries (step E/F and
+the clustered SVIM mode) from a fresh interpreter with the real kernels."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from duet_amd import synth
+from tests import helpers as H
+from tests.test_gpu_r2 import fresh_interpreter, run_product
+
+pytestmark = pytest.mark.gpu
+
+
+def r3_plan():
+    with open(os.path.join(H.GOLDEN, 'seeded_r3.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('dialect', ['svim', 'sniffles'])
+def test_config3_shape_in_the_callers_dialects(dialect, tmp_path):
+    """configs[3] (`--sv_caller svim`: READS= / GT:DP:AD) and configs[4] (`--sv_caller sniffles`, min_support_read = 2:
+    RNAMES= / GT:GQ:DR:DV, refread = GQ -- read_file.py:56-76) on the 24-contig, 2e7-mark genome: the whole product path
+    (native ingest, E/F kernels, rows on the device) against the one reference run recorded in seeded_r3.json (998,750 rows),
+    then the same work dir through gpus=2 (plumbing mode: both ranks on device 0, gloo)."""
+    p = [x for x in r3_plan() if x['dialect'] == dialect][0]
+    home = str(tmp_path / ('config3_' + dialect))
+    synth.write_workdir(home, synth.bench_genome(20000000, p['seed']), dialect=dialect, seed=p['seed'], write_sam=False)
+    got = run_product(home, p['svlen_thres'], p['suppread_thres'], python_path=False)
+    assert sum(1 for l in got.split(b'\n') if l and not l.startswith(b'#')) == p['rows']
+    assert H.sha256_bytes(got) == p['output_sha256']
+    os.remove(home + '/phased_sv.vcf')
+    r = fresh_interpreter('from duet_amd.sv_phasing import sv_phasing\nsv_phasing(%r, %d, %d, 8, False, gpus=2)\n' % (
+        home, p['svlen_thres'], p['suppread_thres']), {'DUET_ONE_GPU': '1'}, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    with open(home + '/phased_sv.vcf', 'rb') as f:
+        assert H.sha256_bytes(f.read()) == p['output_sha256']
+    shutil.rmtree(home)
+
+
+@pytest.mark.parametrize('gpus', [2, 8])
+def test_svim_gpu_mode_sharded_over_ranks(gpus, tmp_path):
+    """`duet -b svim-gpu --gpus N` / svim_mode.sv_phasing_from_bams(..., gpus=N): every rank extracts its own contigs'
+    signatures and runs the device pipeline (A0 -> E/F) on them; one all-gather of candidate records; rank 0 writes.
+    Against the single-GPU run of this process (same kernels, whole genome at once) and its CPU twin."""
+    from duet_amd import svim_mode
+    from oracle import svim_oracle
+    home = str(tmp_path / 'w')
+    synth.write_svim_workdir(home, H.case_contigs('genome_small', 5), 5)
+    svim_mode.sv_phasing_from_bams(home, 50, 2, 4, False, 0.9, 0)
+    one = open(home + '/phased_sv.vcf').read()
+    chroms = svim_mode.init_chrom_list(False, home)
+    want = svim_oracle.phase_workdir(home, chroms, 50, 2, min_sv_size=50)
+    assert one.endswith(svim_mode.rows_text(home, dict(want, chroms=chroms))) and one.count('Duet.') > 100
+    os.remove(home + '/phased_sv.vcf')
+    r = fresh_interpreter('from duet_amd import svim_mode\nsvim_mode.sv_phasing_from_bams(%r, 50, 2, 4, False, 0.9, 0, gpus=%d)\n' % (
+        home, gpus), {'DUET_ONE_GPU': '1'})
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert open(home + '/phased_sv.vcf').read() == one
+
+
+def test_eight_ranks_with_the_real_kernels(tmp_path):
+    """24 contigs over EIGHT ranks (all on device 0, gloo), SVIM dialect, -r 2, step E/F: what the first real 8-GPU run
+    will do except for RCCL."""
+    home = str(tmp_path / 'g')
+    p = [x for x in H.seeded_r2_plan() if x['kind'] == 'genome_small' and x['dialect'] == 'svim'][0]
+    H.build_case(home, 'genome_small', p['seed'], 'svim', write_sam=False)
+    r = fresh_interpreter('from duet_amd.sv_phasing import sv_phasing\nsv_phasing(%r, %d, %d, 8, False, gpus=8)\n' % (
+        home, p['svlen_thres'], p['suppread_thres']), {'DUET_ONE_GPU': '1'})
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    with open(home + '/phased_sv.vcf', 'rb') as f:
+        assert H.sha256_bytes(f.read()) == p['output_sha256']

@@ -23,7 +23,7 @@ from tests.test_c_oracle import materialise_bams
 
 def oracle_compute(sub, svlen_thres, suppread_thres, n_max):
     rc, pred, ps = c_oracle.ef(sub, svlen_thres, suppread_thres)
-    return multi.block_from_arrays(pred, ps, n_max), (multi.RC_DIV_ZERO if rc == -5 else 0)
+    return multi.block_from_arrays(pred, ps, n_max, sub.n_contigs), (multi.RC_DIV_ZERO if rc == -5 else 0)
 
 
 def _worker(rank, world, port, home, svlen_thres, suppread_thres, out_dir):
@@ -52,10 +52,74 @@ def test_sharded_ranks_write_the_golden_bytes(name, src, params, world, tmp_path
              nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), 'rc%d' % r)).read() == '0'
+    multi.assemble(home, False, world)                  # (what the parent does once every rank has exited with 0)
     with open(os.path.join(src, 'phased_sv.vcf'), 'rb') as f:
         want = f.read()
     with open(os.path.join(home, 'phased_sv.vcf'), 'rb') as f:
         assert f.read() == want
+    assert not [n for n in os.listdir(home) if 'part' in n]
+
+
+@pytest.mark.parametrize('dialect', ['svim', 'sniffles'])
+def test_eight_ranks_24_contigs(dialect, tmp_path):
+    """BASELINE configs[3] / [4] in shape: the 24 hg19 contigs over EIGHT ranks, SVIM (READS= / GT:DP:AD) and Sniffles
+    (GT:GQ:DR:DV, refread = GQ) dialects, -r 2: every rank reads only its contigs' BAMs and records, one all-gather, every
+    rank formats and numbers its own rows; the assembled file is the single-process oracle's, byte for byte."""
+    from duet_amd import synth
+    from oracle import ef_oracle
+    home = str(tmp_path / 'g')
+    contigs = synth.bench_genome(60000, 7)
+    synth.write_workdir(home, contigs, dialect=dialect, seed=7, write_sam=True)
+    want = ef_oracle.sv_phasing_text(home, 50, 2)
+    mp.spawn(_worker, args=(8, launch.free_port(), home, 50, 2, str(tmp_path)), nprocs=8, join=True)
+    for r in range(8):
+        assert open(os.path.join(str(tmp_path), 'rc%d' % r)).read() == '0'
+    multi.assemble(home, False, 8)
+    got = open(os.path.join(home, 'phased_sv.vcf')).read()
+    assert got == want
+    assert got.count('\nchr') > 1000
+
+
+def test_both_spellings_of_a_contig_number_across_ranks(tmp_path):
+    """Records spelled chr1 AND 1 (read_file.py:30 accepts both; Q23): two CHROM texts of one contig, whose blocks sit apart
+    in the file (text order: 1 < 2 < chr1 < chr2) with another rank's rows between them."""
+    from duet_amd import bamio
+    from oracle import ef_oracle
+    home = str(tmp_path / 'w')
+    os.makedirs(home + '/sv_calling')
+    os.makedirs(home + '/snp_phasing')
+    rec = '%s\t%d\tid\tN\t<DEL>\t.\tPASS\tPRECISE;SVTYPE=DEL;SVLEN=-80;END=180;RE=5;RNAMES=a,b,c,d;STRAND=+-\tGT:DR:DV:PL:GQ\t0/1:0:5:1,2,3:9'
+    lines = ['##contig=<ID=chr1,length=1000000>', '##contig=<ID=chr2,length=1000000>']
+    for i in range(40):
+        lines.append(rec % (('chr1', '1', 'chr2', '2')[i % 4], 100 + 37 * i))
+    with open(home + '/sv_calling/variants.vcf', 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    sam = ['%s\t0\t%s\t90\t60\t*\t*\t0\t0\t*\t*\tNM:i:1\tHP:i:%d\tPC:i:100\tPS:i:50' % (n, '%s', 1 + i % 2) for i, n in enumerate('abcd')]
+    for c in ('chr1', 'chr2'):
+        bamio.write_bam_from_sam_lines(home + '/snp_phasing/%s.bam' % c, [(c, 1000000)], [l % c for l in sam])
+        with open(home + '/snp_phasing/%s.bam.sam' % c, 'w') as f:
+            f.write('\n'.join(l % c for l in sam) + '\n')
+    want = ef_oracle.sv_phasing_text(home, 50, 2)
+    mp.spawn(_worker, args=(2, launch.free_port(), home, 50, 2, str(tmp_path)), nprocs=2, join=True)
+    multi.assemble(home, False, 2)
+    got = open(home + '/phased_sv.vcf').read()
+    assert got == want and got.count('Duet.') == 40
+
+
+def test_a_rank_that_never_finishes_is_killed(tmp_path):
+    script = tmp_path / 'child.py'
+    script.write_text('import time\ntime.sleep(600)\n')
+    import time
+    t0 = time.time()
+    assert launch.spawn_ranks(2, [str(script)], timeout=2) == 124
+    assert time.time() - t0 < 30
+
+
+def test_spawn_ranks_refuses_a_parent_that_holds_a_gpu(monkeypatch):
+    from duet_amd import _lib
+    monkeypatch.setattr(_lib, 'CONTEXTS_CREATED', 1)
+    with pytest.raises(RuntimeError, match='fresh interpreter'):
+        launch.spawn_ranks(2, ['-c', 'pass'])
 
 
 def test_division_by_zero_reaches_rank0_through_the_block(tmp_path):
