@@ -1657,12 +1657,16 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     uint32_t *d_ctg_off = (uint32_t *)ctx->sv_ws[0].ptr, *d_depth_off = d_ctg_off + (K + 1);
     // (uploaded only when they change: a pageable host-to-device copy in front of every run keeps the host from queueing the
     // run's thirty launches ahead of the device -- 45 us of gaps per 0.37 ms run at 1 M marks)
-    if (ctx->sv_depth_off_at != (void *)d_depth_off || ctx->sv_depth_off.size() != (size_t)K + 1 ||
+    // (the copy is ordered on the stream it was issued on: a run on ANOTHER stream uploads again -- after waiting for that
+    // stream, whose pageable copy may still be reading the host vector)
+    if (ctx->sv_depth_off_at != (void *)d_depth_off || ctx->sv_depth_off.size() != (size_t)K + 1 || ctx->sv_depth_off_stream != st ||
         memcmp(ctx->sv_depth_off.data(), pr->depth_off, ((size_t)K + 1) * 4) != 0) {
+        if (ctx->sv_depth_off_at && ctx->sv_depth_off_stream != st) HIP_TRY(ctx, hipStreamSynchronize(ctx->sv_depth_off_stream));
         HIP_TRY(ctx, hipStreamSynchronize(st));                  // the previous copy's source is about to change
         ctx->sv_depth_off.assign(pr->depth_off, pr->depth_off + K + 1);
         HIP_TRY(ctx, hipMemcpyAsync(d_depth_off, ctx->sv_depth_off.data(), ((size_t)K + 1) * 4, hipMemcpyHostToDevice, st));
         ctx->sv_depth_off_at = (void *)d_depth_off;
+        ctx->sv_depth_off_stream = st;
     }
     // clustering; its emit kernel also writes what a caller VCF would have carried (support, reference reads, GT)
     // and the marks' read indices in output order

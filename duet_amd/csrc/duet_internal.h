@@ -44,6 +44,7 @@ struct duet_ctx {
     DevBuf eval_ws;                        // evaluator (duet_eval.hip): one arena
     DevBuf sv_ws[5];
     std::vector<uint32_t> sv_depth_off;    // the depth offsets the device copy in sv_ws[0] holds (uploaded only when they change)
+    hipStream_t sv_depth_off_stream = nullptr;             // ... and the stream that upload is ordered on
     void *sv_depth_off_at = nullptr;                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};
