@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void cl_maxima(const ClParams p, uint32_t *out
 
 // sort keys, the marks' records -- and, since the keys are at hand, the sort's first digit histogram (what rx_hist would
 // read them back for): one workgroup per radix tile
-__global__ __launch_bounds__(kRxHistThreads) void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps, uint4 *rec4, uint32_t dmask,
-                                                          uint32_t nb, uint32_t *hist /* [256][nb] */, uint32_t *dtot /* or null */)
+__global__ __launch_bounds__(kRxHistThreads) void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps, uint4 *rec4, uint32_t dshift,
+                                                          uint32_t dmask, uint32_t nb, uint32_t *hist /* [256][nb] */, uint32_t *dtot /* or null */)
 {
     __shared__ uint32_t s_h[256];
     const uint32_t tid = threadIdx.x;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kRxHistThreads) void cl_keys(const ClParams p, uint
             else ps[i] = make_uint2(ps_, sp_);
             if (p.idx_packed) keys[i] = key | ((uint64_t)i << p.key_bits);
             else { keys[i] = key; vals[i] = i; }
-            atomicAdd(&s_h[(uint32_t)key & dmask], 1u);
+            atomicAdd(&s_h[(uint32_t)(key >> dshift) & dmask], 1u);
         }
     }
     __syncthreads();
@@ -1501,7 +1501,10 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     else p.ps = (const uint2 *)recs;
     const bool big_sort = (ctx->dbg & DUET_DBG_CLUSTER_LARGE) != 0;     // (tests: the tile-offset path of > 4 M keys)
     const bool rx_totals = nb_rx <= kRxTotalsTiles && !big_sort;
-    hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs,
+    // (Measured and dropped in round 3: global passes over the top 16 bits only + one launch that orders the groups agreeing in
+    // them by the low bits in LDS -- bit-identical, but the ballot ranking of three LDS passes costs what the passes it
+    // replaces do: sort 91 instead of 88 us at 1 M marks, 1010 instead of 745 us at 2e7; profiles/history/r03_*_REJECTED.txt.)
+    hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs, 0u,
                        key_bits >= 8u ? 255u : (1u << key_bits) - 1u, nb_rx, hist, rx_totals ? ctx->rx_dtot : (uint32_t *)nullptr);
     uint64_t *kin = nullptr, *kout = nullptr;
     uint32_t *vin = nullptr;
