@@ -72,6 +72,7 @@ struct ClParams {
     double invn, scale;                               // exact linkage: 1 / normalizer, 2^26 / max_dist (oracle/cluster_oracle.c, rule 3)
     uint32_t mergeable;                               // max_dist >= 0
     uint32_t tps;                                     // scan tiles per work-list shard (kShards shards of consecutive tiles)
+    uint32_t gather_rows;                             // this launch reads its rows through the sort permutation (no cl_box before it)
     // fused SVIM-mode pipeline (all null otherwise): cl_emit also writes the columns ef_classify reads
     const uint32_t *sv_mark_in, *sv_depth, *sv_depth_off;
     uint32_t sv_depth_bin;
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             }
             const uint32_t r = min(min(phi - plo, ehi - elo), chi - clo);
             const float u = (float)r * p.inv_norm + (float)(shi - slo) * __builtin_amdgcn_rcpf((float)max(shi, 1u));
-            const bool one = n < 2 || (p.fast && p.box && !bad && u <= p.t_lo[0]);
+            // (partitions of more than 64 marks belong to the launch that started beside this one: see cl_big_list)
+            const bool one = n < 2 || (n <= 64u && p.fast && p.box && !bad && u <= p.t_lo[0]);
             s_done[j] = one ? 1 : 0;
             if (one) {
                 // (floor means: see emit_prep)
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
                 p.pc[p_lo + j] = 1;
             } else {
                 cls = size_class(n);
+                if (cls == 4) cls = -1;                      // (listed by cl_big_list: their launch starts before this kernel is done)
             }
         }
         // append the others to their class lists (wave-aggregated)
@@ -569,6 +572,20 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             if (p.sv_mark_out) p.sv_mark_out[i] = rd[j];
         } else {
             p.srec[i] = make_uint4(ps_[j], sp_[j], rd[j], mk[j]);
+        }
+    }
+}
+
+// The partitions of more than 64 marks -- a handful, but each is one wavefront's hundred-microsecond chain -- are listed from the
+// partition starts alone, so that their launch can begin on a side stream while cl_box is still looking at everybody's marks.
+__global__ __launch_bounds__(256) void cl_big_list(const ClParams p, uint32_t *list /* class 4 of lists */, uint32_t *counts /* its kShards counters */)
+{
+    const uint32_t n_parts = *p.n_parts;
+    for (uint32_t part = blockIdx.x * blockDim.x + threadIdx.x; part < n_parts; part += gridDim.x * blockDim.x) {
+        const uint32_t s0 = p.part_start[part], n = p.part_start[part + 1] - s0;
+        if (n > 64u) {
+            const uint32_t shard = (s0 / kScanTile) / p.tps;
+            list[(size_t)shard * p.tps * kScanTile + atomicAdd(&counts[shard], 1u)] = part;
         }
     }
 }
@@ -1185,11 +1202,19 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
         const uint32_t k = sl + r * GROUP;
         pk[r] = spk[r] = mk[r] = rd[r] = 0;
         if (k < n) {
-            const uint4 q = p.srec[s + k];
-            pk[r] = q.x;
-            spk[r] = q.y;
-            rd[r] = q.z;
-            mk[r] = q.w;
+            if (p.gather_rows) {
+                mk[r] = mark_at(p, s + k);
+                const uint3 q = load_rec(p, mk[r]);
+                pk[r] = q.x;
+                spk[r] = q.y;
+                rd[r] = q.z;
+            } else {
+                const uint4 q = p.srec[s + k];           // (cl_box laid the rows out in sorted order)
+                pk[r] = q.x;
+                spk[r] = q.y;
+                rd[r] = q.z;
+                mk[r] = q.w;
+            }
         }
         ek[r] = pk[r] + spk[r];
         ck[r] = pk[r] + (spk[r] >> 1);
@@ -1543,18 +1568,27 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.invn = 1.0 / pr->normalizer;
     p.scale = (double)kQOne / pr->max_dist;
     p.mergeable = pr->max_dist >= 0 ? 1u : 0u;
-    // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
-    hipLaunchKernelGGL(cl_box, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
     const uint32_t gridw = std::min(32768u, std::max(1024u, M / 256u));     // (a wavefront per virtual block, striding)
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
     const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
     const uint32_t *l4 = lists + 4 * (size_t)M, *c4 = cnts + 4 * kShards;
-    // the partitions of more than 64 marks on the side stream: few, long chains
+    // The partitions of more than 64 marks on the side stream: few, long chains.  They are listed from the partition starts
+    // alone and read their rows through the sort permutation themselves, so their launch starts beside cl_box, not after it
+    // (1.0 M marks: the chain ended 30-40 us after everything else when it started behind cl_box).
+    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-    if (cap100) hipLaunchKernelGGL((cl_fast_one<64, 2, 100, kLinkOnly>), dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p, l4, c4);
-    else hipLaunchKernelGGL((cl_fast_one<64, 2, 128, kLinkOnly>), dim3(grid < 4096u ? grid : 4096u), dim3(64), 0, ctx->cl_side[0], p, l4, c4);
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+    {
+        ClParams pb = p;
+        pb.gather_rows = 1;
+        const uint32_t g_parts = std::min((M + 255u) / 256u, std::max(256u, (M + 255u) / 256u / 8u));
+        hipLaunchKernelGGL(cl_big_list, dim3(g_parts), dim3(256), 0, ctx->cl_side[0], pb, lists + 4 * (size_t)M, cnts + 4 * kShards);
+        const uint32_t gb = small ? (grid < 4096u ? grid : 4096u) : grid;
+        if (cap100) hipLaunchKernelGGL((cl_fast_one<64, 2, 100, kLinkOnly>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, c4);
+        else hipLaunchKernelGGL((cl_fast_one<64, 2, 128, kLinkOnly>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, c4);
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+    }
+    // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
+    hipLaunchKernelGGL(cl_box, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
     if (small) {
         // one launch for the classes of up to 64 marks
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
