@@ -66,7 +66,8 @@ struct ClParams {
     const uint64_t *skeys;                            // the sorted keys (contig | type | centre)
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
-    float inv_norm, t_lo[1], t_hi[1];                 // fast pass: 1/normalizer; max_dist * (1 -/+ 1e-5) in binary32
+    float inv_norm, t_lo[3], t_hi[3];                 // binary32 pair tests: 1/normalizer; level * (1 -/+ 1e-5) for the levels max_dist, / 2, / 4
+    uint32_t kc;                                      // contracted linkage: the first tier's group limit is min(kc, the variant's own): tests lower it
     uint32_t fast;                                    // 0: parameters outside the fast pass's vetted range, everything goes to the exact linkage
     uint32_t box;                                     // 0: no bounding-box test (tests: every partition through the pair loops)
     double invn, scale;                               // exact linkage: 1 / normalizer, 2^26 / max_dist (oracle/cluster_oracle.c, rule 3)
@@ -398,6 +399,7 @@ struct WorkList {
     const uint32_t *items;          // the class's list, [M]
     const uint32_t *pref;           // (LDS) pref[s] = items in the shards before s, pref[kShards] = all
     uint32_t shard_span;            // positions per shard
+    uint32_t rev_end;               // 0: a shard's piece grows up from its first position; M: down from its last one (see over_append)
     __device__ __forceinline__ uint32_t size() const { return pref[kShards]; }
     __device__ __forceinline__ uint32_t operator[](uint32_t i) const
     {
@@ -406,9 +408,24 @@ struct WorkList {
             const uint32_t mid = (lo + hi) >> 1;
             if (pref[mid] <= i) lo = mid; else hi = mid;
         }
+        if (rev_end) {
+            const uint64_t e = (uint64_t)(lo + 1u) * shard_span;
+            return items[(e < rev_end ? (size_t)e : (size_t)rev_end) - 1u - (i - pref[lo])];
+        }
         return items[(size_t)lo * shard_span + (i - pref[lo])];
     }
 };
+// A partition the contracted linkage hands on (too many groups left, parameters or coordinates outside what it vouches for) goes
+// on the class's SECOND list, kept in the same array: a listed partition has at least two marks, so a shard's piece fills at
+// most half of the shard's positions from below, and the second list grows down from the shard's last position -- at most as
+// many entries as the first one has.
+__device__ __forceinline__ void over_append(const ClParams &p, uint32_t *items, uint32_t *over_counts, uint32_t part, uint32_t s)
+{
+    const uint32_t span = p.tps * kScanTile, shard = (s / kScanTile) / p.tps;
+    const uint64_t e = (uint64_t)(shard + 1u) * span;
+    const uint32_t end = e < p.M ? (uint32_t)e : p.M;
+    items[end - 1u - atomicAdd(&over_counts[shard], 1u)] = part;
+}
 // one wavefront: the running sums of a class's kShards counters into LDS
 __device__ __forceinline__ void worklist_prefix(const uint32_t *counts, uint32_t *pref /* LDS [kShards + 1] */)
 {
@@ -463,9 +480,9 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     __shared__ uint8_t s_done[kScanTile];                  // per partition of the tile: finished here
     __shared__ uint16_t s_pix[kScanTile + kBoxHalo];       // per position: its partition (index within the tile's partitions)
     __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t t0 = blockIdx.x * kScanTile, shard = blockIdx.x / p.tps;
-    const uint32_t p_lo = tile_first[blockIdx.x], p_hi = tile_first[blockIdx.x + 1], np = p_hi - p_lo;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, tile = blockIdx.x;
+    const uint32_t t0 = tile * kScanTile, shard = tile / p.tps;
+    const uint32_t p_lo = tile_first[tile], p_hi = tile_first[tile + 1], np = p_hi - p_lo;
     if (tid < kClasses) s_cnt[tid] = 0;
     for (uint32_t j = tid; j <= np; j += kBoxThreads) s_ps[j] = p.part_start[p_lo + j];
     // the marks' (pos, span), gathered through the sort permutation; each thread keeps its eight positions' mark indices
@@ -1176,7 +1193,7 @@ struct FastSmem {
 
 // what a unit does: the threshold graph first and the exact linkage, in the same wavefront, for what that does not
 // settle -- or the exact linkage right away (the partitions of more than 64 marks: nearly none of them is a set of cliques)
-enum { kFastThenLink = 1, kLinkOnly = 2 };
+enum { kFastThenLink = 1, kLinkOnly = 2, kLinkUnfit = 3 };    // kLinkUnfit: only the partitions tight_unit does not vouch for
 
 // one wave's worth of partitions (64 / GROUP of them, list[base ...]) of one size class
 template <int GROUP, int R, int NCAP, int MODE>
@@ -1229,7 +1246,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
         F[r].clear();
         F[r].set_if(sl + r * GROUP < n, sl + r * GROUP);
     }
-    if (MODE != kLinkOnly) {
+    if (MODE == kFastThenLink) {
         // closed neighbourhoods at the threshold; amb: some pair sits inside the guard band
         BitSet<NW> N0[R];
         bool amb = false;
@@ -1294,38 +1311,516 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
             for (int r = 0; r < R; ++r) F[r] = N0[r];
         }
     }
-    const bool need = has && !solved;
+    const bool wide = group_any(bad);
+    const bool take = MODE == kLinkUnfit ? (wide || !p.fast) : true;
+    const bool need = has && !solved && take;
     if (__ballot(need)) {
         LinkSmem<GROUP, R, NCAP> &X = *reinterpret_cast<LinkSmem<GROUP, R, NCAP> *>(smem_link);
-        link_unit<GROUP, R, NCAP, NW>(p, need, n, sub, sl, pk, spk, group_any(bad), X, S.mask[sub], F);
+        link_unit<GROUP, R, NCAP, NW>(p, need, n, sub, sl, pk, spk, wide, X, S.mask[sub], F);
     }
-    emit_prep<GROUP, R, NW, NMAX>(p, has, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
+    emit_prep<GROUP, R, NW, NMAX>(p, has && take, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
 }
 
-// one size class per launch: what large inputs use (the fused kernel needs the registers and the LDS of all variants at
-// once; with millions of partitions per class there is nothing to gain from fusing)
-template <int GROUP, int R, int NCAP, int MODE>
-__global__ __launch_bounds__(64) void cl_fast_one(const ClParams p, const uint32_t *items, const uint32_t *counts /* [kShards] */)
+// ---------------------------------------------------------------------------------------------
+// agglomeration, contracted: what the threshold graph settles, tight groups, the linkage over what is left
+// ---------------------------------------------------------------------------------------------
+//
+// The round-by-round linkage above keeps a partition's whole triangle of sums in LDS -- 16 KB for 64 marks, 40 KB for a
+// hundred -- and that, not its instruction count, is what bounds it: seven wavefronts per CU, each a chain of dependent LDS
+// round trips (doubling the LDS a workgroup holds doubles the kernels' time: profiles/history, round 3).  On SV-like data the
+// triangle is not needed.  Three facts, all about exact means of the integer distances q (rule 3):
+//   (a) marks in different connected components of {q <= threshold} never merge, and a component that is a clique ends as one
+//       cluster (the comment above fast_unit);
+//   (b) a connected component of {q <= level}, level <= threshold, that is a clique is a NODE of the merge tree (the comment in
+//       link_unit): the serial rule finishes it before it touches its surroundings;
+//   (c) the mean between two unions of such nodes is the sum of the member-pair distances over the product of the sizes.
+// So: level 0 as before; the rows of components that are not cliques ("open" rows) are grouped by (b) at threshold / 2 and / 4;
+// the sums between GROUPS -- k x k numbers, k <= 16 -- are accumulated straight from the rows (each unordered open pair is
+// evaluated once, in binary64 exactly as the oracle does, and added to its groups' cell with an LDS atomic: sums of integers
+// below 2^53, any order gives the same number); the rounds of mutual nearest neighbours then run on the k x k matrix.
+// A workgroup holds 5 KB instead of 21.  The pair tests are binary32 with a guard band; a row with a pair inside a band
+// repeats its tests in binary64 on the exact q, so the bit masks are the exact ones.  Partitions that leave more than k groups
+// (no tight structure: not SV-like) or whose coordinates or parameters are outside what the binary32 tests vouch for go on the
+// class's second work list and get the full triangle from the launch behind this one.
+// groups a partition may have left in the first tier, by rows per unit: what keeps the second lists at a few per cent on SV-like
+// data at the least LDS (the second tier takes as many groups as rows)
+constexpr int tier1_groups(int nmax) { return nmax <= 8 ? 4 : (nmax <= 16 ? 8 : (nmax <= 32 ? 16 : (nmax <= 64 ? 32 : 64))); }
+
+template <int GROUP, int R, int KC_>
+struct TightSmem {
+    static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1, KC = KC_, KT = KC * (KC - 1) / 2;
+    static_assert(KC >= 2 && KC <= 64 && KC <= NMAX, "groups: lanes 0 .. KC-1 of a unit own them");
+    uint4 ps[SUBS][NMAX];                                    // (pos, span, end, centre)
+    double inv[SUBS][NMAX];                                  // 1 / span (0 for span 0), binary64 as the oracle computes it
+    uint64_t mask[SUBS][NMAX][NW];
+    union {
+        double D[SUBS][KT + 2];                              // sums between groups, upper triangle row by row; [KT] "nothing there", [KT + 1] scratch
+        unsigned long long sum[SUBS][NMAX][2];               // (emit_prep, when the linkage is over)
+    };
+    uint8_t gof[SUBS][NMAX];                                 // an open row's group (0xFF: the row is not open)
+    uint8_t ghead[SUBS][KC], gsize[SUBS][KC], nn[SUBS][KC], rep[SUBS][KC];
+    uint8_t alist[SUBS][KC + 4], asize[SUBS][KC + 4];        // the clusters that are left, ascending, and their sizes (read four at a time)
+};
+
+// one wave's worth of partitions (64 / GROUP of them, list[base ...]) of one size class.  First tier (TIER2 false): at most
+// KC_ groups, the partitions beyond that -- and those it does not vouch for -- go on the class's second list (over_items /
+// over_counts); second tier: the second list, as many groups as rows (the partitions it does not vouch for have been dealt
+// with by the full-triangle linkage in front of it: tier2_unit)
+template <int GROUP, int R, int KC_, bool TIER2>
+__device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &list, uint32_t base, unsigned char *smem,
+                                           uint32_t *over_items, uint32_t *over_counts)
 {
-    __shared__ __align__(16) unsigned char smem[sizeof(FastSmem<GROUP, R>)];
-    __shared__ __align__(16) unsigned char smem_link[sizeof(LinkSmem<GROUP, R, NCAP>)];
+    using SM = TightSmem<GROUP, R, KC_>;
+    constexpr int NMAX = SM::NMAX, NW = SM::NW, KC = SM::KC, KT = SM::KT;
+    constexpr bool kOnePass = GROUP == 64;               // classes whose partitions are mostly open: all three levels in one pass over the pairs
+    SM &S = *reinterpret_cast<SM *>(smem);
+    const uint32_t lane = threadIdx.x, sub = lane / GROUP, sl = lane % GROUP;
+    constexpr unsigned long long gm = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    auto group_any = [&](bool x) -> bool { return ((__ballot(x) >> (sub * GROUP)) & gm) != 0ull; };
+    auto wave_max = [&](uint32_t x) -> uint32_t {          // over the wave's groups (x is uniform within a group): a scalar
+#pragma unroll
+        for (int d = 32; d >= GROUP && d > 0; d >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, d, 64));
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+    };
+    const uint32_t li = base + sub;
+    const bool has = li < list.size();
+    const uint32_t part = has ? list[li] : 0u;
+    const uint32_t s = has ? p.part_start[part] : 0u;
+    const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+    __syncthreads();
+    uint32_t pk[R], spk[R], ek[R], ck[R], mk[R], rd[R];
+    double ik[R];
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t k = sl + r * GROUP;
+        pk[r] = spk[r] = mk[r] = rd[r] = 0;
+        if (k < n) {
+            if (p.gather_rows) {
+                mk[r] = mark_at(p, s + k);
+                const uint3 q = load_rec(p, mk[r]);
+                pk[r] = q.x;
+                spk[r] = q.y;
+                rd[r] = q.z;
+            } else {
+                const uint4 q = p.srec[s + k];           // (cl_box laid the rows out in sorted order)
+                pk[r] = q.x;
+                spk[r] = q.y;
+                rd[r] = q.z;
+                mk[r] = q.w;
+            }
+        }
+        ek[r] = pk[r] + spk[r];
+        ck[r] = pk[r] + (spk[r] >> 1);
+        ik[r] = spk[r] ? 1.0 / (double)spk[r] : 0.0;
+        if (k < n) {
+            S.ps[sub][k] = make_uint4(pk[r], spk[r], ek[r], ck[r]);
+            S.inv[sub][k] = ik[r];
+        }
+        bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits
+    }
+    __syncthreads();
+    const bool unfit = group_any(bad) || !p.fast;
+    const bool act = has && n >= 2 && !unfit;            // (uniform within a group)
+    const uint32_t na = act ? n : 0u;
+    const uint32_t n_all = wave_max(na);
+    // q of rule 3 for (this lane's row r, row j), exactly the oracle's operations (ends fit 32 bits here)
+    auto q_exact = [&](int r, uint32_t j) -> double {
+        const uint4 q = S.ps[sub][j];
+        const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], q.z)), absdiff_u32(ck[r], q.w));
+        const double inv = spk[r] > q.y ? ik[r] : S.inv[sub][j];         // 1 / the larger span (the same number when they are equal)
+        const double dp = (double)m * p.invn, ds = (double)absdiff_u32(spk[r], q.y) * inv;
+        return quantise(dp + ds, p.scale);
+    };
+    BitSet<NW> F[R];                                     // the final cluster of each of this lane's marks
+    BitSet<NW> N0[R], g1[R], g2[R];                      // closed neighbourhoods at the threshold, at / 2, at / 4
+    bool row[R], ambr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        F[r].clear();
+        F[r].set_if(sl + r * GROUP < n, sl + r * GROUP);
+        N0[r].clear();
+        g1[r].clear();
+        g2[r].clear();
+        row[r] = sl + r * GROUP < na;
+        ambr[r] = false;
+    }
+    // The pair tests in binary32 (relative error < 4e-7; the fixed point's step is 1.5e-8 of the threshold: hence the 1e-5 guard
+    // band around each level), 32 columns at a time: the bits of one mask word are collected in one register.  L0 / L12: which
+    // levels; cols: the columns that count for L12 (the open rows)
+    auto pair_pass = [&](auto wc, auto l0, auto l12, const BitSet<NW> &cols) {
+        constexpr uint32_t W = decltype(wc)::value;
+        constexpr bool L0 = decltype(l0)::value, L12 = decltype(l12)::value;
+        const uint32_t j1 = min(n_all, 32u * (W + 1u));
+        uint32_t a0[R], a1[R], a2[R], am[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a0[r] = a1[r] = a2[r] = am[r] = 0;
+        const uint32_t cw = (uint32_t)(cols.w[W >> 1] >> (32u * (W & 1u)));
+        // (two columns per step, both loads in front; a column beyond a group's own count reads something stale inside the
+        // array and is masked)
+        auto column = [&](uint32_t j, const uint4 &q) {
+            const bool in = j < na;
+            const bool in12 = L0 ? in : (in && ((cw >> (j - 32u * W)) & 1u));
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t m = min(min(absdiff_u32(pk[r], q.x), absdiff_u32(ek[r], q.z)), absdiff_u32(ck[r], q.w));
+                const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
+                const float dp = (float)m * p.inv_norm;
+                bool amb = false;
+                if constexpr (L0) {
+                    const bool h = fs <= (p.t_hi[0] - dp) * fm, l = fs <= (p.t_lo[0] - dp) * fm;
+                    amb = in && h != l;
+                    a0[r] |= ((in && h) ? 1u : 0u) << (j - 32u * W);
+                }
+                if constexpr (L12) {
+                    const bool h1 = fs <= (p.t_hi[1] - dp) * fm, l1 = fs <= (p.t_lo[1] - dp) * fm;
+                    const bool h2 = fs <= (p.t_hi[2] - dp) * fm, l2 = fs <= (p.t_lo[2] - dp) * fm;
+                    amb = amb || (in12 && (h1 != l1 || h2 != l2));
+                    a1[r] |= ((in12 && h1) ? 1u : 0u) << (j - 32u * W);
+                    a2[r] |= ((in12 && h2) ? 1u : 0u) << (j - 32u * W);
+                }
+                am[r] |= amb ? 1u : 0u;
+            }
+        };
+        for (uint32_t j = 32u * W; j < j1; j += 2) {
+            const uint4 q0 = S.ps[sub][j], q1 = S.ps[sub][j + 1u];
+            column(j, q0);
+            column(j + 1u, q1);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ambr[r] = ambr[r] || am[r] != 0u;
+            if constexpr (L0) N0[r].w[W >> 1] |= (uint64_t)a0[r] << (32u * (W & 1u));
+            if constexpr (L12) {
+                g1[r].w[W >> 1] |= (uint64_t)a1[r] << (32u * (W & 1u));
+                g2[r].w[W >> 1] |= (uint64_t)a2[r] << (32u * (W & 1u));
+            }
+        }
+    };
+    auto all_words = [&](auto l0, auto l12, const BitSet<NW> &cols) {
+        pair_pass(std::integral_constant<uint32_t, 0>{}, l0, l12, cols);
+        if constexpr (NMAX > 32) pair_pass(std::integral_constant<uint32_t, 1>{}, l0, l12, cols);
+        if constexpr (NMAX > 64) {
+            pair_pass(std::integral_constant<uint32_t, 2>{}, l0, l12, cols);
+            pair_pass(std::integral_constant<uint32_t, 3>{}, l0, l12, cols);
+        }
+    };
+    // a row with a pair inside a guard band repeats its levels on the exact q (so does the pair's other row: the binary32
+    // expressions are symmetric)
+    auto exact_rows = [&](auto l0, auto l12, const bool (&on)[R], const BitSet<NW> &cols) {
+        constexpr bool L0 = decltype(l0)::value, L12 = decltype(l12)::value;
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ambr[r] = ambr[r] && on[r];
+            any = any || ambr[r];
+        }
+        if (__ballot(any)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (ambr[r]) {
+                    if constexpr (L0) N0[r].clear();
+                    if constexpr (L12) { g1[r].clear(); g2[r].clear(); }
+                }
+            for (uint32_t j = 0; j < n_all; ++j) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (ambr[r] && j < na) {
+                        const double qq = q_exact(r, j);
+                        if constexpr (L0) N0[r].set_if(qq <= (double)kQOne, j);
+                        if constexpr (L12) {
+                            const bool c = L0 || cols.test(j);
+                            g1[r].set_if(c && qq <= (double)(kQOne / 2), j);
+                            g2[r].set_if(c && qq <= (double)(kQOne / 4), j);
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ambr[r] = false;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    BitSet<NW> nocols;
+    nocols.clear();
+    if constexpr (kOnePass) {
+        all_words(T_{}, T_{}, nocols);
+        exact_rows(T_{}, T_{}, row, nocols);
+    } else {
+        all_words(T_{}, F_{}, nocols);
+        exact_rows(T_{}, F_{}, row, nocols);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        N0[r].set_if(row[r], sl + r * GROUP);
+        if (!row[r]) N0[r].clear();
+    }
+    // a row's component of the graph given by the masks g is a clique <=> the row and all its neighbours have the neighbourhood
+    // of their smallest member (rows with on == false stay out of it)
+    auto clique_rows = [&](BitSet<NW> (&g)[R], const bool (&on)[R], bool (&ok)[R]) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            if (on[r])
+                for (int i = 0; i < NW; ++i) S.mask[sub][me][i] = g[r].w[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ok[r] = false;
+            if (on[r]) {
+                const uint32_t f = g[r].first();
+                BitSet<NW> o;
+                for (int i = 0; i < NW; ++i) o.w[i] = S.mask[sub][f][i];
+                ok[r] = o.equals(g[r]);
+            }
+        }
+        const BitSet<NW> pass = group_ballot<GROUP, R, NW>(ok, sub);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bool c = ok[r];
+            for (int i = 0; i < NW; ++i) c = c && (g[r].w[i] & ~pass.w[i]) == 0ull;
+            ok[r] = c;
+        }
+    };
+    bool ok0[R], open[R];
+    clique_rows(N0, row, ok0);
+    bool any_open = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row[r] && ok0[r]) F[r] = N0[r];              // (a): the component is a clique, hence a cluster
+        open[r] = row[r] && !ok0[r];
+        any_open = any_open || open[r];
+    }
+    bool too_many = false;
+    if (__ballot(any_open)) {
+        const BitSet<NW> omask = group_ballot<GROUP, R, NW>(open, sub);
+        // the open rows' neighbourhoods among themselves at threshold / 2 and / 4 (the rows within threshold / 2 of an open
+        // row are open themselves: they are in its component)
+        if constexpr (!kOnePass) {
+            all_words(F_{}, T_{}, omask);
+            exact_rows(F_{}, T_{}, open, omask);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            for (int i = 0; i < NW; ++i) {
+                g1[r].w[i] &= omask.w[i];
+                g2[r].w[i] &= omask.w[i];
+            }
+            g1[r].set_if(open[r], sl + r * GROUP);
+            g2[r].set_if(open[r], sl + r * GROUP);
+            if (!open[r]) { g1[r].clear(); g2[r].clear(); }
+        }
+        bool ok1[R], ok2[R], head[R];
+        clique_rows(g1, open, ok1);
+        clique_rows(g2, open, ok2);
+        // (b): the groups, named by their smallest member
+        uint32_t into[R], gsz[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            into[r] = ok1[r] ? g1[r].first() : (ok2[r] ? g2[r].first() : me);
+            gsz[r] = ok1[r] ? g1[r].count() : (ok2[r] ? g2[r].count() : 1u);
+            head[r] = open[r] && into[r] == me;
+        }
+        const BitSet<NW> heads = group_ballot<GROUP, R, NW>(head, sub);
+        const uint32_t k = heads.count();
+        too_many = k > (TIER2 ? (uint32_t)KC : min(p.kc, (uint32_t)KC));
+        const uint32_t kk = too_many ? 0u : k;               // (a group that hands its partition on sits the rest out)
+        uint32_t gi[R];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            gi[r] = open[r] ? heads.count_below(into[r]) : 0xFFu;
+            if (row[r]) S.gof[sub][sl + r * GROUP] = (uint8_t)gi[r];         // (0xFF: not an open row)
+            if (head[r] && kk) {
+                S.ghead[sub][gi[r]] = (uint8_t)(sl + r * GROUP);
+                S.gsize[sub][gi[r]] = (uint8_t)gsz[r];
+                S.alist[sub][gi[r]] = (uint8_t)gi[r];
+                S.asize[sub][gi[r]] = (uint8_t)gsz[r];
+            }
+        }
+        double *D = S.D[sub];
+        // entry {a, b}, a < b, sits at rowbase(a) + b
+        auto rowbase = [](uint32_t i) -> int { return (int)(__umul24(i, 2u * KC - i - 1u) >> 1) - (int)i - 1; };
+        for (uint32_t i = sl; i < (uint32_t)KT + 2u; i += GROUP) D[i] = i == (uint32_t)KT ? kNothing : 0.0;
+        __syncthreads();
+        // (c): every unordered pair of rows once -- row i takes i+1 .. i+n/2 (mod n), for even n the distance-n/2 pairs only from
+        // the lower half -- and the pairs of open rows of different groups go into their groups' cell
+        {
+            const uint32_t no = kk ? na : 0u, half = no >> 1, half_all = wave_max(half);
+            uint32_t tmax[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) tmax[r] = (!open[r] || !no) ? 0u : ((!(no & 1u) && sl + r * GROUP >= half) ? half - 1u : half);
+            for (uint32_t t = 1; t <= half_all; ++t) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    uint32_t j = sl + r * GROUP + t;
+                    j = j >= no ? j - no : j;
+                    j = t <= tmax[r] ? j : 0u;
+                    const uint32_t gj = S.gof[sub][j];
+                    if (t <= tmax[r] && gj != 0xFFu && gj != gi[r]) {
+                        const double qq = q_exact(r, j);
+                        const uint32_t lo = min(gi[r], gj), hi = max(gi[r], gj);
+                        __hip_atomic_fetch_add(&D[rowbase(lo) + (int)hi], qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // the rounds of link_unit on the groups: lane a < k owns group a (a cluster keeps the index of its smallest group,
+        // which is the rank of its smallest member: the oracle's tie order)
+        const uint32_t a = sl;
+        const bool mine = a < kk;
+        bool aliveA = mine;
+        uint32_t rootA = a;
+        const int rb_a = rowbase(a < (uint32_t)KC ? a : 0u);
+        constexpr unsigned long long km = KC == 64 ? ~0ull : ((1ull << (KC & 63)) - 1ull);
+        uint32_t nl = kk;                                    // clusters left
+        for (uint32_t round = 0; round < (uint32_t)KC; ++round) {
+            // nearest neighbour of every cluster: smallest mean, ties to the smallest index -- the list of what is left is
+            // ascending, read four entries at a time
+            const double sizeA = aliveA ? (double)S.gsize[sub][a] : 1.0;
+            double bs = kNothing, bn = 1.0;
+            uint32_t bk = 0xFFu;
+            const uint32_t nl_all = wave_max(nl);
+            for (uint32_t t = 0; t < nl_all; t += 4) {
+                const uint32_t ks = *reinterpret_cast<const uint32_t *>(&S.alist[sub][t < (uint32_t)KC ? t : 0u]);
+                const uint32_t ns = *reinterpret_cast<const uint32_t *>(&S.asize[sub][t < (uint32_t)KC ? t : 0u]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t b = (ks >> (8 * w)) & 0xFFu;
+                    const double nk = (double)((ns >> (8 * w)) & 0xFFu);
+                    const bool in = aliveA && t + w < nl && b != a;
+                    const int idx = !in ? KT : (a < b ? rb_a + (int)b : rowbase(b) + (int)a);
+                    double sv = D[idx];
+                    sv = sv <= kFar ? sv : kNothing;
+                    const bool better = sv * bn < bs * nk;
+                    bs = better ? sv : bs;
+                    bn = better ? nk : bn;
+                    bk = better ? b : bk;
+                }
+            }
+            const bool within = bs <= (double)kQOne * (bn * sizeA);
+            bk = (aliveA && within) ? bk : 0xFFu;
+            if (mine) S.nn[sub][a] = (uint8_t)bk;
+            __syncthreads();
+            // mutual nearest neighbours: the larger index goes into the smaller
+            const bool dies = aliveA && bk < a && S.nn[sub][bk < (uint32_t)KC ? bk : 0u] == a;
+            unsigned long long deadK = (__ballot(dies) >> (sub * GROUP)) & km;
+            if (!__ballot(dies)) break;
+            // this round's merges one after the other, each on every lane's own entries: {x, dst} += {x, src} (link_unit's merge_round)
+            const uint32_t nd_all = wave_max((uint32_t)__popcll(deadK));
+            for (uint32_t t = 0; t < nd_all; ++t) {
+                const bool on = deadK != 0ull;
+                const uint32_t src = on ? (uint32_t)__ffsll((long long)deadK) - 1u : 0u;
+                deadK &= deadK - 1ull;
+                const uint32_t dst = on ? S.nn[sub][src] : 0u;
+                const bool upd = on && aliveA && a != dst && a != src;
+                const int i_d = a < dst ? rb_a + (int)dst : rowbase(dst) + (int)a;
+                const int i_s = a < src ? rb_a + (int)src : rowbase(src) + (int)a;
+                const double v = D[upd ? i_d : KT + 1] + D[upd ? i_s : KT + 1];
+                D[upd ? i_d : KT + 1] = v;
+                __syncthreads();
+            }
+            if (dies) S.gsize[sub][bk] = (uint8_t)((uint32_t)S.gsize[sub][bk] + (uint32_t)S.gsize[sub][a]);
+            if (mine) S.rep[sub][a] = (uint8_t)(dies ? bk : a);
+            aliveA = aliveA && !dies;
+            const unsigned long long liveK = (__ballot(aliveA) >> (sub * GROUP)) & km;
+            nl = (uint32_t)__popcll(liveK);
+            __syncthreads();
+            if (mine) rootA = S.rep[sub][rootA];
+            if (aliveA) {
+                const uint32_t at_ = (uint32_t)__popcll(liveK & ((1ull << a) - 1ull));
+                S.alist[sub][at_] = (uint8_t)a;
+                S.asize[sub][at_] = S.gsize[sub][a];
+            }
+            __syncthreads();
+        }
+        // the clusters as bit sets: every open row adds its bit at the smallest member of its group's cluster
+        __syncthreads();
+        if (mine) S.nn[sub][a] = (uint8_t)rootA;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            if (open[r])
+                for (int i = 0; i < NW; ++i) S.mask[sub][me][i] = 0ull;
+        }
+        __syncthreads();
+        uint32_t hr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t me = sl + r * GROUP;
+            hr[r] = me;
+            if (open[r] && kk) {
+                hr[r] = S.ghead[sub][S.nn[sub][gi[r]]];
+                atomicOr((unsigned long long *)&S.mask[sub][hr[r]][NW == 1 ? 0 : (me >> 6)], 1ull << (me & 63u));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (open[r] && kk)
+                for (int i = 0; i < NW; ++i) F[r].w[i] = S.mask[sub][hr[r]][i];
+    }
+    // hand on what this unit does not vouch for
+    const bool over = has && n >= 2 && (unfit || too_many);
+    if (!TIER2 && over && sl == 0) over_append(p, over_items, over_counts, part, s);
+    emit_prep<GROUP, R, NW, NMAX>(p, has && !over, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
+    return __ballot(has && n >= 2 && unfit) != 0ull;     // (some partition of this wave was not vouched for)
+}
+// one size class per launch: what large inputs use (the fused kernel needs the registers of all variants at once; with
+// millions of partitions per class there is nothing to gain from fusing)
+template <int GROUP, int R, int KC>
+__global__ __launch_bounds__(64) void cl_tight_one(const ClParams p, uint32_t *items /* the class's lists */, const uint32_t *counts /* [kShards] */,
+                                                   uint32_t *over_counts /* [kShards] */)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(TightSmem<GROUP, R, KC>)];
     __shared__ uint32_t s_pref[kShards + 1];
     worklist_prefix(counts, s_pref);
     __syncthreads();
-    const WorkList list{items, s_pref, p.tps * kScanTile};
+    const WorkList list{items, s_pref, p.tps * kScanTile, 0u};
     const uint32_t L = list.size();
     for (uint32_t base = blockIdx.x * (64 / GROUP); base < L; base += gridDim.x * (64 / GROUP))
-        fast_unit<GROUP, R, NCAP, MODE>(p, list, base, smem, smem_link);
+        tight_unit<GROUP, R, KC, false>(p, list, base, smem, items, over_counts);
 }
 
+constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
+constexpr int kK8 = tier1_groups(8), kK16 = tier1_groups(16), kK32 = tier1_groups(32), kK64 = tier1_groups(64);
+
 // the classes of up to 64 marks in one launch, largest partitions first (they are the longest chains): a virtual block is
-// one wave's worth of partitions of one class.  (The partitions of more than 64 marks have their own launch beside it:
-// the triangle of a hundred rows is 40 KB of LDS, which would keep this kernel's occupancy down for everybody.)
-constexpr size_t kFastSmemBytes = sizeof(FastSmem<64, 1>) > sizeof(FastSmem<8, 1>) ? sizeof(FastSmem<64, 1>) : sizeof(FastSmem<8, 1>);
-static_assert(kFastSmemBytes >= sizeof(FastSmem<32, 1>) && kFastSmemBytes >= sizeof(FastSmem<16, 1>), "shared scratch too small");
-constexpr size_t kLinkSmemBytes = sizeof(LinkSmem<64, 1, 64>);
-static_assert(kLinkSmemBytes >= sizeof(LinkSmem<32, 1, 32>) && kLinkSmemBytes >= sizeof(LinkSmem<16, 1, 16>) &&
-              kLinkSmemBytes >= sizeof(LinkSmem<8, 1, 8>), "shared scratch too small");
+// one wave's worth of partitions of one class
+constexpr size_t kTightSmemBytes = cmax(cmax(sizeof(TightSmem<64, 1, kK64>), sizeof(TightSmem<32, 1, kK32>)),
+                                        cmax(sizeof(TightSmem<16, 1, kK16>), sizeof(TightSmem<8, 1, kK8>)));
+
+__global__ __launch_bounds__(64, 6) void cl_tight_all(const ClParams p, uint32_t *lists, const uint32_t *cnts /* [kClasses][kShards] */,
+                                                   uint32_t *over_cnts /* [kClasses][kShards] */)
+{
+    __shared__ __align__(16) unsigned char smem[kTightSmemBytes];
+    __shared__ uint32_t s_pref[4][kShards + 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) worklist_prefix(cnts + c * kShards, s_pref[c]);
+    __syncthreads();
+    const size_t M = p.M;
+    const uint32_t span = p.tps * kScanTile;
+    const WorkList l0{lists, s_pref[0], span, 0u}, l1{lists + M, s_pref[1], span, 0u}, l2{lists + 2 * M, s_pref[2], span, 0u},
+        l3{lists + 3 * M, s_pref[3], span, 0u};
+    const uint32_t c0 = l0.size(), c1 = l1.size(), c2 = l2.size(), c3 = l3.size();
+    const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
+        if (vb < b3) tight_unit<64, 1, kK64, false>(p, l3, vb, smem, lists + 3 * M, over_cnts + 3 * kShards);
+        else if (vb < b2) tight_unit<32, 1, kK32, false>(p, l2, (vb - b3) * 2, smem, lists + 2 * M, over_cnts + 2 * kShards);
+        else if (vb < b1) tight_unit<16, 1, kK16, false>(p, l1, (vb - b2) * 4, smem, lists + M, over_cnts + kShards);
+        else tight_unit<8, 1, kK8, false>(p, l0, (vb - b1) * 8, smem, lists, over_cnts);
+    }
+}
+
+// Small inputs (one launch's worth of partitions: the chip is not full and a partition's own chain of dependent steps is what
+// takes the time): the threshold graph and, in the same wavefront, the full-triangle linkage for what it does not settle --
+// one launch, nothing handed on.  Measured at 1.0 M marks: 86 us against 70 + 60 us for the two tiers above.
+constexpr size_t kFastSmemBytes = cmax(cmax(sizeof(FastSmem<64, 1>), sizeof(FastSmem<32, 1>)), cmax(sizeof(FastSmem<16, 1>), sizeof(FastSmem<8, 1>)));
+constexpr size_t kLinkSmemBytes = cmax(cmax(sizeof(LinkSmem<64, 1, 64>), sizeof(LinkSmem<32, 1, 32>)), cmax(sizeof(LinkSmem<16, 1, 16>), sizeof(LinkSmem<8, 1, 8>)));
 
 __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts /* [kClasses][kShards] */)
 {
@@ -1337,7 +1832,8 @@ __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32
     __syncthreads();
     const size_t M = p.M;
     const uint32_t span = p.tps * kScanTile;
-    const WorkList l0{lists, s_pref[0], span}, l1{lists + M, s_pref[1], span}, l2{lists + 2 * M, s_pref[2], span}, l3{lists + 3 * M, s_pref[3], span};
+    const WorkList l0{lists, s_pref[0], span, 0u}, l1{lists + M, s_pref[1], span, 0u}, l2{lists + 2 * M, s_pref[2], span, 0u},
+        l3{lists + 3 * M, s_pref[3], span, 0u};
     const uint32_t c0 = l0.size(), c1 = l1.size(), c2 = l2.size(), c3 = l3.size();
     const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
     for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
@@ -1346,6 +1842,60 @@ __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32
         else if (vb < b1) fast_unit<16, 1, 16, kFastThenLink>(p, l1, (vb - b2) * 4, smem, smem_link);
         else fast_unit<8, 1, 8, kFastThenLink>(p, l0, (vb - b1) * 8, smem, smem_link);
     }
+}
+
+// The second lists: the contracted linkage again, now with as many groups as rows; what it does not vouch for either
+// (coordinates beyond 32 bits, parameters outside the binary32 tests' range) gets the round-by-round linkage on the full
+// triangle.  The two use the same scratch one after the other.
+constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+template <int GROUP, int R, int NCAP>
+struct Tier2Smem {
+    static constexpr size_t link_at = align16(sizeof(FastSmem<GROUP, R>));
+    static constexpr size_t bytes = cmax(link_at + sizeof(LinkSmem<GROUP, R, NCAP>), sizeof(TightSmem<GROUP, R, GROUP * R>));
+};
+template <int GROUP, int R, int NCAP>
+__device__ __forceinline__ void tier2_unit(const ClParams &p, const WorkList &list, uint32_t base, unsigned char *smem)
+{
+    if (tight_unit<GROUP, R, GROUP * R, true>(p, list, base, smem, nullptr, nullptr))
+        fast_unit<GROUP, R, NCAP, kLinkUnfit>(p, list, base, smem, smem + Tier2Smem<GROUP, R, NCAP>::link_at);
+}
+
+constexpr size_t kTier2SmemBytes = cmax(cmax(Tier2Smem<64, 1, 64>::bytes, Tier2Smem<32, 1, 32>::bytes), cmax(Tier2Smem<16, 1, 16>::bytes, Tier2Smem<8, 1, 8>::bytes));
+
+__global__ __launch_bounds__(64) void cl_tier2_all(const ClParams p, const uint32_t *lists, const uint32_t *over_cnts /* [kClasses][kShards] */)
+{
+    __shared__ __align__(16) unsigned char smem[kTier2SmemBytes];
+    __shared__ uint32_t s_pref[4][kShards + 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) worklist_prefix(over_cnts + c * kShards, s_pref[c]);
+    __syncthreads();
+    const size_t M = p.M;
+    const uint32_t span = p.tps * kScanTile;
+    const WorkList l0{lists, s_pref[0], span, p.M}, l1{lists + M, s_pref[1], span, p.M}, l2{lists + 2 * M, s_pref[2], span, p.M},
+        l3{lists + 3 * M, s_pref[3], span, p.M};
+    const uint32_t c0 = l0.size(), c1 = l1.size(), c2 = l2.size(), c3 = l3.size();
+    const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
+        if (vb < b3) tier2_unit<64, 1, 64>(p, l3, vb, smem);
+        else if (vb < b2) tier2_unit<32, 1, 32>(p, l2, (vb - b3) * 2, smem);
+        else if (vb < b1) tier2_unit<16, 1, 16>(p, l1, (vb - b2) * 4, smem);
+        else tier2_unit<8, 1, 8>(p, l0, (vb - b1) * 8, smem);
+    }
+}
+
+// (the partitions of more than 64 marks: their first tier already takes 64 groups; what it hands on gets the full triangle)
+template <int GROUP, int R, int NCAP>
+__global__ __launch_bounds__(64) void cl_link_one(const ClParams p, const uint32_t *items, const uint32_t *over_counts /* [kShards] */)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(FastSmem<GROUP, R>)];
+    __shared__ __align__(16) unsigned char smem_link[sizeof(LinkSmem<GROUP, R, NCAP>)];
+    __shared__ uint32_t s_pref[kShards + 1];
+    worklist_prefix(over_counts, s_pref);
+    __syncthreads();
+    const WorkList list{items, s_pref, p.tps * kScanTile, p.M};
+    const uint32_t L = list.size();
+    for (uint32_t base = blockIdx.x * (64 / GROUP); base < L; base += gridDim.x * (64 / GROUP))
+        fast_unit<GROUP, R, NCAP, kLinkOnly>(p, list, base, smem, smem_link);
 }
 
 // one thread per partition (their count lives on the device: launched over an upper bound): its clusters' records, dense from the
@@ -1470,7 +2020,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     const size_t sizes[15] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
                               ((size_t)nb_sc + 1) * sizeof(PartSum), ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + kClasses * kShards), (size_t)M * 4 * kClasses, ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8), (size_t)M * 16};
+                              ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + 2 * kClasses * kShards), (size_t)M * 4 * kClasses, ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8), (size_t)M * 16};
     int rc;
     for (int i = 0; i < 15; ++i)
         if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
@@ -1542,7 +2092,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     {
         const LoadHead heads{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)};
         PartSum *tiles = (PartSum *)tmpA;                         // 3 words per 2048 marks
-        hipLaunchKernelGGL(part_reduce, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(kClasses * kShards));
+        hipLaunchKernelGGL(part_reduce, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards));
         if (nb_sc <= kSelfSpine && !big_sort) {
             hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal, tile_first);
@@ -1560,18 +2110,23 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint32_t *cnts = scal + 64;                                  // [kClasses][kShards]
     p.tps = (nb_sc + kShards - 1) / kShards;
     p.inv_norm = (float)(1.0 / pr->normalizer);
-    p.t_lo[0] = (float)(pr->max_dist * (1.0 - 1e-5));
-    p.t_hi[0] = (float)(pr->max_dist * (1.0 + 1e-5));
+    for (int l = 0; l < 3; ++l) {
+        p.t_lo[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 - 1e-5));
+        p.t_hi[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 + 1e-5));
+    }
     p.fast = (pr->max_dist >= 1e-6 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
     p.box = (ctx->dbg & DUET_DBG_CLUSTER_NOBOX) ? 0u : 1u;
     p.invn = 1.0 / pr->normalizer;
     p.scale = (double)kQOne / pr->max_dist;
     p.mergeable = pr->max_dist >= 0 ? 1u : 0u;
+    p.kc = (ctx->dbg & DUET_DBG_CLUSTER_KC2) ? 2u : 64u;
+    if (getenv("DUET_X_KC")) p.kc = (uint32_t)atoi(getenv("DUET_X_KC"));
     const uint32_t gridw = std::min(32768u, std::max(1024u, M / 256u));     // (a wavefront per virtual block, striding)
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
-    const uint32_t *l4 = lists + 4 * (size_t)M, *c4 = cnts + 4 * kShards;
+    uint32_t *over = cnts + kClasses * kShards;                  // [kClasses][kShards] the second lists' counters
+    uint32_t *l4 = lists + 4 * (size_t)M, *c4 = cnts + 4 * kShards, *o4 = over + 4 * kShards;
     // The partitions of more than 64 marks on the side stream: few, long chains.  They are listed from the partition starts
     // alone and read their rows through the sort permutation themselves, so their launch starts beside cl_box, not after it
     // (1.0 M marks: the chain ended 30-40 us after everything else when it started behind cl_box).
@@ -1581,24 +2136,34 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         ClParams pb = p;
         pb.gather_rows = 1;
         const uint32_t g_parts = std::min((M + 255u) / 256u, std::max(256u, (M + 255u) / 256u / 8u));
-        hipLaunchKernelGGL(cl_big_list, dim3(g_parts), dim3(256), 0, ctx->cl_side[0], pb, lists + 4 * (size_t)M, cnts + 4 * kShards);
+        hipLaunchKernelGGL(cl_big_list, dim3(g_parts), dim3(256), 0, ctx->cl_side[0], pb, l4, c4);
         const uint32_t gb = small ? (grid < 4096u ? grid : 4096u) : grid;
-        if (cap100) hipLaunchKernelGGL((cl_fast_one<64, 2, 100, kLinkOnly>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, c4);
-        else hipLaunchKernelGGL((cl_fast_one<64, 2, 128, kLinkOnly>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, c4);
+        hipLaunchKernelGGL((cl_tight_one<64, 2, 64>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, (const uint32_t *)c4, o4);
+        const uint32_t gl = std::min(gb, 1024u);
+        if (cap100) hipLaunchKernelGGL((cl_link_one<64, 2, 100>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
+        else hipLaunchKernelGGL((cl_link_one<64, 2, 128>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
         HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
     }
+    const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
     hipLaunchKernelGGL(cl_box, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
-    if (small) {
-        // one launch for the classes of up to 64 marks
+    if (!tiers) {
+        // one launch for the classes of up to 64 marks, nothing handed on
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
+    } else if (small) {
+        hipLaunchKernelGGL(cl_tight_all, dim3(gridw), dim3(64), 0, st, p, lists, (const uint32_t *)cnts, over);
     } else {
-        // one launch per size class (the registers and the LDS each variant needs, not the largest one's)
-        hipLaunchKernelGGL((cl_fast_one<64, 1, 64, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 3 * (size_t)M), (const uint32_t *)(cnts + 3 * kShards));
-        hipLaunchKernelGGL((cl_fast_one<32, 1, 32, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 2 * (size_t)M), (const uint32_t *)(cnts + 2 * kShards));
-        hipLaunchKernelGGL((cl_fast_one<16, 1, 16, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)(lists + 1 * (size_t)M), (const uint32_t *)(cnts + 1 * kShards));
-        hipLaunchKernelGGL((cl_fast_one<8, 1, 8, kFastThenLink>), dim3(grid), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
+        // the first tier, one launch per size class: the registers and the LDS each variant needs, not the largest one's.
+        // (Measured and dropped, profiles/history: the tiles in two or four pieces, a piece's box test on a side stream while the
+        // first tier takes the piece before -- the box test, 32 KB of LDS per workgroup, then waits for room between the first
+        // tier's many small workgroups and takes as long for a piece as it does alone for everything.)
+        hipLaunchKernelGGL((cl_tight_one<64, 1, kK64>), dim3(grid), dim3(64), 0, st, p, lists + 3 * (size_t)M, (const uint32_t *)(cnts + 3 * kShards), over + 3 * kShards);
+        hipLaunchKernelGGL((cl_tight_one<32, 1, kK32>), dim3(grid), dim3(64), 0, st, p, lists + 2 * (size_t)M, (const uint32_t *)(cnts + 2 * kShards), over + 2 * kShards);
+        hipLaunchKernelGGL((cl_tight_one<16, 1, kK16>), dim3(grid), dim3(64), 0, st, p, lists + 1 * (size_t)M, (const uint32_t *)(cnts + 1 * kShards), over + 1 * kShards);
+        hipLaunchKernelGGL((cl_tight_one<8, 1, kK8>), dim3(grid), dim3(64), 0, st, p, lists, (const uint32_t *)cnts, over);
     }
+    // what they handed on
+    if (tiers) hipLaunchKernelGGL(cl_tier2_all, dim3(std::min(gridw, 2048u)), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)over);
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
@@ -1606,13 +2171,14 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     hipLaunchKernelGGL(cl_emit, dim3(std::min(g256.x, std::max(1024u, g256.x / 8u))), b256, 0, st, p);
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
-        uint32_t h[64 + kClasses * kShards];
+        uint32_t h[64 + 2 * kClasses * kShards];
         HIP_TRY(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        uint32_t c[kClasses] = {0, 0, 0, 0, 0};
-        for (int k = 0; k < kClasses; ++k)
+        uint32_t c[2 * kClasses] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 2 * kClasses; ++k)
             for (int sh = 0; sh < kShards; ++sh) c[k] += h[64 + k * kShards + sh];
-        fprintf(stderr, "[duet_cluster] parts %u; past the box test, by size class: %u %u %u %u %u\n", h[0], c[0], c[1], c[2], c[3], c[4]);
+        fprintf(stderr, "[duet_cluster] parts %u; past the box test, by size class: %u %u %u %u %u; handed on to the full triangle: %u %u %u %u %u\n",
+                h[0], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9]);
     }
     return DUET_OK;
 }

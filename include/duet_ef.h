@@ -141,6 +141,9 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */
 #define DUET_DBG_CLUSTER_PAIRS 0x400u   /* A0: sort (key, mark index) pairs even when the index fits the key's spare bits */
 #define DUET_DBG_CLUSTER_NOBOX 0x800u   /* A0: no bounding-box test: every partition goes through the threshold-graph pair loops */
+#define DUET_DBG_CLUSTER_TIERS 0x2000u  /* A0: small inputs take the two-tier contracted linkage of large inputs in one launch per tier */
+#define DUET_DBG_CLUSTER_KC2 0x1000u    /* A0: the contracted linkage keeps partitions with at most 2 groups (default 16); the others
+                                           take the second lists (full-triangle linkage) */
 DUET_API int duet_ctx_set_debug(duet_ctx *ctx, uint32_t flags);
 
 /* Debug/inspection: copy contig k's sorted seed-PS array of the LAST run to `out` (capacity `cap`),

@@ -24,9 +24,11 @@ def check(ctx, marks, **kw):
     want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
     # hints on/off (sort key width), fast paths on/off (DUET_DBG_CLUSTER_EXACT = 0x100: everything through the exact linkage)
     # ... the launch structure of large inputs (DUET_DBG_CLUSTER_LARGE = 0x200), the pair sort (DUET_DBG_CLUSTER_PAIRS = 0x400),
-    # no bounding-box test (DUET_DBG_CLUSTER_NOBOX = 0x800: every partition through the threshold-graph pair loops)
+    # no bounding-box test (DUET_DBG_CLUSTER_NOBOX = 0x800: every partition through the threshold-graph pair loops);
+    # DUET_DBG_CLUSTER_KC2 = 0x1000: partitions with more than two groups left take the second tier;
+    # DUET_DBG_CLUSTER_TIERS = 0x2000: the two tiers in their fused (small-input) launches
     for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600), (True, 0x800),
-                       (True, 0xA00), (True, 0x300)):
+                       (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
