@@ -49,6 +49,8 @@ namespace {
 #include "duet_prims.hip.h"
 
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 struct ClParams {
     uint32_t M;
     uint32_t part_gap, part_max;
@@ -67,6 +69,7 @@ struct ClParams {
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
     float inv_norm, t_lo[3], t_hi[3];                 // binary32 pair tests: 1/normalizer; level * (1 -/+ 1e-5) for the levels max_dist, / 2, / 4
+    float2v t_hl[3];                                  // (t_hi, t_lo) side by side: one packed subtract and multiply per level
     uint32_t kc;                                      // contracted linkage: the first tier's group limit is min(kc, the variant's own): tests lower it
     uint32_t fast;                                    // 0: parameters outside the fast pass's vetted range, everything goes to the exact linkage
     uint32_t box;                                     // 0: no bounding-box test (tests: every partition through the pair loops)
@@ -1467,14 +1470,17 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
                 const float fm = (float)max(max(spk[r], q.y), 1u), fs = (float)absdiff_u32(spk[r], q.y);
                 const float dp = (float)m * p.inv_norm;
                 bool amb = false;
+                const float2v dp2 = {dp, dp}, fm2 = {fm, fm};        // (both bounds of a level in one packed subtract and multiply)
                 if constexpr (L0) {
-                    const bool h = fs <= (p.t_hi[0] - dp) * fm, l = fs <= (p.t_lo[0] - dp) * fm;
+                    const float2v b = (p.t_hl[0] - dp2) * fm2;
+                    const bool h = fs <= b.x, l = fs <= b.y;
                     amb = in && h != l;
                     a0[r] |= ((in && h) ? 1u : 0u) << (j - 32u * W);
                 }
                 if constexpr (L12) {
-                    const bool h1 = fs <= (p.t_hi[1] - dp) * fm, l1 = fs <= (p.t_lo[1] - dp) * fm;
-                    const bool h2 = fs <= (p.t_hi[2] - dp) * fm, l2 = fs <= (p.t_lo[2] - dp) * fm;
+                    const float2v b1 = (p.t_hl[1] - dp2) * fm2, b2 = (p.t_hl[2] - dp2) * fm2;
+                    const bool h1 = fs <= b1.x, l1 = fs <= b1.y;
+                    const bool h2 = fs <= b2.x, l2 = fs <= b2.y;
                     amb = amb || (in12 && (h1 != l1 || h2 != l2));
                     a1[r] |= ((in12 && h1) ? 1u : 0u) << (j - 32u * W);
                     a2[r] |= ((in12 && h2) ? 1u : 0u) << (j - 32u * W);
@@ -1862,7 +1868,8 @@ __device__ __forceinline__ void tier2_unit(const ClParams &p, const WorkList &li
 
 constexpr size_t kTier2SmemBytes = cmax(cmax(Tier2Smem<64, 1, 64>::bytes, Tier2Smem<32, 1, 32>::bytes), cmax(Tier2Smem<16, 1, 16>::bytes, Tier2Smem<8, 1, 8>::bytes));
 
-__global__ __launch_bounds__(64) void cl_tier2_all(const ClParams p, const uint32_t *lists, const uint32_t *over_cnts /* [kClasses][kShards] */)
+__global__ __launch_bounds__(64) void cl_tier2_all(const ClParams p, const uint32_t *lists, const uint32_t *over_cnts /* [kClasses][kShards] */,
+                                                   uint32_t with64 /* 0: the class of 33..64 marks has a launch of its own */)
 {
     __shared__ __align__(16) unsigned char smem[kTier2SmemBytes];
     __shared__ uint32_t s_pref[4][kShards + 1];
@@ -1873,7 +1880,7 @@ __global__ __launch_bounds__(64) void cl_tier2_all(const ClParams p, const uint3
     const uint32_t span = p.tps * kScanTile;
     const WorkList l0{lists, s_pref[0], span, p.M}, l1{lists + M, s_pref[1], span, p.M}, l2{lists + 2 * M, s_pref[2], span, p.M},
         l3{lists + 3 * M, s_pref[3], span, p.M};
-    const uint32_t c0 = l0.size(), c1 = l1.size(), c2 = l2.size(), c3 = l3.size();
+    const uint32_t c0 = l0.size(), c1 = l1.size(), c2 = l2.size(), c3 = with64 ? l3.size() : 0u;
     const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
     for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
         if (vb < b3) tier2_unit<64, 1, 64>(p, l3, vb, smem);
@@ -1881,6 +1888,19 @@ __global__ __launch_bounds__(64) void cl_tier2_all(const ClParams p, const uint3
         else if (vb < b1) tier2_unit<16, 1, 16>(p, l1, (vb - b2) * 4, smem);
         else tier2_unit<8, 1, 8>(p, l0, (vb - b1) * 8, smem);
     }
+}
+
+template <int GROUP, int R, int NCAP>
+__global__ __launch_bounds__(64) void cl_tier2_one(const ClParams p, const uint32_t *items, const uint32_t *over_counts /* [kShards] */)
+{
+    __shared__ __align__(16) unsigned char smem[Tier2Smem<GROUP, R, NCAP>::bytes];
+    __shared__ uint32_t s_pref[kShards + 1];
+    worklist_prefix(over_counts, s_pref);
+    __syncthreads();
+    const WorkList list{items, s_pref, p.tps * kScanTile, p.M};
+    const uint32_t L = list.size();
+    for (uint32_t base = blockIdx.x * (64 / GROUP); base < L; base += gridDim.x * (64 / GROUP))
+        tier2_unit<GROUP, R, NCAP>(p, list, base, smem);
 }
 
 // (the partitions of more than 64 marks: their first tier already takes 64 groups; what it hands on gets the full triangle)
@@ -2113,6 +2133,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     for (int l = 0; l < 3; ++l) {
         p.t_lo[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 - 1e-5));
         p.t_hi[l] = (float)(pr->max_dist / (double)(1 << l) * (1.0 + 1e-5));
+        p.t_hl[l] = float2v{p.t_hi[l], p.t_lo[l]};
     }
     p.fast = (pr->max_dist >= 1e-6 && pr->max_dist <= 1e6 && pr->normalizer >= 1e-3 && pr->normalizer <= 1e9) ? 1u : 0u;
     if (ctx->dbg & DUET_DBG_CLUSTER_EXACT) p.fast = 0;
@@ -2158,12 +2179,18 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         // first tier takes the piece before -- the box test, 32 KB of LDS per workgroup, then waits for room between the first
         // tier's many small workgroups and takes as long for a piece as it does alone for everything.)
         hipLaunchKernelGGL((cl_tight_one<64, 1, kK64>), dim3(grid), dim3(64), 0, st, p, lists + 3 * (size_t)M, (const uint32_t *)(cnts + 3 * kShards), over + 3 * kShards);
+        // (what this class hands on -- the most of all classes -- has its second tier beside the other classes' first one)
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[1], ctx->cl_join[1], 0));
+        hipLaunchKernelGGL((cl_tier2_one<64, 1, 64>), dim3(std::min(grid, 4096u)), dim3(64), 0, ctx->cl_side[1], p, (const uint32_t *)(lists + 3 * (size_t)M), (const uint32_t *)(over + 3 * kShards));
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[2], ctx->cl_side[1]));
         hipLaunchKernelGGL((cl_tight_one<32, 1, kK32>), dim3(grid), dim3(64), 0, st, p, lists + 2 * (size_t)M, (const uint32_t *)(cnts + 2 * kShards), over + 2 * kShards);
         hipLaunchKernelGGL((cl_tight_one<16, 1, kK16>), dim3(grid), dim3(64), 0, st, p, lists + 1 * (size_t)M, (const uint32_t *)(cnts + 1 * kShards), over + 1 * kShards);
         hipLaunchKernelGGL((cl_tight_one<8, 1, kK8>), dim3(grid), dim3(64), 0, st, p, lists, (const uint32_t *)cnts, over);
     }
     // what they handed on
-    if (tiers) hipLaunchKernelGGL(cl_tier2_all, dim3(std::min(gridw, 2048u)), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)over);
+    if (tiers) hipLaunchKernelGGL(cl_tier2_all, dim3(std::min(gridw, 2048u)), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)over, small ? 1u : 0u);
+    if (!small) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[2], 0));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
