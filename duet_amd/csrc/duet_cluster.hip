@@ -5,29 +5,33 @@
 // so there is no reference code to follow; the rule implemented here is this repository's own deterministic
 // statement of the published SVIM 1.4.2 scheme, normative text in oracle/cluster_oracle.c / DESIGN.md section 9.
 //
-// Pipeline:
+// Pipeline (DESIGN.md section 9 has the rule, the argument and the measurements):
 //   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, the mark index in the spare
-//                  bits above them when it fits (else a separate value array)
+//                  bits above them when it fits (else a separate value array); (pos, span[, read index]) side by side
 //   radix sort     stable LSD, 8-bit digits: rx_hist -> tile offsets -> rx_scatter per pass (ballot-ranked, no atomics
 //                  on the data path, so the order is deterministic); keys only when the index rides in the key
 //   partitions     one scan over a composite element straight off the sorted keys: natural partition starts (contig/type
-//                  change or centre gap > part_gap), a partition there and every part_max marks after -> partition ids
-//                  and the partition start list
-//   cl_classes     work lists by partition size (<= 8 / 16 / 32 / 64 / 128 marks)
-//   fast pass      per size class, GROUP lanes per partition: clusters read off the threshold graph where that is
-//                  provably what average linkage produces (see the comment above fast_unit); what it cannot settle
-//                  goes, component by component, on work lists
-//   exact pass     binary64 average linkage for the listed components (nearest-neighbour cache per row)
-//   rank pass      finishes the partitions that had listed components
-//                  fast and rank passes write each mark to its place in the partition's output (order[], and in the
-//                  fused pipeline its read index) and leave, per cluster, a record (rank, end, floor means) at the
-//                  partition's start + the cluster's index
+//                  change or centre gap > part_gap), a partition there and every part_max marks after -> the partition
+//                  start list and the first partition of every 2048-position tile
+//   cl_box         one workgroup per tile: gathers the tile's marks through the sort permutation, finishes the partitions whose
+//                  bounding box proves ONE cluster (most, on SV-like data), lays the others' rows out in sorted order and
+//                  lists them by size class (<= 8 / 16 / 32 / 64 marks; > 64: cl_big_list, on a side stream beside cl_box)
+//   agglomeration  GROUP lanes per partition, one lane per mark.
+//                  small inputs: cl_fast_all -- the threshold graph and, in the same wavefront, the exact linkage on the full
+//                  triangle of sums for what that does not settle (fast_unit, link_unit);
+//                  large inputs: the contracted linkage in two tiers (tight_unit: threshold graph, tight groups, k x k sums,
+//                  rounds on the groups; 5 KB of LDS per wavefront instead of 21), one launch per size class, what a tier does
+//                  not take on the class's second list; the partitions of more than 64 marks take this path at every size
+//                  every path writes each mark to its place in the partition's output (order[], and in the fused pipeline its
+//                  read index) and leaves, per cluster, a record (rank, end, floor means) at the partition's start + the
+//                  cluster's index (emit_prep)
 //   scan + cl_emit clusters per partition -> candidate bases; one thread per partition turns its clusters' records into cand_*[]
 //
-// Bit-exactness vs the oracle: what is emitted depends only on the final clusters; the exact pass evaluates the same
-// binary64 expressions in the same order as the oracle (-ffp-contract=off; ties to the smallest (first, second)
-// index pair), and the fast pass only accepts clusters it can prove (guard bands wider than any rounding error),
-// so both produce the oracle's clusters.
+// Bit-exactness vs the oracle: the rule works on integers (distances in fixed point relative to the threshold, cluster
+// distances exact means), so what is emitted does not depend on the order in which provably-first merges are made; the
+// binary32 pair tests only decide what lies outside their guard bands, the rest is evaluated in binary64 exactly as the
+// oracle does (-ffp-contract=off).  All paths produce the oracle's clusters; tests/test_gpu_cluster.py and tools/stress.py
+// run every case through every path (DUET_DBG_CLUSTER_* in include/duet_ef.h).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -2204,7 +2208,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         uint32_t c[2 * kClasses] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < 2 * kClasses; ++k)
             for (int sh = 0; sh < kShards; ++sh) c[k] += h[64 + k * kShards + sh];
-        fprintf(stderr, "[duet_cluster] parts %u; past the box test, by size class: %u %u %u %u %u; handed on to the full triangle: %u %u %u %u %u\n",
+        fprintf(stderr, "[duet_cluster] parts %u; past the box test, by size class: %u %u %u %u %u; handed on by the first tier: %u %u %u %u %u\n",
                 h[0], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9]);
     }
     return DUET_OK;

@@ -11,7 +11,7 @@ mkdir -p $P
 cd $R
 timeout 1800 python3 -m pytest tests -m gpu -x -q > $O/${T}_tests.log 2>&1
 echo "rc=$?" >> $O/${T}_tests.log
-timeout 600 python3 tools/stress.py 300 1500 > $O/${T}_stress.log 2>&1
+timeout 1200 python3 tools/stress.py 500 6600 > $O/${T}_stress.log 2>&1
 echo "rc=$?" >> $O/${T}_stress.log
 DUET_CL_DEBUG=1 timeout 300 python3 tools/prof_fused.py > $O/${T}_cldebug_small.log 2>&1
 DUET_CL_DEBUG=1 timeout 300 python3 tools/prof_fused.py big > $O/${T}_cldebug_big.log 2>&1

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from the round's counter passes and kernel-trace summaries in profiles/ (what bench.py's
+"""profiles/rNN_pmc_traffic.json from a round's counter passes and kernel-trace summaries in profiles/ (what bench.py's
 `roofline.traffic` and README's table quote): per workload the FETCH_SIZE / WRITE_SIZE means per ef_classify launch, corrected
 as tools/pmc_summary.py documents, beside the kernel-trace average and the algorithmic bytes 12 M + 22 C + 8 R of DESIGN.md.
 
-    python3 tools/pmc_traffic.py > profiles/r02_pmc_traffic.json
+    python3 tools/pmc_traffic.py r03 [collection date, e.g. 2026-10-03T14:10Z] > profiles/r03_pmc_traffic.json
 """
-import csv, json, os
+import csv, json, os, sys
+
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+COLLECTED = sys.argv[2] if len(sys.argv) > 2 else None
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles')
 WORK = [
@@ -37,13 +40,13 @@ def trace_avg(path):
 
 out = []
 for name, text, M, C, R in WORK:
-    files = ['r02_%s_pmc_FETCH_SIZE.csv' % name, 'r02_%s_pmc_WRITE_SIZE.csv' % name, 'r02_%s_kernel_stats.csv' % name]
+    files = ['%s_%s_pmc_FETCH_SIZE.csv' % (ROUND, name), '%s_%s_pmc_WRITE_SIZE.csv' % (ROUND, name), '%s_%s_kernel_stats.csv' % (ROUND, name)]
     f_kb, nf = mean_counter(os.path.join(ROOT, files[0]), 'FETCH_SIZE')
     w_kb, nw = mean_counter(os.path.join(ROOT, files[1]), 'WRITE_SIZE')
     us, calls = trace_avg(os.path.join(ROOT, files[2]))
     traffic = int(round((2 * f_kb + w_kb) * 1024))
     alg = 12 * M + 22 * C + 8 * R
-    out.append({'kernel': 'ef_classify', 'workload': text, 'FETCH_SIZE_KB_per_launch': f_kb, 'WRITE_SIZE_KB_per_launch': w_kb,
+    out.append({'kernel': 'ef_classify', 'workload': text, 'collected': COLLECTED, 'FETCH_SIZE_KB_per_launch': f_kb, 'WRITE_SIZE_KB_per_launch': w_kb,
                 'launches_counted': [nf, nw],
                 'correction': 'counters are KB; FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads), WRITE_SIZE exact',
                 'traffic_bytes_per_launch': traffic, 'kernel_trace_avg_us': us, 'kernel_trace_calls': calls, 'files': files,
