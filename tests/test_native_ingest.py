@@ -190,3 +190,58 @@ def test_rows_pool_and_header(name, src, params, tmp_path):
     assert rows is not None and rows['n_chrom_texts'] >= 1
     assert ing.header(False).decode() + rows_from_pool(ing, rows, pred, ps) == want
     ing.close()
+
+
+@pytest.mark.parametrize('name,src,params', H.full_cases()[:6], ids=[c[0] for c in H.full_cases()[:6]])
+def test_sharded_entry_points(name, src, params, tmp_path):
+    """What the N-GPU path builds on (duet_amd/multi.py): the pre-count agrees with the parsed call set, an ingest that owns
+    a subset of the contigs holds exactly their candidates, and the per-rank text blocks, numbered from the counts of all
+    ranks and laid end to end in the order of their CHROM texts, are the single-process file body."""
+    home = str(tmp_path / name)
+    shutil.copytree(src, home)
+    materialise_bams(home)
+    vcf, sam = home + '/sv_calling/variants.vcf', home + '/snp_phasing/'
+    whole = native.NativeIngest.load(vcf, sam, CHROMS, 2)
+    assert whole is not None and whole.handle
+    K = whole.soa.n_contigs
+    per_contig = np.diff(np.asarray(whole.soa.cand_ctg_off, dtype=np.int64))
+    n_rec, n_bytes = native.NativeIngest.precount(vcf, CHROMS)
+    assert np.array_equal(np.asarray(n_rec[:K], dtype=np.int64), per_contig)
+    assert all((b > 0) == (r > 0) for r, b in zip(n_rec[:K], n_bytes[:K]))
+    rc, pred, ps = c_oracle.ef(whole.soa, params['svlen_thres'], params['suppread_thres'])
+    assert rc == 0
+    want = b''.join(l for l in whole.emit(pred, ps, False).splitlines(keepends=True) if not l.startswith(b'#'))     # the rows
+    # two "ranks": the contigs dealt out alternately among those that have records
+    have = [k for k in range(K) if per_contig[k]]
+    owned = [have[0::2], have[1::2]]
+    parts, kept = [], []
+    for mine in owned:
+        ing = native.NativeIngest.load(vcf, sam, CHROMS, 2, owned=mine)
+        assert ing is not None and ing.handle
+        mine_cnt = np.diff(np.asarray(ing.soa.cand_ctg_off, dtype=np.int64))
+        assert all(mine_cnt[k] == (per_contig[k] if k in mine else 0) for k in range(K))
+        rc, p1, s1 = c_oracle.ef(ing.soa, params['svlen_thres'], params['suppread_thres'])
+        assert rc == 0
+        parts.append((ing, p1, s1))
+        kept.append(ing.count_kept(p1))
+    total = kept[0] + kept[1]
+    assert np.array_equal(total, whole.count_kept(pred))
+    # rows are numbered in the order of the CHROM texts (byte order), a slot's rows consecutively
+    from duet_amd import multi
+    order = multi.text_order(CHROMS)
+    base = np.ones(2 * K, dtype=np.int64)
+    run = 1                                              # (the ID column counts from 1: write_file.py:9-14)
+    for slot in order:
+        base[slot] = run
+        run += int(total[slot])
+    blocks = {}
+    for ing, p1, s1 in parts:
+        text, off, ln = ing.emit_blocks(p1, s1, base)
+        for slot in range(2 * K):
+            if ln[slot]:
+                assert slot not in blocks
+                blocks[slot] = text[int(off[slot]):int(off[slot]) + int(ln[slot])]
+        ing.close()
+    body = b''.join(blocks.get(slot, b'') for slot in order)
+    assert body == want
+    whole.close()
