@@ -597,6 +597,8 @@ def single_gpu_run(args, ctx, torch):
         ex['fused_clustered_and_phased_config2'] = fused
         ex['fused_clustered_and_phased_2e7_marks'] = fused_point(ctx, torch, engine, synth,
                                                                   synth.bench_genome(20000000, 3), runs=5)
+        ex['fused_clustered_and_phased_2e7_marks_scan_order'] = fused_point(ctx, torch, engine, synth,
+                                                                             synth.bench_genome(20000000, 3), runs=5, scan_order=True)
         ex['three_timed_regions_config2'] = abi_and_e2e(ctx, soa, contig, float(iso.total_ms))
         ex['concurrent_jobs_config2'] = concurrent_jobs(torch, _lib, DeviceProblem, soa, args.steps)
     return out
@@ -789,13 +791,13 @@ def cluster_point(ctx, torch, synth, contigs):
             'note': 'latency-bound at this size: ~30 small launches; the few 65..100-mark partitions are on the critical path'}
 
 
-def fused_point(ctx, torch, engine, synth, contigs, runs=20):
+def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False):
     """The metric read literally -- marks clustered AND phased: duet_svim_phase_device on raw shuffled marks
     (A0 sort + linkage + emit, adapter, E/F) resident in HBM, checked against the two C oracles composed."""
     from duet_amd.devmem import DeviceSvim
     c_oracle = cpu_leg()
     soa = engine.soa_from_synth(contigs)
-    marks = synth.raw_marks(contigs, 1, reads_of=soa)
+    marks = synth.raw_marks(contigs, 1, reads_of=soa, scan_order=scan_order)
     depth, depth_off = synth.depth_bins(contigs, 1000, 1)
     ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
     for _ in range(3):
@@ -841,6 +843,8 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20):
                          'run_ms': dt * 1e3,
                          'note': 'whole pipeline: (B_A0 + B_EF) / wall time per run, back-to-back runs resident in HBM; the '
                                  'sort passes and the pair distances of the agglomeration are not credited (SURVEY 8d)'},
+            'mark_order': ('as a scan of coordinate-sorted BAMs emits them (contig by contig, read by read)' if scan_order
+                           else 'shuffled over the whole genome (worst case for the gathers through the sort permutation)'),
             'note': 'asynchronous call (E/F planned on the device); the second figure is the variant with one host round trip'}
 
 

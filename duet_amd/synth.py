@@ -236,10 +236,12 @@ def bench_genome(n_marks_target, seed, labels=None, reads_per_mark=0.2, mean_deg
 MARK_TYPES = {'DEL': 0, 'INS': 1, 'INV': 2, 'DUP': 3}
 
 
-def raw_marks(contigs, seed, pos_jitter=40, span_jitter_pct=6, shuffle=True, reads_of=None):
+def raw_marks(contigs, seed, pos_jitter=40, span_jitter_pct=6, shuffle=True, reads_of=None, scan_order=False):
     """Raw SV marks (signatures) for the A0 clustering stage: every support-read mark of every candidate
     becomes one (contig, type, pos, span) record near its candidate -- pos +- pos_jitter, span within
-    +- span_jitter_pct % of the candidate's |SVLEN| -- in shuffled order (a BAM scan emits them read by read).
+    +- span_jitter_pct % of the candidate's |SVLEN| -- in shuffled order (the worst case for everything that gathers by
+    mark index), or with scan_order in the order a scan of coordinate-sorted BAMs emits them: contig by contig, read by read,
+    a read starting up to 10 kb in front of its mark.
     -> dict(contig u16[M], type u8[M], pos u32[M], span u32[M], truth int64[M] (global candidate index)
             [, read u32[M] = the mark's index into reads_of.read_tag or 0xFFFFFFFF, when reads_of (an EfSoA built
             from the same contigs) is given])"""
@@ -266,7 +268,11 @@ def raw_marks(contigs, seed, pos_jitter=40, span_jitter_pct=6, shuffle=True, rea
     out = {k: np.concatenate(v) if v else np.zeros(0, dtype=np.int64) for k, v in parts.items()}
     if reads_of is not None:
         out['read'] = reads_of.mark_read.astype(np.int64)          # same (candidate-major) order as the marks above
-    if shuffle and len(out['pos']):
+    if scan_order and len(out['pos']):
+        start = np.maximum(out['pos'] - rng.below(len(out['pos']), 10000), 0)
+        perm = np.argsort(out['contig'] * (1 << 40) + start, kind='stable')
+        out = {k: v[perm] for k, v in out.items()}
+    elif shuffle and len(out['pos']):
         perm = np.argsort(rng.u64(len(out['pos'])), kind='stable')
         out = {k: v[perm] for k, v in out.items()}
     res = dict(contig=out['contig'].astype(np.uint16), type=out['type'].astype(np.uint8),

@@ -13,7 +13,7 @@ for a in sys.argv[1:]:
         ctx.set_debug(int(a[4:], 0))      # DUET_DBG_* bits of include/duet_ef.h, e.g. dbg=0x200
 contigs = synth.bench_genome(20000000, 3) if big else [synth.bench_contig('1', 200000, 100000, 1)]
 soa = engine.soa_from_synth(contigs)
-marks = synth.raw_marks(contigs, 1, reads_of=soa)
+marks = synth.raw_marks(contigs, 1, reads_of=soa, scan_order='scan' in sys.argv[1:])
 depth, depth_off = synth.depth_bins(contigs, 1000, 1)
 ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
 for _ in range(3):
