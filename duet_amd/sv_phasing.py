@@ -95,7 +95,9 @@ def sv_phasing(home, svlen_thres, suppread_thres, thread, include_all_ctgs, devi
     out_vcf = home + '/phased_sv.vcf'
     logging.info('create output .vcf file')
     done = False
-    if int(gpus) > 1:
+    # (DUET_FORCE_RANKS=1: the one-process-per-GPU path even with one GPU -- rank 0 of 1 over RCCL; tests use it to take the
+    # collective through the real backend on a one-GPU box)
+    if int(gpus) > 1 or os.environ.get('DUET_FORCE_RANKS') == '1':
         from duet_amd import multi
         done = multi.sv_phasing_sharded(home, svlen_thres, suppread_thres, thread, include_all_ctgs, int(gpus))
     if not done:

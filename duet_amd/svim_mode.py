@@ -223,7 +223,7 @@ def sv_phasing_from_bams(home, svlen_thres, suppread_thres, thread, include_all_
     with open(out_vcf, 'w') as out:
         out.write(header_text(home, chroms))
     logging.info('extract SNP and SV signatures from the haplotagged alignments')
-    if int(gpus) > 1:
+    if int(gpus) > 1 or os.environ.get('DUET_FORCE_RANKS') == '1':       # (see sv_phasing.py)
         from duet_amd import launch
         argv = ['-m', 'duet_amd.svim_mode', home, str(int(svlen_thres)), str(int(suppread_thres)), str(int(thread)),
                 '1' if include_all_ctgs else '0', repr(float(cluster_max_distance))]

@@ -74,3 +74,29 @@ def test_eight_ranks_with_the_real_kernels(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     with open(home + '/phased_sv.vcf', 'rb') as f:
         assert H.sha256_bytes(f.read()) == p['output_sha256']
+
+
+def test_one_rank_over_rccl(tmp_path):
+    """The collective backend a real multi-GPU run uses, on the one GPU of this box: DUET_FORCE_RANKS=1 takes
+    `sv_phasing(..., gpus=1)` and the sharded SVIM mode through the one-process-per-GPU path with ONE rank and backend "nccl"
+    (RCCL: communicator set-up on the device, all_gather_into_tensor on device memory beside the kernels' stream, barrier,
+    tear-down) instead of the gloo plumbing mode of the other sharded tests."""
+    home = str(tmp_path / 'g')
+    p = [x for x in H.seeded_r2_plan() if x['kind'] == 'genome_small' and x['dialect'] == 'sniffles'][0]
+    H.build_case(home, 'genome_small', p['seed'], 'sniffles', write_sam=False)
+    r = fresh_interpreter('from duet_amd.sv_phasing import sv_phasing\nsv_phasing(%r, %d, %d, 4, False, gpus=1)\n' % (
+        home, p['svlen_thres'], p['suppread_thres']), {'DUET_FORCE_RANKS': '1', 'NCCL_DEBUG': 'VERSION'})
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b'RCCL version' in r.stdout + r.stderr            # (the library announces itself when its communicator is set up)
+    with open(home + '/phased_sv.vcf', 'rb') as f:
+        assert H.sha256_bytes(f.read()) == p['output_sha256']
+    from duet_amd import svim_mode
+    home2 = str(tmp_path / 'w')
+    synth.write_svim_workdir(home2, H.case_contigs('genome_small', 5), 5)
+    svim_mode.sv_phasing_from_bams(home2, 50, 2, 4, False, 0.9, 0)
+    one = open(home2 + '/phased_sv.vcf').read()
+    os.remove(home2 + '/phased_sv.vcf')
+    r = fresh_interpreter('from duet_amd import svim_mode\nsvim_mode.sv_phasing_from_bams(%r, 50, 2, 4, False, 0.9, 0, gpus=1)\n' % home2,
+                          {'DUET_FORCE_RANKS': '1'})
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert open(home2 + '/phased_sv.vcf').read() == one
