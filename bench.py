@@ -217,7 +217,7 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, group):
     Every job is gathered completely before the clock stops."""
     from duet_amd.dist import GroupedGather
     stream = torch.cuda.current_stream().cuda_stream
-    gg = GroupedGather(dp.out_storage, dp.out_blocks[0].numel(), world, group, dist_mod)
+    gg = GroupedGather(dp.out_storage, dp.out_blocks[0].numel(), world, group, dist_mod, always=dist_mod is not None)
 
     def one():
         dp.run(ctx, stream, gg.next_slot())
@@ -229,7 +229,7 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, group):
     ctx.check(stream)
     ctx.set_profiling(3)                 # HIP start/stop events on ef_classify's own dispatch, every 8th step
     ctx.profile_collect()
-    if world > 1:
+    if dist_mod is not None:
         dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -237,7 +237,7 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, group):
         one()
     gg.drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_mod is not None:
         dist_mod.barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_collect()
@@ -650,16 +650,25 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist_mod = None
-    if world > 1:
+    # DUET_BENCH_RCCL_SELF=1 (a check on a 1-GPU box, never a measurement): the N > 1 code path as ONE rank over backend
+    # "nccl" -- communicator set-up, the asynchronous all_gather_into_tensor on RCCL's stream beside the kernels' raw
+    # stream, barriers, all-reduces -- on the sharded configs[2] problem
+    rccl_self = world == 1 and os.environ.get('DUET_BENCH_RCCL_SELF') == '1'
+    if world > 1 or rccl_self:
         import torch.distributed as dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if rccl_self:
+            from duet_amd import launch as _launch
+            os.environ.setdefault('MASTER_PORT', str(_launch.free_port()))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if one_gpu:
             dist_mod.init_process_group('gloo')
         else:
             dist_mod.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     ctx = _lib.Context(local_rank)
-    if world == 1:
+    if world == 1 and not rccl_self:
         out = single_gpu_run(args, ctx, torch)
     else:
         out = sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu)
@@ -672,7 +681,7 @@ def main():
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     os.close(json_fd)
 
-    if world > 1:
+    if dist_mod is not None:
         dist_mod.barrier()
         dist_mod.destroy_process_group()
     ctx.close()

@@ -89,15 +89,17 @@ class GroupedGather(object):
     `storage` is one uint8 tensor of n_groups * group blocks of `rb` bytes (a job's results go into the block
     next_slot() returns); when a group is full its blocks go out in ONE asynchronous all_gather_into_tensor, which
     overlaps the jobs of the next group(s); a group's buffer is reused only after its collective has completed.
-    With world == 1 nothing is communicated and the slots simply rotate."""
+    With world == 1 nothing is communicated and the slots simply rotate -- unless `always` is set (a one-rank process
+    group over the real backend: the collective machinery runs with nobody to talk to)."""
 
-    def __init__(self, storage, rb, world, group, dist_mod=None):
+    def __init__(self, storage, rb, world, group, dist_mod=None, always=False):
         self.storage, self.rb, self.world, self.dist = storage, int(rb), int(world), dist_mod
-        self.G = int(group) if world > 1 else 1
+        self.comm = int(world) > 1 or (bool(always) and dist_mod is not None)
+        self.G = int(group) if self.comm else 1
         self.n_groups = max(1, storage.numel() // (self.rb * self.G))
         self.pending = [None] * self.n_groups
         self.gathered = [None] * self.n_groups
-        if self.world > 1:
+        if self.comm:
             import torch                                     # receive buffers up front: no allocation inside a timed region
             for g in range(self.n_groups):
                 self.gathered[g] = torch.empty(self.world * self.G * self.rb, dtype=torch.uint8, device=storage.device)
@@ -120,7 +122,7 @@ class GroupedGather(object):
 
     def flush(self):
         g, k = self.group, self.filled
-        if self.world > 1 and k:
+        if self.comm and k:
             import torch
             if self.gathered[g] is None:
                 self.gathered[g] = torch.empty(self.world * self.G * self.rb, dtype=torch.uint8, device=self.storage.device)
@@ -139,7 +141,7 @@ class GroupedGather(object):
 
     def last_job_blocks(self):
         """After drain(): uint8 [world, rb], every rank's block of the most recent job (None when world == 1)."""
-        if self.world == 1 or self.last is None:
+        if not self.comm or self.last is None:
             return None
         g, k = self.last
         return self.gathered[g][:self.world * k * self.rb].view(self.world, k, self.rb)[:, k - 1, :]

@@ -91,7 +91,7 @@ def _grouped_worker(rank, world, port, n_jobs, out_dir):
     try:
         rb, G = 48, 4
         storage = torch.zeros(2 * G * rb, dtype=torch.uint8)
-        gg = D.GroupedGather(storage, rb, world, G, dist)
+        gg = D.GroupedGather(storage, rb, world, G, dist, always=world == 1)
         ok = True
         seen = 0
         for job in range(n_jobs):
@@ -126,6 +126,15 @@ def test_grouped_gather_two_ranks_gloo(tmp_path, n_jobs):
     for r in range(2):
         with open(str(tmp_path / ('rank%d' % r))) as f:
             assert f.read() == 'ok'
+
+
+def test_grouped_gather_one_rank_group_still_communicates(tmp_path):
+    """always=True: a process group of ONE rank goes through the collectives all the same (bench.py's DUET_BENCH_RCCL_SELF check
+    of the real backend on a one-GPU box; gloo here)."""
+    port = _free_port()
+    mp.spawn(_grouped_worker, args=(1, port, 9, str(tmp_path)), nprocs=1, join=True)
+    with open(str(tmp_path / 'rank0')) as f:
+        assert f.read() == 'ok'
 
 
 def test_grouped_gather_single_rank_rotates_slots():

@@ -100,3 +100,21 @@ def test_one_rank_over_rccl(tmp_path):
                           {'DUET_FORCE_RANKS': '1'})
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert open(home2 + '/phased_sv.vcf').read() == one
+
+
+def test_bench_sharded_path_as_one_rank_over_rccl():
+    """bench.py's N > 1 code path -- LPT sharding, the asynchronous all_gather_into_tensor per problem on RCCL's stream beside
+    the kernels' raw stream, barriers, the all-reduced per-rank figures, the fused sharded extra -- as ONE rank over backend
+    "nccl" (DUET_BENCH_RCCL_SELF=1; two ranks cannot share this box's GPU under RCCL)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['DUET_BENCH_RCCL_SELF'] = '1'
+    out = subprocess.check_output([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2',
+                                   '--genome-marks', '2000000'], env=env, timeout=900).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['parity_vs_oracle'] is True
+    assert d['topology']['backend'] == 'nccl' and d['topology']['world_size'] == 1 and d['topology']['rccl_version']
+    assert d['gather']['collectives_per_problem'] == 1
+    assert d['extra']['fused_clustered_and_phased_sharded']['parity_rank0_vs_composed_oracles'] is True
