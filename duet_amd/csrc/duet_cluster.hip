@@ -131,10 +131,12 @@ __global__ __launch_bounds__(256) void cl_maxima(const ClParams p, uint32_t *out
 // sort keys, the marks' records -- and, since the keys are at hand, the sort's first digit histogram (what rx_hist would
 // read them back for): one workgroup per radix tile
 __global__ __launch_bounds__(kRxHistThreads) void cl_keys(const ClParams p, uint64_t *keys, uint32_t *vals, uint2 *ps, uint4 *rec4, uint32_t dshift,
-                                                          uint32_t dmask, uint32_t nb, uint32_t *hist /* [256][nb] */, uint32_t *dtot /* or null */)
+                                                          uint32_t dmask, uint32_t nb, uint32_t *hist /* [256][nb] */, uint32_t *dtot /* or null */,
+                                                          uint32_t *zero /* a counter of a later launch */)
 {
     __shared__ uint32_t s_h[256];
     const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) *zero = 0;
     if (tid < 256) s_h[tid] = 0;
     __syncthreads();
 #pragma unroll
@@ -2100,15 +2102,30 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     else p.ps = (const uint2 *)recs;
     const bool big_sort = (ctx->dbg & DUET_DBG_CLUSTER_LARGE) != 0;     // (tests: the tile-offset path of > 4 M keys)
     const bool rx_totals = nb_rx <= kRxTotalsTiles && !big_sort;
-    // (Measured and dropped in round 3: global passes over the top 16 bits only + one launch that orders the groups agreeing in
-    // them by the low bits in LDS -- bit-identical, but the ballot ranking of three LDS passes costs what the passes it
-    // replaces do: sort 91 instead of 88 us at 1 M marks, 1010 instead of 745 us at 2e7; profiles/history/r03_*_REJECTED.txt.)
-    hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs, 0u,
-                       key_bits >= 8u ? 255u : (1u << key_bits) - 1u, nb_rx, hist, rx_totals ? ctx->rx_dtot : (uint32_t *)nullptr);
+    // Small inputs whose keys would take four passes or more: global passes over the top 16 bits only, then the groups of keys
+    // that agree in them -- the marks of one type within 2^(key_bits - 16) centres, a few dozen -- are put in order by their low
+    // bits locally (rx_local: a rank count in LDS; rx_big for a group of more than 256 keys).  8 launches instead of 13.
+    // (The first attempt at this, earlier in round 3, ordered the groups with three ballot-ranked LDS radix passes and cost
+    // what the global passes it replaced did: 91 against 88 us at 1 M marks; on the uneven groups of 2e7 marks over a whole
+    // genome it was slower, 1010 against 745 us, and large inputs keep the plain LSD passes.)
+    const bool small_in = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
+    const bool hybrid = small_in && p.idx_packed && key_bits > 24u && !(ctx->dbg & DUET_DBG_CLUSTER_LSD);
+    const uint32_t top_shift = hybrid ? key_bits - 16u : 0u;
+    uint32_t *big_count = scal + 40, *big_list = valsA;          // (the value buffers are idle when the index rides in the key)
+    hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs, top_shift,
+                       key_bits - top_shift >= 8u ? 255u : (1u << (key_bits - top_shift)) - 1u, nb_rx, hist, rx_totals ? ctx->rx_dtot : (uint32_t *)nullptr,
+                       big_count);
     uint64_t *kin = nullptr, *kout = nullptr;
     uint32_t *vin = nullptr;
-    if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, nullptr, &kout, big_sort, true);
+    if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, nullptr, &kout, big_sort, true, top_shift);
     else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, &vin, &kout, big_sort, true);
+    if (hybrid) {
+        const uint32_t cap = (ctx->dbg & DUET_DBG_CLUSTER_SMALLCAP) ? 3u : (uint32_t)kLocHalo;
+        hipLaunchKernelGGL(rx_local, dim3((M + kLocTile - 1) / kLocTile), dim3(kLocThreads), 0, st, (const uint64_t *)kin, kout, M, top_shift, key_bits, cap,
+                           big_list, big_count);
+        hipLaunchKernelGGL(rx_big, dim3(256), dim3(256), 0, st, kin, kout, M, top_shift, key_bits, (const uint32_t *)big_list, (const uint32_t *)big_count);
+        uint64_t *t = kin; kin = kout; kout = t;
+    }
     p.sorted = vin;
     p.skeys = kin;
     // partitions: one composite scan straight off the sorted keys -> each position's partition id, the partition start

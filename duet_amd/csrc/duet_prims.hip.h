@@ -390,7 +390,8 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
 inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, uint32_t *valsB, uint32_t n, uint32_t key_bits,
                              uint32_t *hist, uint32_t *spart, uint32_t *dtot /* [kDtotCopies][256], zero between sorts */, hipStream_t st,
                              uint64_t **keys_out, uint32_t **vals_out, uint64_t **keys_spare, bool force_scan = false,
-                             bool first_hist_done = false /* the producer of the keys already filled hist (and dtot) for digit 0 */)
+                             bool first_hist_done = false /* the producer of the keys already filled hist (and dtot) for the first digit */,
+                             uint32_t first_shift = 0 /* the passes cover bits [first_shift, key_bits) only */)
 {
     const uint32_t nb_rx = (n + kRxTile - 1) / kRxTile, nh = 256 * nb_rx;
     // up to 1024 tiles (4 M keys) the tile offsets take ONE launch: rx_hist also accumulates the digit totals (atomics, a
@@ -399,9 +400,9 @@ inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, 
     if (nb_rx > kRxTotalsTiles || force_scan) dtot = nullptr;
     uint64_t *kin = keysA, *kout = keysB;
     uint32_t *vin = valsA, *vout = valsB;
-    for (uint32_t shift = 0; shift < key_bits; shift += 8) {
+    for (uint32_t shift = first_shift; shift < key_bits; shift += 8) {
         const uint32_t dmask = key_bits - shift >= 8 ? 255u : (1u << (key_bits - shift)) - 1u;
-        if (shift != 0 || !first_hist_done)
+        if (shift != first_shift || !first_hist_done)
             hipLaunchKernelGGL(rx_hist, dim3(nb_rx), dim3(kRxHistThreads), 0, st, (const uint64_t *)kin, n, shift, dmask, nb_rx, hist, dtot);
         if (dtot) hipLaunchKernelGGL(rx_offsets, dim3(256), dim3(256), 0, st, hist, nb_rx, (const uint32_t *)dtot);
         else launch_scan<0>(LoadPlain{hist}, nh, spart, StorePlain{hist}, nullptr, st, nullptr, force_scan);   // in place: scan_apply reads a tile before writing it
@@ -417,6 +418,238 @@ inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, 
     *keys_out = kin;
     if (vals_out) *vals_out = vin;
     if (keys_spare) *keys_spare = kout;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// the low bits, locally: keys that global passes have ordered by their bits [lo, key_bits) (stably: ties in input order)
+// ---------------------------------------------------------------------------------------------
+//
+// A GROUP is a run of keys that agree in the bits [lo, key_bits).  Small inputs on a genome have small groups (a group is the
+// marks of one type within 2^lo centres): each is put in order by its low bits with a rank count in LDS -- no more passes over
+// the whole array.  rx_local: one workgroup per tile of kLocTile positions takes the groups that START in its tile and hold at
+// most `cap` keys (cap <= kLocHalo: such a group ends inside the tile's window); larger groups go on a list for rx_big.
+// The result is stable (ties keep their order), so the whole sort is.
+constexpr int kLocTile = 2048, kLocHalo = 256, kLocThreads = 1024;
+__global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint64_t *out, uint32_t n, uint32_t lo, uint32_t key_bits, uint32_t cap,
+                                                        uint32_t *big_list, uint32_t *big_count)
+{
+    constexpr int W = kLocTile + kLocHalo, kNone = 0x7FFF;
+    constexpr int kPer = (W + 1 + kLocThreads - 1) / kLocThreads;
+    __shared__ uint64_t s_k[W + 1];                        // the window and the key behind it
+    __shared__ uint32_t s_low[W + 4];                      // the keys' low bits (lo < 32 for every input this path takes)
+    __shared__ int16_t s_gs[W + 1];                        // start of the position's group inside the window (-1: it starts before the window)
+    __shared__ int16_t s_ge[W + 1];                        // end of the position's group (first position behind it; kNone: beyond the window)
+    __shared__ int s_carry[2][kLocThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t0 = blockIdx.x * kLocTile;
+    const uint64_t kmask = key_bits >= 64u ? ~0ull : (1ull << key_bits) - 1ull;
+    const uint32_t lmask = (1u << lo) - 1u;
+    for (uint32_t i = tid; i <= W; i += kLocThreads) {
+        const uint64_t k = t0 + i < n ? in[t0 + i] : 0ull;
+        s_k[i] = k;
+        s_low[i] = (uint32_t)k & lmask;
+    }
+    const uint64_t before = t0 ? in[t0 - 1u] : 0ull;
+    __syncthreads();
+    // group starts: a running maximum of (head ? position : -1) over the window; ends: a running minimum from the right of
+    // (head or behind the last key ? position : kNone) over the positions behind each one.  kPer positions per thread
+    bool head[kPer];
+    int mine[kPer];
+    int run = -1;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t i = tid * kPer + j;
+        head[j] = false;
+        if (i <= (uint32_t)W) {
+            if (t0 + i >= n) head[j] = true;               // (the end of the keys closes the last group)
+            else {
+                const uint64_t prev = i ? s_k[i - 1] : before;
+                head[j] = t0 + i == 0u || ((s_k[i] & kmask) >> lo) != ((prev & kmask) >> lo);
+            }
+        }
+        run = head[j] ? (int)i : run;
+        mine[j] = run;
+    }
+    int x = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x = max(x, y);
+    }
+    if (lane == 63) s_carry[0][wave] = x;
+    // from the right: what this thread's positions see behind them
+    int back[kPer];
+    int rrun = kNone;
+#pragma unroll
+    for (int j = kPer - 1; j >= 0; --j) {
+        const uint32_t i = tid * kPer + j;
+        back[j] = rrun;                                    // (the nearest head strictly behind position i, within this thread's positions)
+        rrun = (i <= (uint32_t)W && head[j]) ? (int)i : rrun;
+    }
+    int z = rrun;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_down(z, d, 64);
+        if ((int)lane + d < 64) z = min(z, y);
+    }
+    if (lane == 0) s_carry[1][wave] = z;
+    __syncthreads();
+    int carry = -1, rcarry = kNone;
+    for (uint32_t w = 0; w < wave; ++w) carry = max(carry, s_carry[0][w]);
+    for (uint32_t w = wave + 1; w < kLocThreads / 64; ++w) rcarry = min(rcarry, s_carry[1][w]);
+    const int px = __shfl_up(x, 1, 64), nz = __shfl_down(z, 1, 64);
+    if (lane > 0) carry = max(carry, px);
+    if (lane < 63) rcarry = min(rcarry, nz);
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t i = tid * kPer + j;
+        if (i <= (uint32_t)W) {
+            s_gs[i] = (int16_t)max(mine[j], carry);
+            s_ge[i] = (int16_t)min(back[j], rcarry);
+        }
+    }
+    __syncthreads();
+    // the groups that start in the tile and hold more than cap keys go on the list (their first keys report them)
+    for (uint32_t i = tid; i < (uint32_t)kLocTile; i += kLocThreads)
+        if (t0 + i < n && s_gs[i] == (int)i && (uint32_t)(s_ge[i] - (int)i) > cap) big_list[atomicAdd(big_count, 1u)] = t0 + i;
+    // every key of a group this tile owns: its rank by the low bits, ties in input order (four keys of the group per step)
+    for (uint32_t i = tid; i < (uint32_t)W; i += kLocThreads) {
+        const int gs = s_gs[i];
+        if (t0 + i >= n || gs < 0 || gs >= kLocTile) continue;
+        const uint32_t len = (uint32_t)(s_ge[gs] - gs);
+        if (len > cap) continue;
+        const uint32_t me = s_low[i];
+        uint32_t rank = 0;
+        for (uint32_t j = (uint32_t)gs; j < (uint32_t)gs + len; j += 4) {
+            const uint32_t o0 = s_low[j], o1 = s_low[j + 1], o2 = s_low[j + 2], o3 = s_low[j + 3];
+            const uint32_t e = (uint32_t)gs + len;        // (bitwise on purpose: no branch per key)
+            rank += (uint32_t)((o0 < me) | ((o0 == me) & (j < i)));
+            rank += (uint32_t)((j + 1 < e) & ((o1 < me) | ((o1 == me) & (j + 1 < i))));
+            rank += (uint32_t)((j + 2 < e) & ((o2 < me) | ((o2 == me) & (j + 2 < i))));
+            rank += (uint32_t)((j + 3 < e) & ((o3 < me) | ((o3 == me) & (j + 3 < i))));
+        }
+        out[t0 + (uint32_t)gs + rank] = s_k[i];
+    }
+}
+
+// The groups of more than cap keys: one workgroup per group.  Up to kBigLds keys: loaded into LDS and ranked there like rx_local
+// does; beyond that stable LSD passes over the low bits within the group's own range of the two buffers (256 keys at a time:
+// ballot match inside a wave, the waves' counts side by side).  Rare on a genome; slow but sure when a locus piles up (2 us per
+// 256 keys and pass).  a: the keys as the global passes left them (the groups' ranges of b are nobody else's); the result
+// ends in b.
+constexpr int kBigLds = 1024;
+__global__ __launch_bounds__(256) void rx_big(uint64_t *a, uint64_t *b, uint32_t n, uint32_t lo, uint32_t key_bits, const uint32_t *big_list,
+                                              const uint32_t *big_count)
+{
+    __shared__ uint64_t s_k[kBigLds];
+    __shared__ uint32_t s_low[kBigLds + 4];
+    __shared__ uint32_t s_base[256];                       // where the next key of each digit goes
+    __shared__ uint32_t s_wcnt[4][256];
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_end;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t kmask = key_bits >= 64u ? ~0ull : (1ull << key_bits) - 1ull;
+    const uint32_t lmask = (1u << lo) - 1u;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t count = *big_count;
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t gs = big_list[e];
+        __syncthreads();
+        if (tid == 0) s_end = 0xFFFFFFFFu;
+        __syncthreads();
+        // the group's first kBigLds keys (and the one behind them) in one round of loads: most groups end among them
+        uint64_t g = 0;
+        {
+            const uint64_t first = a[gs];
+            g = (first & kmask) >> lo;
+            for (uint32_t i = tid; i <= (uint32_t)kBigLds; i += 256u) {
+                const uint32_t pos = gs + i;
+                const uint64_t k = pos < n ? a[pos] : 0ull;
+                const bool in = pos < n && ((k & kmask) >> lo) == g;
+                if (i < (uint32_t)kBigLds) { s_k[i] = k; s_low[i] = (uint32_t)k & lmask; }
+                if (!in) atomicMin(&s_end, i);              // (group numbers do not decrease along a: the first "no" ends the group)
+            }
+        }
+        __syncthreads();
+        const uint32_t len_lds = s_end;
+        if (len_lds <= (uint32_t)kBigLds) {
+            for (uint32_t i = tid; i < len_lds; i += 256u) {
+                const uint32_t me = s_low[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < len_lds; j += 4) {
+                    const uint32_t o0 = s_low[j], o1 = s_low[j + 1], o2 = s_low[j + 2], o3 = s_low[j + 3];
+                    rank += (uint32_t)((o0 < me) | ((o0 == me) & (j < i)));
+                    rank += (uint32_t)((j + 1 < len_lds) & ((o1 < me) | ((o1 == me) & (j + 1 < i))));
+                    rank += (uint32_t)((j + 2 < len_lds) & ((o2 < me) | ((o2 == me) & (j + 2 < i))));
+                    rank += (uint32_t)((j + 3 < len_lds) & ((o3 < me) | ((o3 == me) & (j + 3 < i))));
+                }
+                b[gs + rank] = s_k[i];
+            }
+            continue;
+        }
+        uint32_t lo_i = gs + (uint32_t)kBigLds, hi_i = n;  // first position behind the group, by bisection
+        while (hi_i - lo_i > 1u) {
+            const uint32_t mid = lo_i + ((hi_i - lo_i) >> 1);
+            if (((a[mid] & kmask) >> lo) == g) lo_i = mid; else hi_i = mid;
+        }
+        const uint32_t ge = hi_i;
+        uint64_t *src = a, *dst = b;
+        for (uint32_t shift = 0; shift < lo; shift += 8) {
+            const uint32_t dmask = lo - shift >= 8u ? 255u : (1u << (lo - shift)) - 1u;
+            __syncthreads();
+            s_base[tid] = 0;
+            __syncthreads();
+            for (uint32_t i = gs + tid; i < ge; i += 256u) atomicAdd(&s_base[(uint32_t)(src[i] >> shift) & dmask], 1u);
+            __syncthreads();
+            {   // exclusive scan of the 256 digit counts
+                const uint32_t c = s_base[tid];
+                uint32_t x = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(x, d, 64);
+                    if ((int)lane >= d) x += y;
+                }
+                if (lane == 63) s_scan[wave] = x;
+                __syncthreads();
+                uint32_t carry = 0;
+                for (uint32_t w = 0; w < wave; ++w) carry += s_scan[w];
+                s_base[tid] = gs + carry + x - c;
+            }
+            for (uint32_t c0 = gs; c0 < ge; c0 += 256u) {
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s_wcnt[w][tid] = 0;
+                __syncthreads();
+                const uint32_t i = c0 + tid;
+                const bool valid = i < ge;
+                const uint64_t k = valid ? src[i] : 0ull;
+                const uint32_t d = (uint32_t)(k >> shift) & dmask;
+                unsigned long long same = __ballot(valid);
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) {
+                    const bool on = (d >> bit) & 1u;
+                    const unsigned long long bm = __ballot(on);
+                    same &= on ? bm : ~bm;
+                }
+                const uint32_t rank = (uint32_t)__popcll(same & lt);
+                if (valid && rank == 0) s_wcnt[wave][d] = (uint32_t)__popcll(same);
+                __syncthreads();
+                if (valid) {
+                    uint32_t at = s_base[d] + rank;
+                    for (uint32_t w = 0; w < wave; ++w) at += s_wcnt[w][d];
+                    dst[at] = k;
+                }
+                __syncthreads();
+                s_base[tid] += s_wcnt[0][tid] + s_wcnt[1][tid] + s_wcnt[2][tid] + s_wcnt[3][tid];
+            }
+            __syncthreads();
+            uint64_t *t = src; src = dst; dst = t;
+        }
+        if (src == a) {                                    // an even number of passes left the result in a
+            __threadfence_block();
+            for (uint32_t i = gs + tid; i < ge; i += 256u) b[i] = a[i];
+        }
+    }
 }
 
 #endif

@@ -26,9 +26,11 @@ def check(ctx, marks, **kw):
     # ... the launch structure of large inputs (DUET_DBG_CLUSTER_LARGE = 0x200), the pair sort (DUET_DBG_CLUSTER_PAIRS = 0x400),
     # no bounding-box test (DUET_DBG_CLUSTER_NOBOX = 0x800: every partition through the threshold-graph pair loops);
     # DUET_DBG_CLUSTER_KC2 = 0x1000: partitions with more than two groups left take the second tier;
-    # DUET_DBG_CLUSTER_TIERS = 0x2000: the two tiers in their fused (small-input) launches
+    # DUET_DBG_CLUSTER_TIERS = 0x2000: the two tiers in their fused (small-input) launches; DUET_DBG_CLUSTER_SMALLCAP = 0x4000 /
+    # DUET_DBG_CLUSTER_LSD = 0x8000: where the low bits are sorted locally, groups of more than 3 keys through the
+    # one-workgroup-per-group path / plain LSD passes instead
     for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600), (True, 0x800),
-                       (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800)):
+                       (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800), (True, 0x4000), (False, 0x8000)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
@@ -84,6 +86,19 @@ def test_sv_like_marks(ctx, seed):
 def test_random_marks(ctx, seed):
     marks = random_marks(seed, 3000 + 700 * seed)
     check(ctx, marks, max_dist=[0.3, 0.5, 0.9, 1.4, 0.9, 0.05][seed])
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_genome_sized_coordinates(ctx, seed):
+    """Positions around 2e8 (28-bit centres: keys of 30+ bits): small inputs then sort the top 16 key bits globally and the low
+    bits locally -- sparse data through the rank count in LDS (rx_local), dense clumps through the per-group passes (rx_big)
+    -- each case also with groups cut at 3 keys and with plain LSD passes (check()'s debug combinations)."""
+    if seed % 2:
+        marks = sv_like_marks(40 + seed, 1200 + 300 * seed)
+    else:
+        marks = random_marks(40 + seed, 6000 + 2500 * seed, clumps=50 + 400 * seed, contigs=1 + seed % 3, types=2)
+    marks = dict(marks, pos=(marks['pos'].astype(np.uint64) + 200000000 + 7777 * seed).astype(np.uint32))
+    check(ctx, marks, max_dist=[0.9, 0.5, 0.3, 0.9, 1.2, 0.7][seed])
 
 
 def test_edge_sizes(ctx):
