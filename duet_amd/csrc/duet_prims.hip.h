@@ -437,17 +437,21 @@ __global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint
     constexpr int W = kLocTile + kLocHalo, kNone = 0x7FFF;
     constexpr int kPer = (W + 1 + kLocThreads - 1) / kLocThreads;
     __shared__ uint64_t s_k[W + 1];                        // the window and the key behind it
-    __shared__ uint32_t s_low[W + 4];                      // the keys' low bits (lo < 32 for every input this path takes)
+    __shared__ uint32_t s_low[W + 4];                      // the keys' low bits (lo < 32 for every input this path takes), see below
     __shared__ int16_t s_gs[W + 1];                        // start of the position's group inside the window (-1: it starts before the window)
     __shared__ int16_t s_ge[W + 1];                        // end of the position's group (first position behind it; kNone: beyond the window)
     __shared__ int s_carry[2][kLocThreads / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t0 = blockIdx.x * kLocTile;
     const uint64_t kmask = key_bits >= 64u ? ~0ull : (1ull << key_bits) - 1ull;
     const uint32_t lmask = (1u << lo) - 1u;
+    // (up to 20 low bits: a key's low bits and its place in the window make ONE 32-bit number, distinct for every key -- the
+    // rank is a count of smaller numbers, one compare per key; beyond, low bits and place are compared separately)
+    const bool packed = lo <= 20u;
     for (uint32_t i = tid; i <= W; i += kLocThreads) {
         const uint64_t k = t0 + i < n ? in[t0 + i] : 0ull;
         s_k[i] = k;
-        s_low[i] = (uint32_t)k & lmask;
+        const uint32_t low = (uint32_t)k & lmask;
+        s_low[i] = packed ? (low << 12) | i : low;
     }
     const uint64_t before = t0 ? in[t0 - 1u] : 0ull;
     __syncthreads();
@@ -518,15 +522,17 @@ __global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint
         if (t0 + i >= n || gs < 0 || gs >= kLocTile) continue;
         const uint32_t len = (uint32_t)(s_ge[gs] - gs);
         if (len > cap) continue;
-        const uint32_t me = s_low[i];
-        uint32_t rank = 0;
-        for (uint32_t j = (uint32_t)gs; j < (uint32_t)gs + len; j += 4) {
-            const uint32_t o0 = s_low[j], o1 = s_low[j + 1], o2 = s_low[j + 2], o3 = s_low[j + 3];
-            const uint32_t e = (uint32_t)gs + len;        // (bitwise on purpose: no branch per key)
-            rank += (uint32_t)((o0 < me) | ((o0 == me) & (j < i)));
-            rank += (uint32_t)((j + 1 < e) & ((o1 < me) | ((o1 == me) & (j + 1 < i))));
-            rank += (uint32_t)((j + 2 < e) & ((o2 < me) | ((o2 == me) & (j + 2 < i))));
-            rank += (uint32_t)((j + 3 < e) & ((o3 < me) | ((o3 == me) & (j + 3 < i))));
+        const uint32_t me = s_low[i], e = (uint32_t)gs + len;
+        uint32_t rank = 0, j = (uint32_t)gs;
+        if (packed) {
+            for (const uint32_t e4 = (uint32_t)gs + (len & ~3u); j < e4; j += 4)
+                rank += (uint32_t)(s_low[j] < me) + (uint32_t)(s_low[j + 1] < me) + (uint32_t)(s_low[j + 2] < me) + (uint32_t)(s_low[j + 3] < me);
+            for (; j < e; ++j) rank += (uint32_t)(s_low[j] < me);
+        } else {
+            for (; j < e; ++j) {
+                const uint32_t o = s_low[j];
+                rank += (uint32_t)((o < me) | ((o == me) & (j < i)));    // (bitwise on purpose: no branch per key)
+            }
         }
         out[t0 + (uint32_t)gs + rank] = s_k[i];
     }

@@ -101,6 +101,14 @@ def test_genome_sized_coordinates(ctx, seed):
     check(ctx, marks, max_dist=[0.9, 0.5, 0.3, 0.9, 1.2, 0.7][seed])
 
 
+def test_genome_sized_coordinates_edge_sizes(ctx):
+    """... around the local sort's tile (2048 positions) and halo (256): groups that start in one tile and end in the next."""
+    for M in (1, 2, 3, 255, 2047, 2048, 2049, 2303, 2304, 2305, 4097, 6144):
+        marks = random_marks(500 + M, M, clumps=2 + M % 5, contigs=1, types=1 + M % 2, spread=900)
+        marks = dict(marks, pos=(marks['pos'].astype(np.uint64) + 230000000).astype(np.uint32))
+        check(ctx, marks)
+
+
 def test_edge_sizes(ctx):
     for M in (1, 2, 3, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097):
         check(ctx, random_marks(M, M, clumps=3))
