@@ -2109,8 +2109,11 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // what the global passes it replaced did: 91 against 88 us at 1 M marks; on the uneven groups of 2e7 marks over a whole
     // genome it was slower, 1010 against 745 us, and large inputs keep the plain LSD passes.)
     const bool small_in = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
-    const bool hybrid = small_in && p.idx_packed && key_bits > 24u && !(ctx->dbg & DUET_DBG_CLUSTER_LSD);
-    const uint32_t top_shift = hybrid ? key_bits - 16u : 0u;
+    // (the global passes take the top 16 bits of a small input's keys, the top 24 of a large one's: groups of a few keys to a
+    // few dozen either way on a genome; used where that saves two passes or more)
+    const uint32_t top_bits = small_in ? 16u : 24u;
+    const bool hybrid = p.idx_packed && (key_bits + 7u) / 8u >= top_bits / 8u + 2u && !(ctx->dbg & DUET_DBG_CLUSTER_LSD);
+    const uint32_t top_shift = hybrid ? key_bits - top_bits : 0u;
     uint32_t *big_count = scal + 40, *big_list = valsA;          // (the value buffers are idle when the index rides in the key)
     hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs, top_shift,
                        key_bits - top_shift >= 8u ? 255u : (1u << (key_bits - top_shift)) - 1u, nb_rx, hist, rx_totals ? ctx->rx_dtot : (uint32_t *)nullptr,
@@ -2121,8 +2124,12 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, &vin, &kout, big_sort, true);
     if (hybrid) {
         const uint32_t cap = (ctx->dbg & DUET_DBG_CLUSTER_SMALLCAP) ? 3u : (uint32_t)kLocHalo;
-        hipLaunchKernelGGL(rx_local, dim3((M + kLocTile - 1) / kLocTile), dim3(kLocThreads), 0, st, (const uint64_t *)kin, kout, M, top_shift, key_bits, cap,
-                           big_list, big_count);
+        if (small_in)
+            hipLaunchKernelGGL(rx_local<1024>, dim3((M + kLocTile - 1) / kLocTile), dim3(1024), 0, st, (const uint64_t *)kin, kout, M, top_shift, key_bits, cap,
+                               big_list, big_count);
+        else
+            hipLaunchKernelGGL(rx_local<256>, dim3((M + kLocTile - 1) / kLocTile), dim3(256), 0, st, (const uint64_t *)kin, kout, M, top_shift, key_bits, cap,
+                               big_list, big_count);
         hipLaunchKernelGGL(rx_big, dim3(256), dim3(256), 0, st, kin, kout, M, top_shift, key_bits, (const uint32_t *)big_list, (const uint32_t *)big_count);
         uint64_t *t = kin; kin = kout; kout = t;
     }

@@ -430,47 +430,55 @@ inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, 
 // the whole array.  rx_local: one workgroup per tile of kLocTile positions takes the groups that START in its tile and hold at
 // most `cap` keys (cap <= kLocHalo: such a group ends inside the tile's window); larger groups go on a list for rx_big.
 // The result is stable (ties keep their order), so the whole sort is.
-constexpr int kLocTile = 2048, kLocHalo = 256, kLocThreads = 1024;
-__global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint64_t *out, uint32_t n, uint32_t lo, uint32_t key_bits, uint32_t cap,
-                                                        uint32_t *big_list, uint32_t *big_count)
+constexpr int kLocTile = 2048, kLocHalo = 256;
+template <int THREADS>                                     // 1024 for small inputs (a tile's latency counts), 256 for large ones (more tiles in flight)
+__global__ __launch_bounds__(THREADS) void rx_local(const uint64_t *in, uint64_t *out, uint32_t n, uint32_t lo, uint32_t key_bits, uint32_t cap,
+                                                    uint32_t *big_list, uint32_t *big_count)
 {
     constexpr int W = kLocTile + kLocHalo, kNone = 0x7FFF;
-    constexpr int kPer = (W + 1 + kLocThreads - 1) / kLocThreads;
-    __shared__ uint64_t s_k[W + 1];                        // the window and the key behind it
+    constexpr int kIter = (W + 1 + THREADS - 1) / THREADS;  // keys per thread (position tid + it * THREADS: it keeps them in registers)
+    constexpr int kPer = kIter;                            // positions per thread in the scans (tid * kPer + j)
     __shared__ uint32_t s_low[W + 4];                      // the keys' low bits (lo < 32 for every input this path takes), see below
+    __shared__ uint8_t s_head[W + 1];                      // the position starts a group (or lies behind the last key)
     __shared__ int16_t s_gs[W + 1];                        // start of the position's group inside the window (-1: it starts before the window)
     __shared__ int16_t s_ge[W + 1];                        // end of the position's group (first position behind it; kNone: beyond the window)
-    __shared__ int s_carry[2][kLocThreads / 64];
+    __shared__ int s_carry[2][THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t0 = blockIdx.x * kLocTile;
     const uint64_t kmask = key_bits >= 64u ? ~0ull : (1ull << key_bits) - 1ull;
     const uint32_t lmask = (1u << lo) - 1u;
     // (up to 20 low bits: a key's low bits and its place in the window make ONE 32-bit number, distinct for every key -- the
     // rank is a count of smaller numbers, one compare per key; beyond, low bits and place are compared separately)
     const bool packed = lo <= 20u;
-    for (uint32_t i = tid; i <= W; i += kLocThreads) {
-        const uint64_t k = t0 + i < n ? in[t0 + i] : 0ull;
-        s_k[i] = k;
-        const uint32_t low = (uint32_t)k & lmask;
-        s_low[i] = packed ? (low << 12) | i : low;
+    uint64_t key[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const uint32_t i = tid + it * THREADS;
+        key[it] = (i <= (uint32_t)W && t0 + i < n) ? in[t0 + i] : 0ull;
     }
-    const uint64_t before = t0 ? in[t0 - 1u] : 0ull;
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const uint32_t i = tid + it * THREADS;
+        const bool live = i <= (uint32_t)W && t0 + i < n;
+        const uint64_t g = (key[it] & kmask) >> lo;
+        // the group number of the position in front: the lane in front holds it, lane 0 fetches it
+        uint64_t pg = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(g >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)g, 1, 64);
+        if (lane == 0 && live && t0 + i > 0u) pg = (in[t0 + i - 1u] & kmask) >> lo;
+        if (i <= (uint32_t)W) {
+            s_head[i] = (!live || t0 + i == 0u || g != pg) ? 1 : 0;      // (the end of the keys closes the last group)
+            const uint32_t low = (uint32_t)key[it] & lmask;
+            s_low[i] = packed ? (low << 12) | i : low;
+        }
+    }
     __syncthreads();
     // group starts: a running maximum of (head ? position : -1) over the window; ends: a running minimum from the right of
-    // (head or behind the last key ? position : kNone) over the positions behind each one.  kPer positions per thread
+    // (head ? position : kNone) over the positions behind each one.  kPer consecutive positions per thread
     bool head[kPer];
     int mine[kPer];
     int run = -1;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const uint32_t i = tid * kPer + j;
-        head[j] = false;
-        if (i <= (uint32_t)W) {
-            if (t0 + i >= n) head[j] = true;               // (the end of the keys closes the last group)
-            else {
-                const uint64_t prev = i ? s_k[i - 1] : before;
-                head[j] = t0 + i == 0u || ((s_k[i] & kmask) >> lo) != ((prev & kmask) >> lo);
-            }
-        }
+        head[j] = i <= (uint32_t)W && s_head[i] != 0;
         run = head[j] ? (int)i : run;
         mine[j] = run;
     }
@@ -481,14 +489,13 @@ __global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint
         if ((int)lane >= d) x = max(x, y);
     }
     if (lane == 63) s_carry[0][wave] = x;
-    // from the right: what this thread's positions see behind them
     int back[kPer];
     int rrun = kNone;
 #pragma unroll
     for (int j = kPer - 1; j >= 0; --j) {
         const uint32_t i = tid * kPer + j;
         back[j] = rrun;                                    // (the nearest head strictly behind position i, within this thread's positions)
-        rrun = (i <= (uint32_t)W && head[j]) ? (int)i : rrun;
+        rrun = head[j] ? (int)i : rrun;
     }
     int z = rrun;
 #pragma unroll
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint
     __syncthreads();
     int carry = -1, rcarry = kNone;
     for (uint32_t w = 0; w < wave; ++w) carry = max(carry, s_carry[0][w]);
-    for (uint32_t w = wave + 1; w < kLocThreads / 64; ++w) rcarry = min(rcarry, s_carry[1][w]);
+    for (uint32_t w = wave + 1; w < (uint32_t)(THREADS / 64); ++w) rcarry = min(rcarry, s_carry[1][w]);
     const int px = __shfl_up(x, 1, 64), nz = __shfl_down(z, 1, 64);
     if (lane > 0) carry = max(carry, px);
     if (lane < 63) rcarry = min(rcarry, nz);
@@ -514,12 +521,15 @@ __global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint
     }
     __syncthreads();
     // the groups that start in the tile and hold more than cap keys go on the list (their first keys report them)
-    for (uint32_t i = tid; i < (uint32_t)kLocTile; i += kLocThreads)
+    for (uint32_t i = tid; i < (uint32_t)kLocTile; i += THREADS)
         if (t0 + i < n && s_gs[i] == (int)i && (uint32_t)(s_ge[i] - (int)i) > cap) big_list[atomicAdd(big_count, 1u)] = t0 + i;
-    // every key of a group this tile owns: its rank by the low bits, ties in input order (four keys of the group per step)
-    for (uint32_t i = tid; i < (uint32_t)W; i += kLocThreads) {
+    // every key of a group this tile owns: its rank by the low bits, ties in input order
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const uint32_t i = tid + it * THREADS;
+        if (i >= (uint32_t)W || t0 + i >= n) continue;
         const int gs = s_gs[i];
-        if (t0 + i >= n || gs < 0 || gs >= kLocTile) continue;
+        if (gs < 0 || gs >= kLocTile) continue;
         const uint32_t len = (uint32_t)(s_ge[gs] - gs);
         if (len > cap) continue;
         const uint32_t me = s_low[i], e = (uint32_t)gs + len;
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(kLocThreads) void rx_local(const uint64_t *in, uint
                 rank += (uint32_t)((o < me) | ((o == me) & (j < i)));    // (bitwise on purpose: no branch per key)
             }
         }
-        out[t0 + (uint32_t)gs + rank] = s_k[i];
+        out[t0 + (uint32_t)gs + rank] = key[it];
     }
 }
 
