@@ -66,6 +66,7 @@ constexpr uint32_t kSortLds = 15360;              // seeds sorted in LDS (60 KiB
 constexpr uint32_t kLongCnt = 16;                   // ... when they hold more entries than this
 constexpr uint32_t kLongTiles = 256;                // ef_seed_sort: tiles whose entries are copied by the whole workgroup
 constexpr uint32_t kMaxRuns = 32;                  // ef_seed_sort merges up to this many ascending runs by rank
+constexpr uint32_t kSeedTab = 4096;                // ef_seed_sort: slots of the hash set an unsorted seed list goes through first
 constexpr uint32_t kFewRuns = 4;                   // ... right away when it finds no more descents than this
 constexpr uint32_t kOneLds = 4096;                // seed array staged in LDS by ef_finalize (16 KiB)
 constexpr uint32_t kC2Quota = 64;                 // group-summary slots of a classify tile's own; a tile with more multi-PS candidates reserves the rest from
@@ -616,6 +617,8 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     __shared__ uint32_t s_unsorted;
     __shared__ uint32_t s_nruns, s_run[kMaxRuns + 1];
     __shared__ uint32_t s_nlong, s_long[kLongTiles][2];
+    __shared__ uint32_t s_tab[kSeedTab];                  // the distinct seeds of an unsorted list (open addressing)
+    __shared__ uint32_t s_ndist;
     const uint32_t k = blockIdx.x, tid = threadIdx.x;
     STAMP(1, 0);
     const uint32_t c_lo = p.n_small ? p.ctg_small[k] : p.ctg_off[k];
@@ -787,6 +790,54 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
         // network.  (Six rounds before looking at the runs again cost the fused pipeline 12 of its 31 us here -- the long runs
         // never go away --, and merging 20 short runs by rank costs a position-sorted VCF 10 us where two rounds cost 1.)
         bool todo = unsorted;
+        if (todo && n >= 256u && !(p.dbg & 0x40u)) {
+            // An unsorted list is unsorted because of the ORDER of the candidates (stage A0 emits them by type, then position;
+            // a caller's VCF may not be position-sorted), not because there are many different seeds: a contig has a few
+            // hundred phase sets.  The distinct values through a hash set, then those few are ranked -- instead of ordering
+            // all n entries.  More than kSeedTab / 2 distinct seeds, or a probe sequence of more than 32: the paths below.
+            for (uint32_t i = tid; i < kSeedTab; i += kSortThreads) s_tab[i] = kEmpty;
+            if (tid == 0) { s_ndist = 0; s_unsorted = 0; }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += kSortThreads) {
+                const uint32_t key = s_key[i];                 // (a PS is at most 2^32 - 2: kEmpty is free)
+                uint32_t h = (key * 2654435761u) >> 20, probes = 0;
+                for (;;) {
+                    const uint32_t old = atomicCAS(&s_tab[h], kEmpty, key);
+                    if (old == kEmpty) { atomicAdd(&s_ndist, 1u); break; }
+                    if (old == key) break;
+                    h = (h + 1u) & (kSeedTab - 1u);
+                    if (++probes > 32u) { s_unsorted = 1; break; }
+                }
+            }
+            __syncthreads();
+            const uint32_t u = s_ndist;
+            if (s_unsorted == 0 && u <= kSeedTab / 2u) {
+                // compact the set (four slots per thread), rank the values, store them in order
+                uint32_t mine[kSeedTab / kSortThreads], cnt = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kSeedTab / kSortThreads; ++j) {
+                    mine[j] = s_tab[tid * (kSeedTab / kSortThreads) + j];
+                    cnt += mine[j] != kEmpty ? 1u : 0u;
+                }
+                uint32_t total;
+                uint32_t at = block_exscan(cnt, tid, s_part, kSortThreads, &total);
+                __syncthreads();                               // (everybody has read s_key and the table)
+#pragma unroll
+                for (uint32_t j = 0; j < kSeedTab / kSortThreads; ++j)
+                    if (mine[j] != kEmpty) s_key[at++] = mine[j];
+                __syncthreads();
+                for (uint32_t i = tid; i < u; i += kSortThreads) {
+                    const uint32_t me = s_key[i];
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < u; ++j) rank += s_key[j] < me ? 1u : 0u;
+                    glist[rank] = me;
+                }
+                if (tid == 0) { p.n_one[k] = u; region[0] = u; }
+                STAMP(1, 3);
+                return;
+            }
+            __syncthreads();
+        }
         auto count_runs = [&]() {
             __syncthreads();
             if (tid == 0) s_nruns = 0;

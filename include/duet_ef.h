@@ -136,6 +136,7 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 /* Diagnostics: low bits ablate E/F kernel phases (tools/ablate.py); DUET_DBG_CLUSTER_EXACT sends every A0
  * partition through the exact linkage instead of the bounding-box / threshold-graph fast paths (the outputs are
  * identical; tests use it to exercise both).  0 in production. */
+#define DUET_DBG_EF_NO_SEED_HASH 0x40u   /* E/F: ef_seed_sort orders an unsorted seed list itself instead of taking its distinct values through a hash set first */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */

@@ -112,6 +112,25 @@ def test_fuzz_soa(ctx, seed):
     check_against_c_oracle(ctx, soa, 52, 4)
 
 
+@pytest.mark.parametrize('n_ps', [3, 40, 700, 1900, 2300, 6000])
+def test_unsorted_candidates_seed_set_paths(ctx, n_ps):
+    """Candidates NOT in position order with n_ps phase sets per contig: the seed list arrives unsorted.  Few distinct seeds go
+    through ef_seed_sort's hash set (up to 2048 of them), more through the run merges / the bitonic network; each case also with
+    the hash set switched off (debug bit 0x40) -- the seed sets (and everything decided from them) are the same."""
+    soa = soa_fuzz.random_soa(900 + n_ps, n_contigs=2, cands_per_contig=(9000, 14000), reads_per_contig=(4000, 6000),
+                              n_ps=(n_ps, n_ps), ps_spread=3000000, deg=(1, 6), empty_contig_rate=0, no_seed_contig_rate=0,
+                              sorted_pos=False)
+    check_against_c_oracle(ctx, soa)
+    seeds = [ctx.seed_ps(k).copy() for k in range(2)]
+    ctx.set_debug(0x40)
+    try:
+        check_against_c_oracle(ctx, soa)
+        for k in range(2):
+            assert np.array_equal(ctx.seed_ps(k), seeds[k]) and np.all(seeds[k][1:] > seeds[k][:-1])
+    finally:
+        ctx.set_debug(0)
+
+
 def test_multi_ps_heavy(ctx):
     """Most candidates see several phase sets (more than the 4 groups a summary holds, and more
     multi-PS candidates per workgroup than summary slots): exercises both ef_finalize paths."""
