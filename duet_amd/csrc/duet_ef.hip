@@ -783,16 +783,32 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     if (n == 0) {
         n_one = 0;
     } else if (n <= kSortLds) {
-        // A few long ascending runs (candidates ordered by type, then position -- stage A0's order -- give one run per type) are
-        // merged by rank right away.  More descents than that are the local disorder of position-ordered candidates (neighbours
-        // that straddle a phase-set boundary): one or two odd-even rounds remove it (the rounds stop as soon as nothing moves);
-        // what is left then is sorted, or a few long runs again, or -- after four more rounds -- real disorder for the bitonic
-        // network.  (Six rounds before looking at the runs again cost the fused pipeline 12 of its 31 us here -- the long runs
-        // never go away --, and merging 20 short runs by rank costs a position-sorted VCF 10 us where two rounds cost 1.)
+        // Many descents are usually the local disorder of position-ordered candidates (neighbours that straddle a phase-set
+        // boundary): one or two odd-even rounds remove it (the rounds stop as soon as nothing moves).  What is unsorted after
+        // that -- long runs: candidates ordered by type, then position (stage A0's order) give one run per type; or real
+        // disorder -- goes through a hash set when its distinct values are few (below), else: a few long runs are merged by
+        // rank, after four more rounds the rest takes the bitonic network.  (Six rounds before looking at the runs again cost
+        // the fused pipeline 12 of its 31 us here -- the long runs never go away --, and merging 20 short runs by rank costs a
+        // position-sorted VCF 10 us where two rounds cost 1.)
         bool todo = unsorted;
+        auto count_runs = [&]() {
+            __syncthreads();
+            if (tid == 0) s_nruns = 0;
+            __syncthreads();
+            for (uint32_t i = tid + 1; i < n; i += kSortThreads)
+                if (s_key[i] < s_key[i - 1]) {
+                    const uint32_t r = atomicAdd(&s_nruns, 1u);
+                    if (r < kMaxRuns) s_run[r] = i;
+                }
+            __syncthreads();
+        };
+        if (todo && s_nruns > kFewRuns) {
+            todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 2);
+            if (todo) count_runs();
+        }
         if (todo && n >= 256u && !(p.dbg & 0x40u)) {
-            // An unsorted list is unsorted because of the ORDER of the candidates (stage A0 emits them by type, then position;
-            // a caller's VCF may not be position-sorted), not because there are many different seeds: a contig has a few
+            // What two odd-even rounds did not fix is unsorted because of the ORDER of the candidates (stage A0 emits them by type,
+            // then position; a caller's VCF may not be position-sorted), not because there are many different seeds: a contig has a few
             // hundred phase sets.  The distinct values through a hash set, then those few are ranked -- instead of ordering
             // all n entries.  More than kSeedTab / 2 distinct seeds, or a probe sequence of more than 32: the paths below.
             for (uint32_t i = tid; i < kSeedTab; i += kSortThreads) s_tab[i] = kEmpty;
@@ -838,24 +854,9 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
             }
             __syncthreads();
         }
-        auto count_runs = [&]() {
-            __syncthreads();
-            if (tid == 0) s_nruns = 0;
-            __syncthreads();
-            for (uint32_t i = tid + 1; i < n; i += kSortThreads)
-                if (s_key[i] < s_key[i - 1]) {
-                    const uint32_t r = atomicAdd(&s_nruns, 1u);
-                    if (r < kMaxRuns) s_run[r] = i;
-                }
-            __syncthreads();
-        };
-        if (todo && s_nruns > kFewRuns) {
-            todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 2);
+        if (todo && s_nruns >= kMaxRuns) {
+            todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 4);
             if (todo) count_runs();
-            if (todo && s_nruns >= kMaxRuns) {
-                todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 4);
-                if (todo) count_runs();
-            }
         }
         if (todo && s_nruns < kMaxRuns) {
             // Up to 31 ascending runs: merge neighbouring runs pairwise, log2(runs) rounds.  An element's place in the merged
