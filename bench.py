@@ -797,7 +797,7 @@ def cluster_point(ctx, torch, synth, contigs):
     return {'marks': M, 'candidates_found': dc.n_cands(), 'candidates_oracle': int(len(want['cand_off']) - 1),
             'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'algorithmic_bytes_18_per_mark': 18 * M,
             'GBs_vs_B_A0': 18 * M / dt / 1e9, 'cpu_oracle_ms_1core': cpu * 1e3,
-            'note': 'latency-bound at this size: ~30 small launches; the few 65..100-mark partitions are on the critical path'}
+            'note': 'latency-bound at this size: ~20 small launches; the partitions with the most groups left are on the critical path'}
 
 
 def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False):
@@ -846,7 +846,7 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False):
     return {'marks': M, 'candidates_found': int(ds.n_found), 'phased': int((got['pred'] != 0).sum()),
             'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'ms_per_run_with_count_returned': dt_wait * 1e3,
             'parity_vs_composed_oracles': ok,
-            'roofline': {'kernels': 'duet_svim_phase_device: A0 (sort, partitions, linkage, emit) + E/F, ~30 launches',
+            'roofline': {'kernels': 'duet_svim_phase_device: A0 (sort, partitions, linkage, emit) + E/F, ~25 launches',
                          'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                          'traffic': None, 'algorithmic_bytes_per_run': b_a0 + b_ef, 'B_A0_18_per_mark': b_a0, 'B_EF': b_ef,
                          'run_ms': dt * 1e3,

@@ -8,8 +8,10 @@
 // Pipeline (DESIGN.md section 9 has the rule, the argument and the measurements):
 //   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, the mark index in the spare
 //                  bits above them when it fits (else a separate value array); (pos, span[, read index]) side by side
-//   radix sort     stable LSD, 8-bit digits: rx_hist -> tile offsets -> rx_scatter per pass (ballot-ranked, no atomics
-//                  on the data path, so the order is deterministic); keys only when the index rides in the key
+//   radix sort     stable LSD passes, 8-bit digits: rx_hist -> tile offsets -> rx_scatter per pass (ballot-ranked, no atomics
+//                  on the data path, so the order is deterministic); keys only when the index rides in the key.  Where that
+//                  saves two passes the passes cover the top 16 / 24 key bits only and the keys that agree in them -- a few to
+//                  a few dozen -- are ordered by their low bits where they lie (rx_local: a rank count in LDS; rx_big)
 //   partitions     one scan over a composite element straight off the sorted keys: natural partition starts (contig/type
 //                  change or centre gap > part_gap), a partition there and every part_max marks after -> the partition
 //                  start list and the first partition of every 2048-position tile
