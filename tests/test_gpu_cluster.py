@@ -101,6 +101,15 @@ def test_genome_sized_coordinates(ctx, seed):
     check(ctx, marks, max_dist=[0.9, 0.5, 0.3, 0.9, 1.2, 0.7][seed])
 
 
+def test_genome_sized_keys_of_35_bits(ctx):
+    """20 contigs x 3 types x 28-bit centres: 35 key bits, the width at which LARGE inputs (the launch structure
+    DUET_DBG_CLUSTER_LARGE selects in check()) sort the top 24 bits globally and the low 11 locally (rx_local<256>)."""
+    for seed in (0, 1):
+        marks = random_marks(70 + seed, 9000 + 4000 * seed, clumps=30 + 3000 * seed, contigs=20, types=3, spread=400 + 900 * seed)
+        marks = dict(marks, pos=(marks['pos'].astype(np.uint64) + 240000000).astype(np.uint32))
+        check(ctx, marks, max_dist=[0.9, 0.4][seed])
+
+
 def test_genome_sized_coordinates_edge_sizes(ctx):
     """... around the local sort's tile (2048 positions) and halo (256): groups that start in one tile and end in the next."""
     for M in (1, 2, 3, 255, 2047, 2048, 2049, 2303, 2304, 2305, 4097, 6144):
