@@ -1199,7 +1199,8 @@ struct FastSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
     uint4 ps[SUBS][NMAX];                                    // (pos, span, end, centre): one 16-byte broadcast read per pair
     uint64_t mask[SUBS][NMAX][NW];
-    unsigned long long sum[SUBS][NMAX][2];
+    // (emit_prep's sums live in the linkage's scratch, which is idle by then: 1 KB less per workgroup is the eighth
+    // workgroup per CU for cl_fast_all)
 };
 
 // what a unit does: the threshold graph first and the exact linkage, in the same wavefront, for what that does not
@@ -1329,7 +1330,9 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
         LinkSmem<GROUP, R, NCAP> &X = *reinterpret_cast<LinkSmem<GROUP, R, NCAP> *>(smem_link);
         link_unit<GROUP, R, NCAP, NW>(p, need, n, sub, sl, pk, spk, wide, X, S.mask[sub], F);
     }
-    emit_prep<GROUP, R, NW, NMAX>(p, has && take, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
+    static_assert(sizeof(LinkSmem<GROUP, R, NCAP>) >= sizeof(unsigned long long) * 2 * (64 / GROUP) * NMAX, "emit_prep's sums do not fit the linkage's scratch");
+    unsigned long long (*sums)[2] = reinterpret_cast<unsigned long long (*)[2]>(smem_link) + (size_t)sub * NMAX;
+    emit_prep<GROUP, R, NW, NMAX>(p, has && take, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], sums, mk, rd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1840,21 +1843,33 @@ __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32
 {
     __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
     __shared__ __align__(16) unsigned char smem_link[kLinkSmemBytes];
-    __shared__ uint32_t s_pref[4][kShards + 1];
+    __shared__ uint32_t s_pref[kShards + 1];               // the running sums of ONE class's shard counters at a time
+    // the classes' totals (one wavefront: a lane per shard)
+    uint32_t tot[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) worklist_prefix(cnts + c * kShards, s_pref[c]);
-    __syncthreads();
+    for (int c = 0; c < 4; ++c) {
+        uint32_t x = cnts[c * kShards + (threadIdx.x & 63u)];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d, 64);
+        tot[c] = x;
+    }
     const size_t M = p.M;
     const uint32_t span = p.tps * kScanTile;
-    const WorkList l0{lists, s_pref[0], span, 0u}, l1{lists + M, s_pref[1], span, 0u}, l2{lists + 2 * M, s_pref[2], span, 0u},
-        l3{lists + 3 * M, s_pref[3], span, 0u};
-    const uint32_t c0 = l0.size(), c1 = l1.size(), c2 = l2.size(), c3 = l3.size();
-    const uint32_t b3 = c3, b2 = b3 + (c2 + 1) / 2, b1 = b2 + (c1 + 3) / 4, b0 = b1 + (c0 + 7) / 8;
+    const uint32_t b3 = tot[3], b2 = b3 + (tot[2] + 1) / 2, b1 = b2 + (tot[1] + 3) / 4, b0 = b1 + (tot[0] + 7) / 8;
+    int loaded = -1;
     for (uint32_t vb = blockIdx.x; vb < b0; vb += gridDim.x) {
-        if (vb < b3) fast_unit<64, 1, 64, kFastThenLink>(p, l3, vb, smem, smem_link);
-        else if (vb < b2) fast_unit<32, 1, 32, kFastThenLink>(p, l2, (vb - b3) * 2, smem, smem_link);
-        else if (vb < b1) fast_unit<16, 1, 16, kFastThenLink>(p, l1, (vb - b2) * 4, smem, smem_link);
-        else fast_unit<8, 1, 8, kFastThenLink>(p, l0, (vb - b1) * 8, smem, smem_link);
+        const int c = vb < b3 ? 3 : (vb < b2 ? 2 : (vb < b1 ? 1 : 0));
+        if (c != loaded) {
+            __syncthreads();
+            worklist_prefix(cnts + c * kShards, s_pref);
+            __syncthreads();
+            loaded = c;
+        }
+        const WorkList l{lists + (size_t)c * M, s_pref, span, 0u};
+        if (c == 3) fast_unit<64, 1, 64, kFastThenLink>(p, l, vb, smem, smem_link);
+        else if (c == 2) fast_unit<32, 1, 32, kFastThenLink>(p, l, (vb - b3) * 2, smem, smem_link);
+        else if (c == 1) fast_unit<16, 1, 16, kFastThenLink>(p, l, (vb - b2) * 4, smem, smem_link);
+        else fast_unit<8, 1, 8, kFastThenLink>(p, l, (vb - b1) * 8, smem, smem_link);
     }
 }
 
