@@ -17,7 +17,7 @@
 //                  start list and the first partition of every 2048-position tile
 //   cl_box         one workgroup per tile: gathers the tile's marks through the sort permutation, finishes the partitions whose
 //                  bounding box proves ONE cluster (most, on SV-like data), lays the others' rows out in sorted order and
-//                  lists them by size class (<= 8 / 16 / 32 / 64 marks; > 64: cl_big_list, on a side stream beside cl_box)
+//                  lists them by size class (<= 8 / 16 / 32 / 64 marks; > 64: cl_tight_big finds them itself, on a side stream beside cl_box)
 //   agglomeration  GROUP lanes per partition, one lane per mark.
 //                  small inputs: cl_fast_all -- the threshold graph and, in the same wavefront, the exact linkage on the full
 //                  triangle of sums for what that does not settle (fast_unit, link_unit);
@@ -411,9 +411,10 @@ struct WorkList {
     const uint32_t *pref;           // (LDS) pref[s] = items in the shards before s, pref[kShards] = all
     uint32_t shard_span;            // positions per shard
     uint32_t rev_end;               // 0: a shard's piece grows up from its first position; M: down from its last one (see over_append)
-    __device__ __forceinline__ uint32_t size() const { return pref[kShards]; }
+    __device__ __forceinline__ uint32_t size() const { return items ? pref[kShards] : shard_span; }
     __device__ __forceinline__ uint32_t operator[](uint32_t i) const
     {
+        if (!items) return i;                              // (no list: the items are the numbers 0 .. shard_span - 1 themselves)
         uint32_t lo = 0, hi = kShards;                     // pref[lo] <= i < pref[hi]
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             }
             const uint32_t r = min(min(phi - plo, ehi - elo), chi - clo);
             const float u = (float)r * p.inv_norm + (float)(shi - slo) * __builtin_amdgcn_rcpf((float)max(shi, 1u));
-            // (partitions of more than 64 marks belong to the launch that started beside this one: see cl_big_list)
+            // (partitions of more than 64 marks belong to the launch that started beside this one: cl_tight_big)
             const bool one = n < 2 || (n <= 64u && p.fast && p.box && !bad && u <= p.t_lo[0]);
             s_done[j] = one ? 1 : 0;
             if (one) {
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
                 p.pc[p_lo + j] = 1;
             } else {
                 cls = size_class(n);
-                if (cls == 4) cls = -1;                      // (listed by cl_big_list: their launch starts before this kernel is done)
+                if (cls == 4) cls = -1;                      // (cl_tight_big finds them itself: its launch starts before this kernel is done)
             }
         }
         // append the others to their class lists (wave-aggregated)
@@ -600,20 +601,6 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             if (p.sv_mark_out) p.sv_mark_out[i] = rd[j];
         } else {
             p.srec[i] = make_uint4(ps_[j], sp_[j], rd[j], mk[j]);
-        }
-    }
-}
-
-// The partitions of more than 64 marks -- a handful, but each is one wavefront's hundred-microsecond chain -- are listed from the
-// partition starts alone, so that their launch can begin on a side stream while cl_box is still looking at everybody's marks.
-__global__ __launch_bounds__(256) void cl_big_list(const ClParams p, uint32_t *list /* class 4 of lists */, uint32_t *counts /* its kShards counters */)
-{
-    const uint32_t n_parts = *p.n_parts;
-    for (uint32_t part = blockIdx.x * blockDim.x + threadIdx.x; part < n_parts; part += gridDim.x * blockDim.x) {
-        const uint32_t s0 = p.part_start[part], n = p.part_start[part + 1] - s0;
-        if (n > 64u) {
-            const uint32_t shard = (s0 / kScanTile) / p.tps;
-            list[(size_t)shard * p.tps * kScanTile + atomicAdd(&counts[shard], 1u)] = part;
         }
     }
 }
@@ -1803,6 +1790,28 @@ __global__ __launch_bounds__(64) void cl_tight_one(const ClParams p, uint32_t *i
         tight_unit<GROUP, R, KC, false>(p, list, base, smem, items, over_counts);
 }
 
+// The partitions of more than 64 marks without a list: a wavefront looks at 64 partitions' sizes at a time and takes the ones
+// it finds (a handful in a million marks; the launch that listed them first cost their chain 10 us).
+template <int KC>
+__global__ __launch_bounds__(64) void cl_tight_big(const ClParams p, uint32_t *over_items, uint32_t *over_counts /* [kShards] */,
+                                                   uint32_t *found /* how many there were (statistics) */)
+{
+    __shared__ __align__(16) unsigned char smem[sizeof(TightSmem<64, 2, KC>)];
+    const uint32_t n_parts = *p.n_parts, lane = threadIdx.x;
+    const WorkList all{nullptr, nullptr, n_parts, 0u};
+    for (uint32_t b0 = blockIdx.x * 64u; b0 < n_parts; b0 += gridDim.x * 64u) {
+        const uint32_t part = b0 + lane;
+        const bool big = part < n_parts && p.part_start[part + 1] - p.part_start[part] > 64u;
+        unsigned long long m = __ballot(big);
+        while (m) {
+            const uint32_t at = (uint32_t)__ffsll((long long)m) - 1u;
+            m &= m - 1ull;
+            tight_unit<64, 2, KC, false>(p, all, b0 + at, smem, over_items, over_counts);
+            if (lane == 0) atomicAdd(found, 1u);
+        }
+    }
+}
+
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 constexpr int kK8 = tier1_groups(8), kK16 = tier1_groups(16), kK32 = tier1_groups(32), kK64 = tier1_groups(64);
 
@@ -2201,10 +2210,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     {
         ClParams pb = p;
         pb.gather_rows = 1;
-        const uint32_t g_parts = std::min((M + 255u) / 256u, std::max(256u, (M + 255u) / 256u / 8u));
-        hipLaunchKernelGGL(cl_big_list, dim3(g_parts), dim3(256), 0, ctx->cl_side[0], pb, l4, c4);
-        const uint32_t gb = small ? (grid < 4096u ? grid : 4096u) : grid;
-        hipLaunchKernelGGL((cl_tight_one<64, 2, 64>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, (const uint32_t *)c4, o4);
+        const uint32_t gb = std::min(4096u, std::max(256u, (M / 64u + 63u) / 64u));      // (partitions <= marks; 64 of them per wavefront and step)
+        hipLaunchKernelGGL((cl_tight_big<64>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, o4, c4);
         const uint32_t gl = std::min(gb, 1024u);
         if (cap100) hipLaunchKernelGGL((cl_link_one<64, 2, 100>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
         else hipLaunchKernelGGL((cl_link_one<64, 2, 128>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
