@@ -2137,7 +2137,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const bool small_in = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     // (the global passes take the top 16 bits of a small input's keys, the top 24 of a large one's: groups of a few keys to a
     // few dozen either way on a genome; used where that saves two passes or more)
-    const uint32_t top_bits = small_in ? 16u : 24u;
+    const uint32_t top_bits = M <= (2u << 20) ? 16u : 24u;     // (16 bits leave groups of a hundred keys and more beyond 2 M marks)
     const bool hybrid = p.idx_packed && (key_bits + 7u) / 8u >= top_bits / 8u + 2u && !(ctx->dbg & DUET_DBG_CLUSTER_LSD);
     const uint32_t top_shift = hybrid ? key_bits - top_bits : 0u;
     uint32_t *big_count = scal + 40, *big_list = valsA;          // (the value buffers are idle when the index rides in the key)
