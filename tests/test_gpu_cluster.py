@@ -110,6 +110,26 @@ def test_genome_sized_keys_of_35_bits(ctx):
         check(ctx, marks, max_dist=[0.9, 0.4][seed])
 
 
+@pytest.mark.parametrize('g', [255, 256, 257, 1023, 1024, 1025, 3000])
+def test_local_sort_group_sizes_at_its_limits(ctx, g):
+    """Groups (keys that agree in the top 16 key bits: one type within 16 k centres here) of exactly g keys around the local
+    sort's limits -- 256 keys for the rank count in a tile's window, 1024 for the one-workgroup LDS path, LSD passes beyond --
+    between ordinary small groups, on both sides of a tile boundary."""
+    rng = synth.SplitMix(4242 + g)
+    parts = []
+    base = 200000000
+    for k, size in enumerate([40, g, 17, g, 300, 5, g]):
+        win = base + k * 16384 * 3                   # every group in a window of its own (16384 centres = the low 14 bits)
+        pos = win + rng.between(size, 0, 12000)
+        parts.append((pos, rng.between(size, 30, 4000)))
+    pos = np.concatenate([p for p, _ in parts]).astype(np.uint32)
+    span = np.concatenate([s_ for _, s_ in parts]).astype(np.uint32)
+    M = len(pos)
+    perm = np.argsort(rng.below(M, 1 << 30), kind='stable')
+    marks = dict(contig=np.zeros(M, dtype=np.uint16), type=np.zeros(M, dtype=np.uint8), pos=pos[perm], span=span[perm])
+    check(ctx, marks, part_gap=1000)
+
+
 def test_genome_sized_coordinates_edge_sizes(ctx):
     """... around the local sort's tile (2048 positions) and halo (256): groups that start in one tile and end in the next."""
     for M in (1, 2, 3, 255, 2047, 2048, 2049, 2303, 2304, 2305, 4097, 6144):
