@@ -2196,7 +2196,6 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.scale = (double)kQOne / pr->max_dist;
     p.mergeable = pr->max_dist >= 0 ? 1u : 0u;
     p.kc = (ctx->dbg & DUET_DBG_CLUSTER_KC2) ? 2u : 64u;
-    if (getenv("DUET_X_KC")) p.kc = (uint32_t)atoi(getenv("DUET_X_KC"));
     const uint32_t gridw = std::min(32768u, std::max(1024u, M / 256u));     // (a wavefront per virtual block, striding)
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
