@@ -53,6 +53,7 @@
 namespace {
 
 #include "duet_prims.hip.h"
+#include "duet_recsort.hip.h"
 
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -72,6 +73,9 @@ struct ClParams {
     const uint4 *rec4;                                // fused pipeline instead: (pos, span, read index, -) -- the agglomeration's gather
                                                       // also fetches what the output needs, cl_emit does not gather again
     const uint64_t *skeys;                            // the sorted keys (contig | type | centre)
+    uint32_t rec_mode;                                // the sort carried the records (duet_recsort.hip.h): srec holds EVERY sorted position's record,
+                                                      // w = (contig | type) << idx_bits | mark index; no sorted keys, no permutation
+    uint32_t idx_bits, idx_mask;                      // (idx_mask = ~0 outside rec_mode: srec's w is the mark index itself)
     const uint32_t *part_start;                       // [P+1]
     const uint32_t *n_parts;                          // device scalar
     float inv_norm, t_lo[3], t_hi[3];                 // binary32 pair tests: 1/normalizer; level * (1 -/+ 1e-5) for the levels max_dist, / 2, / 4
@@ -167,36 +171,39 @@ __global__ __launch_bounds__(kRxHistThreads) void cl_keys(const ClParams p, uint
 // loads and stores
 // i if sorted position i starts a natural partition (contig/type change or centre gap), else 0: everything needed
 // is in the sorted keys -- (contig, type) in the high bits, the centre in the low bits
+// (E: the sorted elements -- 8-byte keys, or the 16-byte records where the sort carried them; keyof: an element's sort key)
+template <class E, class KeyOf>
 struct LoadHead {
-    const uint64_t *keys;
+    const E *keys;
     uint32_t centre_bits, part_gap;
-    uint64_t km;                                            // the key proper (a packed mark index sits above it)
-    __device__ __forceinline__ uint32_t operator()(uint32_t i) const
-    {
-        if (i == 0) return 0u;
-        const uint64_t a = keys[i - 1] & km, b = keys[i] & km;
-        const uint64_t cm = (1ull << centre_bits) - 1ull;
-        const bool cut = (a >> centre_bits) != (b >> centre_bits) || (b & cm) - (a & cm) > (uint64_t)part_gap;
-        return cut ? i : 0u;
-    }
+    KeyOf keyof;
 };
-// the same for the kScanItems consecutive positions base .. base + kScanItems - 1 of one scan thread, from 16-byte loads (base is a
-// multiple of kScanItems and the key buffer is hipMalloc-aligned): head[j] = position base + j starts a natural partition
-__device__ __forceinline__ void load_heads(const LoadHead &h, uint32_t base, uint32_t n, bool (&head)[kScanItems])
+// head[j] = position base + j starts a natural partition, for the kScanItems consecutive positions base .. base + kScanItems - 1
+// of one scan thread (keys: from 16-byte loads -- base is a multiple of kScanItems and the buffer is hipMalloc-aligned)
+template <class E, class KeyOf>
+__device__ __forceinline__ void load_heads(const LoadHead<E, KeyOf> &h, uint32_t base, uint32_t n, bool (&head)[kScanItems])
 {
     static_assert(kScanItems % 2 == 0, "two keys per load");
     uint64_t k[kScanItems + 1];
-    k[0] = base > 0 && base <= n ? h.keys[base - 1] & h.km : 0ull;
+    k[0] = base > 0 && base <= n ? h.keyof(h.keys[base - 1]) : 0ull;
+    if constexpr (std::is_same<E, uint64_t>::value) {
 #pragma unroll
-    for (int j = 0; j < kScanItems; j += 2) {
-        if (base + j + 1 < n) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(h.keys + base + j);
-            k[j + 1] = v.x & h.km;
-            k[j + 2] = v.y & h.km;
-        } else {
-            k[j + 1] = base + j < n ? h.keys[base + j] & h.km : 0ull;
-            k[j + 2] = 0ull;
+        for (int j = 0; j < kScanItems; j += 2) {
+            if (base + j + 1 < n) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(h.keys + base + j);
+                k[j + 1] = h.keyof(v.x);
+                k[j + 2] = h.keyof(v.y);
+            } else {
+                k[j + 1] = base + j < n ? h.keyof(h.keys[base + j]) : 0ull;
+                k[j + 2] = 0ull;
+            }
         }
+    } else {
+        E e[kScanItems];
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) e[j] = h.keys[min(base + j, n - 1u)];
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) k[j + 1] = base + j < n ? h.keyof(e[j]) : 0ull;
     }
     const uint64_t cm = (1ull << h.centre_bits) - 1ull;
 #pragma unroll
@@ -265,7 +272,8 @@ __device__ __forceinline__ PartSum part_block_exscan(const PartSum &mine, uint32
     return before;
 }
 
-__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero, uint32_t nzero)
+template <class E, class KeyOf>
+__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead<E, KeyOf> in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero, uint32_t nzero)
 {
     __shared__ PartSum s_w[kScanThreads / 64 + 1];
     const uint32_t tid = threadIdx.x;
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(1024) void part_spine(PartSum *tiles, uint32_t nb, 
 
 // SELF: tiles[] holds the tiles' own summaries and every block combines the ones before it by itself.  pid (optional): every
 // position's partition id -- nobody downstream needs it since cl_emit walks partitions
-template <bool SELF>
-__global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead in, uint32_t n, uint32_t pm, const PartSum *tiles, uint32_t *pid,
+template <bool SELF, class E, class KeyOf>
+__global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead<E, KeyOf> in, uint32_t n, uint32_t pm, const PartSum *tiles, uint32_t *pid,
                                                            uint32_t *part_start, uint32_t *n_parts, uint32_t *tile_first /* [tiles + 1]: the first
                                                            partition that starts in each tile (cl_box owns a tile's partitions) */)
 {
@@ -484,6 +492,9 @@ constexpr double kQCap = 2199023255552.0;          // 2^41
 // a pair loop.  The others go on the work lists by size class.
 constexpr int kBoxThreads = 256;
 constexpr int kBoxHalo = 128;                      // a partition has at most 128 marks: the last one of a tile ends within the halo
+// REC: the sort carried the records -- the tile's rows are p.srec[t0 ...] as they lie (no permutation, no gather), and the rows of
+// the partitions left open stay where they are for the agglomeration kernels
+template <bool REC>
 __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const uint32_t *tile_first, uint32_t *lists /* [kClasses][M] */,
                                                       uint32_t *counts /* [kClasses][kShards] */)
 {
@@ -506,14 +517,21 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
 #pragma unroll
         for (int j = 0; j < kScanItems; ++j) at[j] = min(t0 + j * kBoxThreads + tid, p.M - 1u);
         at[kScanItems] = min(t0 + kScanTile + min(tid, (uint32_t)kBoxHalo - 1u), p.M - 1u);      // the halo (threads < kBoxHalo)
-        if (p.idx_packed) {
+        if (REC) {
+#pragma unroll
+            for (int j = 0; j <= kScanItems; ++j) {
+                const uint4 q = p.srec[at[j]];
+                ps_[j] = q.x; sp_[j] = q.y; rd[j] = q.z; mk[j] = q.w & p.idx_mask;
+            }
+        } else if (p.idx_packed) {
 #pragma unroll
             for (int j = 0; j <= kScanItems; ++j) mk[j] = (uint32_t)(p.skeys[at[j]] >> p.key_bits);
         } else {
 #pragma unroll
             for (int j = 0; j <= kScanItems; ++j) mk[j] = p.sorted[at[j]];
         }
-        if (p.rec4) {
+        if (REC) {
+        } else if (p.rec4) {
 #pragma unroll
             for (int j = 0; j <= kScanItems; ++j) {
                 const uint4 q = p.rec4[mk[j]];
@@ -599,7 +617,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
         if (s_done[s_pix[i - t0]]) {
             p.order[i] = mk[j];
             if (p.sv_mark_out) p.sv_mark_out[i] = rd[j];
-        } else {
+        } else if (!REC) {
             p.srec[i] = make_uint4(ps_[j], sp_[j], rd[j], mk[j]);
         }
     }
@@ -1225,11 +1243,11 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
                 spk[r] = q.y;
                 rd[r] = q.z;
             } else {
-                const uint4 q = p.srec[s + k];           // (cl_box laid the rows out in sorted order)
+                const uint4 q = p.srec[s + k];           // (the rows in sorted order: cl_box laid them out, or the sort carried them)
                 pk[r] = q.x;
                 spk[r] = q.y;
                 rd[r] = q.z;
-                mk[r] = q.w;
+                mk[r] = q.w & p.idx_mask;
             }
         }
         ek[r] = pk[r] + spk[r];
@@ -1404,11 +1422,11 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
                 spk[r] = q.y;
                 rd[r] = q.z;
             } else {
-                const uint4 q = p.srec[s + k];           // (cl_box laid the rows out in sorted order)
+                const uint4 q = p.srec[s + k];           // (the rows in sorted order: cl_box laid them out, or the sort carried them)
                 pk[r] = q.x;
                 spk[r] = q.y;
                 rd[r] = q.z;
-                mk[r] = q.w;
+                mk[r] = q.w & p.idx_mask;
             }
         }
         ek[r] = pk[r] + spk[r];
@@ -1959,7 +1977,8 @@ __global__ void cl_emit(const ClParams p)
     // (a grid of a fraction of the bound -- the marks -- strides over the partitions: see cl_classes)
     for (uint32_t part = blockIdx.x * blockDim.x + threadIdx.x; part < n_parts; part += gridDim.x * blockDim.x) {
         const uint32_t s = p.part_start[part], nc = p.pc[part], c0 = p.cbase[part];
-        const uint64_t hi = (p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits;                        // contig | type, straight from the sorted key
+        const uint64_t hi = p.rec_mode ? (uint64_t)(p.srec[s].w >> p.idx_bits)
+                                       : (p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits;           // contig | type, straight from the sorted key / record
         const uint32_t k = (uint32_t)(hi >> p.type_bits), type = (uint32_t)(hi & ((1ull << p.type_bits) - 1ull));
         uint32_t d_lo = 0, nb = 0;
         if (p.sv_svread) {
@@ -2070,21 +2089,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t nb_sc = (M + kScanTile - 1) / kScanTile;
     const uint32_t nb_rx = (M + kRxTile - 1) / kRxTile;
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
-    const size_t sizes[15] = {(size_t)M * 8, (size_t)M * 8, (size_t)M * 4, (size_t)M * 4, (size_t)256 * nb_rx * 4,
-                              ((size_t)nb_sc + 1) * sizeof(PartSum), ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                              ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + 2 * kClasses * kShards), (size_t)M * 4 * kClasses, ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * (sv ? 16 : 8), (size_t)M * 16};
     int rc;
-    for (int i = 0; i < 15; ++i)
-        if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
-    uint64_t *keysA = (uint64_t *)ctx->cl_ws[0].ptr, *keysB = (uint64_t *)ctx->cl_ws[1].ptr;
-    uint32_t *valsA = (uint32_t *)ctx->cl_ws[2].ptr, *valsB = (uint32_t *)ctx->cl_ws[3].ptr;
-    uint32_t *hist = (uint32_t *)ctx->cl_ws[4].ptr;
-    uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr;             // the partition scan's tile summaries
-    uint32_t *tile_first = (uint32_t *)ctx->cl_ws[6].ptr;       // [tiles + 1] first partition starting in each scan tile
-    uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
-    uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
-    uint32_t *cbase = (uint32_t *)ctx->cl_ws[13].ptr + (M + 1);      // (the first M + 1 words hold label8 / comp8)
-    uint32_t *pc = (uint32_t *)ctx->cl_ws[10].ptr;
+    if ((rc = duet_reserve(ctx, ctx->cl_ws[11], 4 * (64 + 2 * kClasses * kShards)))) return rc;
     uint32_t *scal = (uint32_t *)ctx->cl_ws[11].ptr;      // [0] = n_parts
 
     ClParams p;
@@ -2113,6 +2119,45 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     if (key_bits > 64) return duet_fail(ctx, DUET_ERR_INVALID, "sort key does not fit 64 bits");
     p.key_bits = key_bits;
     p.idx_packed = key_bits + bits_for(M - 1) <= 64 && !(ctx->dbg & DUET_DBG_CLUSTER_PAIRS);
+    // The record travels with the key (duet_recsort.hip.h) when contig, type and mark index fit one word of it
+    const uint32_t idx_bits = bits_for(M - 1);
+    const bool rec_mode = contig_bits + p.type_bits + idx_bits <= 32u &&
+                          !(ctx->dbg & (DUET_DBG_CLUSTER_PAIRS | DUET_DBG_CLUSTER_LSD | DUET_DBG_CLUSTER_KEYSORT));
+    p.rec_mode = rec_mode ? 1u : 0u;
+    p.idx_bits = idx_bits;
+    p.idx_mask = rec_mode ? (uint32_t)((1ull << idx_bits) - 1ull) : 0xFFFFFFFFu;
+    // the digits of the record sort: LSD passes of up to kRsMaxW bits over the key's top bits, so many of them that the marks
+    // that agree in them (a GROUP: one type within 2^lo centres) are a few dozen; the low bits are ordered group by group
+    uint32_t rs_lo = 0, rs_np = 0, rs_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rec_mode) {
+        uint32_t T = std::max(bits_for(M >> 5), 8u);
+        T = std::min(T, key_bits);
+        if (key_bits - T > 31u) T = key_bits - 31u;            // (the local stage holds the low bits in 32-bit words)
+        rs_lo = key_bits - T;
+        rs_np = (T + kRsMaxW - 1u) / kRsMaxW;
+        for (uint32_t i = 0; i < rs_np; ++i) rs_w[i] = T / rs_np + (i < T % rs_np ? 1u : 0u);
+    }
+    const uint32_t nb_rs = (M + kRsTile - 1) / kRsTile, rs_chunks = (nb_rs + kRsChunk - 1) / kRsChunk;
+    {
+        const size_t hist_legacy = (size_t)256 * nb_rx * 4, hist_rec = ((size_t)nb_rs + rs_chunks + 1) * (4u << kRsMaxW);
+        const size_t sizes[15] = {rec_mode ? 16 : (size_t)M * 8, rec_mode ? 16 : (size_t)M * 8, (size_t)M * 4, rec_mode ? 16 : (size_t)M * 4,
+                                  rec_mode ? hist_rec : hist_legacy,
+                                  ((size_t)nb_sc + 1) * sizeof(PartSum), ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
+                                  ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + 2 * kClasses * kShards), (size_t)M * 4 * kClasses,
+                                  ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * ((sv || rec_mode) ? 16 : 8), (size_t)M * 16};
+        for (int i = 0; i < 15; ++i)
+            if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
+    }
+    scal = (uint32_t *)ctx->cl_ws[11].ptr;
+    uint64_t *keysA = (uint64_t *)ctx->cl_ws[0].ptr, *keysB = (uint64_t *)ctx->cl_ws[1].ptr;
+    uint32_t *valsA = (uint32_t *)ctx->cl_ws[2].ptr, *valsB = (uint32_t *)ctx->cl_ws[3].ptr;
+    uint32_t *hist = (uint32_t *)ctx->cl_ws[4].ptr;
+    uint32_t *tmpA = (uint32_t *)ctx->cl_ws[5].ptr;             // the partition scan's tile summaries
+    uint32_t *tile_first = (uint32_t *)ctx->cl_ws[6].ptr;       // [tiles + 1] first partition starting in each scan tile
+    uint32_t *spart = (uint32_t *)ctx->cl_ws[7].ptr;
+    uint32_t *part_start = (uint32_t *)ctx->cl_ws[8].ptr;
+    uint32_t *cbase = (uint32_t *)ctx->cl_ws[13].ptr + (M + 1);      // (the first M + 1 words hold label8 / comp8)
+    uint32_t *pc = (uint32_t *)ctx->cl_ws[10].ptr;
 
     // outputs (the agglomeration kernels write the marks' output order themselves)
     if (sv) {
@@ -2138,9 +2183,70 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // (the global passes take the top 16 bits of a small input's keys, the top 24 of a large one's: groups of a few keys to a
     // few dozen either way on a genome; used where that saves two passes or more)
     const uint32_t top_bits = M <= (2u << 20) ? 16u : 24u;     // (16 bits leave groups of a hundred keys and more beyond 2 M marks)
-    const bool hybrid = p.idx_packed && (key_bits + 7u) / 8u >= top_bits / 8u + 2u && !(ctx->dbg & DUET_DBG_CLUSTER_LSD);
+    // (rx_local and rx_big hold the low bits in 32-bit words: wider keys than top_bits + 31 take plain LSD passes)
+    const bool hybrid = !rec_mode && p.idx_packed && (key_bits + 7u) / 8u >= top_bits / 8u + 2u && key_bits - top_bits < 32u && !(ctx->dbg & DUET_DBG_CLUSTER_LSD);
     const uint32_t top_shift = hybrid ? key_bits - top_bits : 0u;
     uint32_t *big_count = scal + 40, *big_list = valsA;          // (the value buffers are idle when the index rides in the key)
+    const uint32_t loc_cap = (ctx->dbg & DUET_DBG_CLUSTER_SMALLCAP) ? 3u : (uint32_t)kLocHalo;
+    PartSum *tiles = (PartSum *)tmpA;                             // the partition scan's tile summaries: 3 words per 2048 marks
+    p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
+    if (rec_mode) {
+        // the record sort (duet_recsort.hip.h): the first pass reads the caller's arrays, every pass moves 16-byte records
+        RsSrc src;
+        src.contig = pr->mark_contig; src.type = pr->mark_type; src.pos = pr->mark_pos; src.span = pr->mark_span;
+        src.read = sv ? sv->mark_in : nullptr;
+        src.type_bits = p.type_bits; src.idx_bits = idx_bits; src.centre_bits = p.centre_bits;
+        uint4 *buf[2] = {(uint4 *)ctx->cl_ws[14].ptr, (uint4 *)recs};
+        const bool rs_small = nb_rs <= kRsSmallTiles && !big_sort;
+        uint32_t *dtot = rs_small ? ctx->rx_dtot : (uint32_t *)nullptr;
+        uint32_t *partial = hist + ((size_t)nb_rs << kRsMaxW), *dbase = partial + ((size_t)rs_chunks << kRsMaxW);
+        const uint4 *rin = nullptr;
+        int at = 0;                                               // the buffer the next launch writes
+        uint32_t shift = rs_lo;
+        for (uint32_t ps = 0; ps < rs_np; ++ps) {
+            const uint32_t w = rs_w[ps];
+            if (ps == 0) hipLaunchKernelGGL(rs_hist<true>, dim3(nb_rs), dim3(kRsHistThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, hist, dtot, big_count);
+            else hipLaunchKernelGGL(rs_hist<false>, dim3(nb_rs), dim3(kRsHistThreads), 0, st, src, rin, M, shift, w, hist, dtot, (uint32_t *)nullptr);
+            if (rs_small) {
+                hipLaunchKernelGGL(rs_offsets_small, dim3(std::max(1u, (1u << w) / 64u)), dim3(1024), 0, st, hist, nb_rs, w, (const uint32_t *)dtot);
+            } else {
+                hipLaunchKernelGGL(rs_col_reduce, dim3(rs_chunks), dim3(256), 0, st, (const uint32_t *)hist, nb_rs, w, partial);
+                hipLaunchKernelGGL(rs_col_spine, dim3(1), dim3(1024), 0, st, partial, rs_chunks, w, dbase);
+                hipLaunchKernelGGL(rs_col_apply, dim3(rs_chunks), dim3(256), 0, st, hist, nb_rs, w, (const uint32_t *)partial, (const uint32_t *)dbase);
+            }
+            if (ps == 0) {
+                if (w <= 8u) hipLaunchKernelGGL((rs_scatter<8, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
+            } else {
+                if (w <= 8u) hipLaunchKernelGGL((rs_scatter<8, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
+            }
+            rin = buf[at];
+            at ^= 1;
+            shift += w;
+        }
+        if (rs_lo > 0) {
+            const KeyOfRec keyof{p.centre_bits, idx_bits};
+            if (small_in)
+                hipLaunchKernelGGL((rx_local<1024, uint4, KeyOfRec>), dim3((M + kLocTile - 1) / kLocTile), dim3(1024), 0, st, rin, buf[at], M, rs_lo, keyof, loc_cap, big_list, big_count);
+            else
+                hipLaunchKernelGGL((rx_local<256, uint4, KeyOfRec>), dim3((M + kLocTile - 1) / kLocTile), dim3(256), 0, st, rin, buf[at], M, rs_lo, keyof, loc_cap, big_list, big_count);
+            hipLaunchKernelGGL((rx_big<uint4, KeyOfRec>), dim3(256), dim3(256), 0, st, (uint4 *)rin, buf[at], M, rs_lo, keyof, (const uint32_t *)big_list, (const uint32_t *)big_count);
+            rin = buf[at];
+        }
+        p.srec = (uint4 *)rin;
+        p.rec4 = nullptr; p.ps = nullptr;
+        const LoadHead<uint4, KeyOfRec> heads{rin, p.centre_bits, p.part_gap, KeyOfRec{p.centre_bits, idx_bits}};
+        hipLaunchKernelGGL((part_reduce<uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards));
+        if (nb_sc <= kSelfSpine && !big_sort) {
+            hipLaunchKernelGGL((part_apply<true, uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+                               part_start, scal, tile_first);
+        } else {
+            hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
+            hipLaunchKernelGGL((part_apply<false, uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+                               part_start, scal, tile_first);
+        }
+    } else {
     hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs, top_shift,
                        key_bits - top_shift >= 8u ? 255u : (1u << (key_bits - top_shift)) - 1u, nb_rx, hist, rx_totals ? ctx->rx_dtot : (uint32_t *)nullptr,
                        big_count);
@@ -2148,15 +2254,15 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint32_t *vin = nullptr;
     if (p.idx_packed) radix_sort_pairs(keysA, keysB, nullptr, nullptr, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, nullptr, &kout, big_sort, true, top_shift);
     else radix_sort_pairs(keysA, keysB, valsA, valsB, M, key_bits, hist, spart, ctx->rx_dtot, st, &kin, &vin, &kout, big_sort, true);
+    const KeyOfU64 keyof{key_mask(key_bits)};
     if (hybrid) {
-        const uint32_t cap = (ctx->dbg & DUET_DBG_CLUSTER_SMALLCAP) ? 3u : (uint32_t)kLocHalo;
         if (small_in)
-            hipLaunchKernelGGL(rx_local<1024>, dim3((M + kLocTile - 1) / kLocTile), dim3(1024), 0, st, (const uint64_t *)kin, kout, M, top_shift, key_bits, cap,
+            hipLaunchKernelGGL((rx_local<1024, uint64_t, KeyOfU64>), dim3((M + kLocTile - 1) / kLocTile), dim3(1024), 0, st, (const uint64_t *)kin, kout, M, top_shift, keyof, loc_cap,
                                big_list, big_count);
         else
-            hipLaunchKernelGGL(rx_local<256>, dim3((M + kLocTile - 1) / kLocTile), dim3(256), 0, st, (const uint64_t *)kin, kout, M, top_shift, key_bits, cap,
+            hipLaunchKernelGGL((rx_local<256, uint64_t, KeyOfU64>), dim3((M + kLocTile - 1) / kLocTile), dim3(256), 0, st, (const uint64_t *)kin, kout, M, top_shift, keyof, loc_cap,
                                big_list, big_count);
-        hipLaunchKernelGGL(rx_big, dim3(256), dim3(256), 0, st, kin, kout, M, top_shift, key_bits, (const uint32_t *)big_list, (const uint32_t *)big_count);
+        hipLaunchKernelGGL((rx_big<uint64_t, KeyOfU64>), dim3(256), dim3(256), 0, st, kin, kout, M, top_shift, keyof, (const uint32_t *)big_list, (const uint32_t *)big_count);
         uint64_t *t = kin; kin = kout; kout = t;
     }
     p.sorted = vin;
@@ -2164,21 +2270,20 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // partitions: one composite scan straight off the sorted keys -> each position's partition id, the partition start
     // list and their number (scal[0]); it also zeroes the work-list counters
     {
-        const LoadHead heads{(const uint64_t *)kin, p.centre_bits, p.part_gap, key_mask(key_bits)};
-        PartSum *tiles = (PartSum *)tmpA;                         // 3 words per 2048 marks
-        hipLaunchKernelGGL(part_reduce, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards));
+        const LoadHead<uint64_t, KeyOfU64> heads{(const uint64_t *)kin, p.centre_bits, p.part_gap, keyof};
+        hipLaunchKernelGGL((part_reduce<uint64_t, KeyOfU64>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards));
         if (nb_sc <= kSelfSpine && !big_sort) {
-            hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+            hipLaunchKernelGGL((part_apply<true, uint64_t, KeyOfU64>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal, tile_first);
         } else {
             hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
-            hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+            hipLaunchKernelGGL((part_apply<false, uint64_t, KeyOfU64>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal, tile_first);
         }
     }
-    p.part_start = part_start; p.n_parts = scal; p.pc = pc;
-    p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
     p.srec = (uint4 *)ctx->cl_ws[14].ptr;
+    }
+    p.part_start = part_start; p.n_parts = scal; p.pc = pc;
     const uint32_t grid = M < 16384u ? M : 16384u;               // partitions <= marks; kernels stride over them
     uint32_t *lists = (uint32_t *)ctx->cl_ws[12].ptr;            // [kClasses][M] partitions by size class, each list in kShards pieces
     uint32_t *cnts = scal + 64;                                  // [kClasses][kShards]
@@ -2208,7 +2313,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
     {
         ClParams pb = p;
-        pb.gather_rows = 1;
+        pb.gather_rows = rec_mode ? 0u : 1u;                     // (rec_mode: the sorted rows are there already)
         const uint32_t gb = std::min(4096u, std::max(256u, (M / 64u + 63u) / 64u));      // (partitions <= marks; 64 of them per wavefront and step)
         hipLaunchKernelGGL((cl_tight_big<64>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, o4, c4);
         const uint32_t gl = std::min(gb, 1024u);
@@ -2218,7 +2323,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     }
     const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
-    hipLaunchKernelGGL(cl_box, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
+    if (rec_mode) hipLaunchKernelGGL(cl_box<true>, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
+    else hipLaunchKernelGGL(cl_box<false>, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
     if (!tiers) {
         // one launch for the classes of up to 64 marks, nothing handed on
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);

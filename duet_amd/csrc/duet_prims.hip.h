@@ -431,8 +431,13 @@ inline void radix_sort_pairs(uint64_t *keysA, uint64_t *keysB, uint32_t *valsA, 
 // most `cap` keys (cap <= kLocHalo: such a group ends inside the tile's window); larger groups go on a list for rx_big.
 // The result is stable (ties keep their order), so the whole sort is.
 constexpr int kLocTile = 2048, kLocHalo = 256;
-template <int THREADS>                                     // 1024 for small inputs (a tile's latency counts), 256 for large ones (more tiles in flight)
-__global__ __launch_bounds__(THREADS) void rx_local(const uint64_t *in, uint64_t *out, uint32_t n, uint32_t lo, uint32_t key_bits, uint32_t cap,
+// E: the sort element -- an 8-byte key (the mark index in its spare bits) or, where the record travels with the key, the
+// 16-byte mark record (duet_recsort.hip.h); keyof(e) is its sort key
+template <class E> __device__ __forceinline__ E rx_zero();
+template <> __device__ __forceinline__ uint64_t rx_zero<uint64_t>() { return 0ull; }
+template <> __device__ __forceinline__ uint4 rx_zero<uint4>() { return make_uint4(0u, 0u, 0u, 0u); }
+template <int THREADS, class E, class KeyOf>               // 1024 threads for small inputs (a tile's latency counts), 256 for large ones (more tiles in flight)
+__global__ __launch_bounds__(THREADS) void rx_local(const E *in, E *out, uint32_t n, uint32_t lo, const KeyOf keyof, uint32_t cap,
                                                     uint32_t *big_list, uint32_t *big_count)
 {
     constexpr int W = kLocTile + kLocHalo, kNone = 0x7FFF;
@@ -444,28 +449,28 @@ __global__ __launch_bounds__(THREADS) void rx_local(const uint64_t *in, uint64_t
     __shared__ int16_t s_ge[W + 1];                        // end of the position's group (first position behind it; kNone: beyond the window)
     __shared__ int s_carry[2][THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t0 = blockIdx.x * kLocTile;
-    const uint64_t kmask = key_bits >= 64u ? ~0ull : (1ull << key_bits) - 1ull;
-    const uint32_t lmask = (1u << lo) - 1u;
+    const uint32_t lmask = (1u << lo) - 1u;                 // (lo < 32: the callers see to it)
     // (up to 20 low bits: a key's low bits and its place in the window make ONE 32-bit number, distinct for every key -- the
     // rank is a count of smaller numbers, one compare per key; beyond, low bits and place are compared separately)
     const bool packed = lo <= 20u;
-    uint64_t key[kIter];
+    E key[kIter];
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const uint32_t i = tid + it * THREADS;
-        key[it] = (i <= (uint32_t)W && t0 + i < n) ? in[t0 + i] : 0ull;
+        key[it] = (i <= (uint32_t)W && t0 + i < n) ? in[t0 + i] : rx_zero<E>();
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const uint32_t i = tid + it * THREADS;
         const bool live = i <= (uint32_t)W && t0 + i < n;
-        const uint64_t g = (key[it] & kmask) >> lo;
+        const uint64_t kk = keyof(key[it]);
+        const uint64_t g = kk >> lo;
         // the group number of the position in front: the lane in front holds it, lane 0 fetches it
         uint64_t pg = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(g >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)g, 1, 64);
-        if (lane == 0 && live && t0 + i > 0u) pg = (in[t0 + i - 1u] & kmask) >> lo;
+        if (lane == 0 && live && t0 + i > 0u) pg = keyof(in[t0 + i - 1u]) >> lo;
         if (i <= (uint32_t)W) {
             s_head[i] = (!live || t0 + i == 0u || g != pg) ? 1 : 0;      // (the end of the keys closes the last group)
-            const uint32_t low = (uint32_t)key[it] & lmask;
+            const uint32_t low = (uint32_t)kk & lmask;
             s_low[i] = packed ? (low << 12) | i : low;
         }
     }
@@ -554,17 +559,17 @@ __global__ __launch_bounds__(THREADS) void rx_local(const uint64_t *in, uint64_t
 // 256 keys and pass).  a: the keys as the global passes left them (the groups' ranges of b are nobody else's); the result
 // ends in b.
 constexpr int kBigLds = 1024;
-__global__ __launch_bounds__(256) void rx_big(uint64_t *a, uint64_t *b, uint32_t n, uint32_t lo, uint32_t key_bits, const uint32_t *big_list,
+template <class E, class KeyOf>
+__global__ __launch_bounds__(256) void rx_big(E *a, E *b, uint32_t n, uint32_t lo, const KeyOf keyof, const uint32_t *big_list,
                                               const uint32_t *big_count)
 {
-    __shared__ uint64_t s_k[kBigLds];
+    __shared__ E s_k[kBigLds];
     __shared__ uint32_t s_low[kBigLds + 4];
     __shared__ uint32_t s_base[256];                       // where the next key of each digit goes
     __shared__ uint32_t s_wcnt[4][256];
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_end;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t kmask = key_bits >= 64u ? ~0ull : (1ull << key_bits) - 1ull;
     const uint32_t lmask = (1u << lo) - 1u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const uint32_t count = *big_count;
@@ -576,13 +581,13 @@ __global__ __launch_bounds__(256) void rx_big(uint64_t *a, uint64_t *b, uint32_t
         // the group's first kBigLds keys (and the one behind them) in one round of loads: most groups end among them
         uint64_t g = 0;
         {
-            const uint64_t first = a[gs];
-            g = (first & kmask) >> lo;
+            g = keyof(a[gs]) >> lo;
             for (uint32_t i = tid; i <= (uint32_t)kBigLds; i += 256u) {
                 const uint32_t pos = gs + i;
-                const uint64_t k = pos < n ? a[pos] : 0ull;
-                const bool in = pos < n && ((k & kmask) >> lo) == g;
-                if (i < (uint32_t)kBigLds) { s_k[i] = k; s_low[i] = (uint32_t)k & lmask; }
+                const E k = pos < n ? a[pos] : rx_zero<E>();
+                const uint64_t kk = keyof(k);
+                const bool in = pos < n && (kk >> lo) == g;
+                if (i < (uint32_t)kBigLds) { s_k[i] = k; s_low[i] = (uint32_t)kk & lmask; }
                 if (!in) atomicMin(&s_end, i);              // (group numbers do not decrease along a: the first "no" ends the group)
             }
         }
@@ -606,16 +611,16 @@ __global__ __launch_bounds__(256) void rx_big(uint64_t *a, uint64_t *b, uint32_t
         uint32_t lo_i = gs + (uint32_t)kBigLds, hi_i = n;  // first position behind the group, by bisection
         while (hi_i - lo_i > 1u) {
             const uint32_t mid = lo_i + ((hi_i - lo_i) >> 1);
-            if (((a[mid] & kmask) >> lo) == g) lo_i = mid; else hi_i = mid;
+            if ((keyof(a[mid]) >> lo) == g) lo_i = mid; else hi_i = mid;
         }
         const uint32_t ge = hi_i;
-        uint64_t *src = a, *dst = b;
+        E *src = a, *dst = b;
         for (uint32_t shift = 0; shift < lo; shift += 8) {
             const uint32_t dmask = lo - shift >= 8u ? 255u : (1u << (lo - shift)) - 1u;
             __syncthreads();
             s_base[tid] = 0;
             __syncthreads();
-            for (uint32_t i = gs + tid; i < ge; i += 256u) atomicAdd(&s_base[(uint32_t)(src[i] >> shift) & dmask], 1u);
+            for (uint32_t i = gs + tid; i < ge; i += 256u) atomicAdd(&s_base[(uint32_t)(keyof(src[i]) >> shift) & dmask], 1u);
             __syncthreads();
             {   // exclusive scan of the 256 digit counts
                 const uint32_t c = s_base[tid];
@@ -638,8 +643,8 @@ __global__ __launch_bounds__(256) void rx_big(uint64_t *a, uint64_t *b, uint32_t
                 __syncthreads();
                 const uint32_t i = c0 + tid;
                 const bool valid = i < ge;
-                const uint64_t k = valid ? src[i] : 0ull;
-                const uint32_t d = (uint32_t)(k >> shift) & dmask;
+                const E k = valid ? src[i] : rx_zero<E>();
+                const uint32_t d = (uint32_t)(keyof(k) >> shift) & dmask;
                 unsigned long long same = __ballot(valid);
 #pragma unroll
                 for (int bit = 0; bit < 8; ++bit) {
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(256) void rx_big(uint64_t *a, uint64_t *b, uint32_t
                 s_base[tid] += s_wcnt[0][tid] + s_wcnt[1][tid] + s_wcnt[2][tid] + s_wcnt[3][tid];
             }
             __syncthreads();
-            uint64_t *t = src; src = dst; dst = t;
+            E *t = src; src = dst; dst = t;
         }
         if (src == a) {                                    // an even number of passes left the result in a
             __threadfence_block();

@@ -29,8 +29,11 @@ def check(ctx, marks, **kw):
     # DUET_DBG_CLUSTER_TIERS = 0x2000: the two tiers in their fused (small-input) launches; DUET_DBG_CLUSTER_SMALLCAP = 0x4000 /
     # DUET_DBG_CLUSTER_LSD = 0x8000: where the low bits are sorted locally, groups of more than 3 keys through the
     # one-workgroup-per-group path / plain LSD passes instead
+    # DUET_DBG_CLUSTER_KEYSORT = 0x10000: the key-only sort of rounds 1-3 (+ the gather through the permutation) where the
+    # default now carries the 16-byte record with the key
     for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600), (True, 0x800),
-                       (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800), (True, 0x4000), (False, 0x8000)):
+                       (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800), (True, 0x4000), (False, 0x8000),
+                       (True, 0x10000), (False, 0x10200), (True, 0x14000), (False, 0x4200), (True, 0x10800)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
@@ -213,3 +216,34 @@ def test_between_one_and_four_million_marks(ctx):
     got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'])
     for f in FIELDS:
         assert np.array_equal(got[f], want[f]), f
+
+
+@pytest.mark.parametrize('M', [3, 200, 5000, 70000])
+def test_wide_keys_few_marks(ctx, M):
+    """Positions next to 2^32 with contig ids next to 65535 and many types: 33 + 16 + 8 = 57 key bits.  With few marks the
+    index still fits the key's spare bits, and the local ordering of the low bits (32-bit words) must not be offered more
+    than 31 of them: such keys take more global passes (round-3 advisor finding); contig + type + index do not fit one record
+    word either, so this is the key-only sort."""
+    rng = synth.SplitMix(9100 + M)
+    pos = (0xFFFFFFFF - 3000000 + rng.between(M, 0, 40) * 70000 + rng.between(M, 0, 900)).astype(np.uint32)
+    span = rng.between(M, 30, 3000).astype(np.uint32)
+    contig = (65535 - rng.below(M, 3) * 20000).astype(np.uint16)
+    typ = (255 - rng.below(M, 2) * 200).astype(np.uint8)
+    check(ctx, dict(contig=contig, type=typ, pos=pos, span=span))
+
+
+def test_record_sort_digit_plans(ctx):
+    """The record sort's pass plan over sizes and key widths: one, two and three global digits, digits of fewer than eight
+    bits, no local stage at all (tiny keys), and a contig / type / index word filled to its 32 bits."""
+    cases = [
+        (300, dict(clumps=3, contigs=1, types=1, spread=50), 0),                # 13-bit keys: a single digit, lo = 5
+        (40000, dict(clumps=300, contigs=2, types=2, spread=700), 0),           # 21-bit keys
+        (150000, dict(clumps=4000, contigs=24, types=2, spread=900), 200000000),# 34-bit keys, 13 top bits: two digits
+        (9000, dict(clumps=50, contigs=4000, types=3, spread=300), 0),          # 12 contig + 2 type + 14 index bits
+        (33000, dict(clumps=60, contigs=60000, types=2, spread=300), 0),        # 16 + 1 + 15 = 32 bits of the record word
+    ]
+    for k, (M, kw, off) in enumerate(cases):
+        marks = random_marks(880 + k, M, **kw)
+        if off:
+            marks = dict(marks, pos=(marks['pos'].astype(np.uint64) + off).astype(np.uint32))
+        check(ctx, marks, max_dist=[0.9, 0.5, 0.9, 0.3, 0.9][k])
