@@ -178,40 +178,51 @@ struct LoadHead {
     uint32_t centre_bits, part_gap;
     KeyOf keyof;
 };
-// head[j] = position base + j starts a natural partition, for the kScanItems consecutive positions base .. base + kScanItems - 1
-// of one scan thread (keys: from 16-byte loads -- base is a multiple of kScanItems and the buffer is hipMalloc-aligned)
+// head[j] = position base + j starts a natural partition, for the kScanItems consecutive positions tid * kScanItems + j of one
+// scan thread of the tile at t0.  The elements are read side by side (thread tid takes the positions j * kScanThreads + tid: a
+// wave's load is one run of memory, where eight consecutive 16-byte records per lane were 64 different lines per instruction),
+// the flags change hands in LDS; the tile's flags also go out as one byte per thread (hbits[t0 / 8 + tid], bit j): part_apply
+// then reads 1 bit per mark instead of the elements again.
 template <class E, class KeyOf>
-__device__ __forceinline__ void load_heads(const LoadHead<E, KeyOf> &h, uint32_t base, uint32_t n, bool (&head)[kScanItems])
+__device__ __forceinline__ void load_heads(const LoadHead<E, KeyOf> &h, uint32_t t0, uint32_t n, bool (&head)[kScanItems], uint8_t *s_f /* LDS [kScanTile] */,
+                                           uint8_t *hbits)
 {
-    static_assert(kScanItems % 2 == 0, "two keys per load");
-    uint64_t k[kScanItems + 1];
-    k[0] = base > 0 && base <= n ? h.keyof(h.keys[base - 1]) : 0ull;
-    if constexpr (std::is_same<E, uint64_t>::value) {
+    static_assert(kScanItems == 8, "one flag byte per thread");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint64_t s_edge[kScanItems][kScanThreads / 64];      // every wave's last key, per round of loads
+    E e[kScanItems];
 #pragma unroll
-        for (int j = 0; j < kScanItems; j += 2) {
-            if (base + j + 1 < n) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(h.keys + base + j);
-                k[j + 1] = h.keyof(v.x);
-                k[j + 2] = h.keyof(v.y);
-            } else {
-                k[j + 1] = base + j < n ? h.keyof(h.keys[base + j]) : 0ull;
-                k[j + 2] = 0ull;
-            }
-        }
-    } else {
-        E e[kScanItems];
-#pragma unroll
-        for (int j = 0; j < kScanItems; ++j) e[j] = h.keys[min(base + j, n - 1u)];
-#pragma unroll
-        for (int j = 0; j < kScanItems; ++j) k[j + 1] = base + j < n ? h.keyof(e[j]) : 0ull;
-    }
+    for (int j = 0; j < kScanItems; ++j) e[j] = h.keys[min(t0 + j * kScanThreads + tid, n - 1u)];
+    const E before = h.keys[(tid == 0 && t0 > 0u) ? t0 - 1u : 0u];   // (leaves with the others: no round trip of its own)
     const uint64_t cm = (1ull << h.centre_bits) - 1ull;
 #pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+        if (lane == 63u) s_edge[j][wave] = h.keyof(e[j]);
+    __syncthreads();
+#pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
-        const uint32_t i = base + j;
-        const uint64_t a = k[j], b = k[j + 1];
-        head[j] = i < n && (i == 0 || (a >> h.centre_bits) != (b >> h.centre_bits) || (b & cm) - (a & cm) > (uint64_t)h.part_gap);
+        const uint32_t i = t0 + j * kScanThreads + tid;
+        const uint64_t b = h.keyof(e[j]);
+        // the key in front: the lane in front holds it; lane 0 has it from the wave in front
+        uint64_t a = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(b >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)b, 1, 64);
+        if (lane == 0) a = wave > 0 ? s_edge[j][wave - 1u] : (j > 0 ? s_edge[j > 0 ? j - 1 : 0][kScanThreads / 64 - 1] : h.keyof(before));
+        s_f[j * kScanThreads + tid] = (i < n && (i == 0 || (a >> h.centre_bits) != (b >> h.centre_bits) || (b & cm) - (a & cm) > (uint64_t)h.part_gap)) ? 1 : 0;
     }
+    __syncthreads();
+    const uint2 f = *reinterpret_cast<const uint2 *>(s_f + tid * kScanItems);
+    uint32_t byte = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        head[j] = (((j < 4 ? f.x : f.y) >> (8 * (j & 3))) & 1u) != 0;
+        byte |= head[j] ? 1u << j : 0u;
+    }
+    hbits[t0 / kScanItems + tid] = (uint8_t)byte;
+}
+__device__ __forceinline__ void load_head_bits(const uint8_t *hbits, uint32_t t0, bool (&head)[kScanItems])
+{
+    const uint32_t byte = hbits[t0 / kScanItems + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) head[j] = (byte >> j) & 1u;
 }
 
 // clusters of partition i.  The partition count lives on the device: the scan is launched over the M positions (an upper
@@ -273,16 +284,18 @@ __device__ __forceinline__ PartSum part_block_exscan(const PartSum &mine, uint32
 }
 
 template <class E, class KeyOf>
-__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead<E, KeyOf> in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero, uint32_t nzero)
+__global__ __launch_bounds__(kScanThreads) void part_reduce(const LoadHead<E, KeyOf> in, uint32_t n, uint32_t pm, PartSum *tiles, uint32_t *zero, uint32_t nzero,
+                                                            uint8_t *hbits /* [tiles * kScanThreads] one flag byte per scan thread */)
 {
     __shared__ PartSum s_w[kScanThreads / 64 + 1];
+    __shared__ __align__(8) uint8_t s_f[kScanTile];
     const uint32_t tid = threadIdx.x;
     if (zero && blockIdx.x == 0)
         for (uint32_t i = tid; i < nzero; i += kScanThreads) zero[i] = 0;     // the work-list counters of the kernels that follow
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     PartSum acc{kNoHead, 0, 0};
     bool head[kScanItems];
-    load_heads(in, base, n, head);
+    load_heads(in, blockIdx.x * kScanTile, n, head, s_f, hbits);
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j)
         if (head[j]) acc = part_combine(acc, PartSum{base + j, base + j, 0}, pm);
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(1024) void part_spine(PartSum *tiles, uint32_t nb, 
 
 // SELF: tiles[] holds the tiles' own summaries and every block combines the ones before it by itself.  pid (optional): every
 // position's partition id -- nobody downstream needs it since cl_emit walks partitions
-template <bool SELF, class E, class KeyOf>
-__global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead<E, KeyOf> in, uint32_t n, uint32_t pm, const PartSum *tiles, uint32_t *pid,
+template <bool SELF>
+__global__ __launch_bounds__(kScanThreads) void part_apply(const uint8_t *hbits, uint32_t n, uint32_t pm, const PartSum *tiles, uint32_t *pid,
                                                            uint32_t *part_start, uint32_t *n_parts, uint32_t *tile_first /* [tiles + 1]: the first
                                                            partition that starts in each tile (cl_box owns a tile's partitions) */)
 {
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(kScanThreads) void part_apply(const LoadHead<E, Key
     const uint32_t base = blockIdx.x * kScanTile + tid * kScanItems;
     bool head[kScanItems];
     PartSum acc{kNoHead, 0, 0};
-    load_heads(in, base, n, head);
+    load_head_bits(hbits, blockIdx.x * kScanTile, head);
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j)
         if (head[j]) acc = part_combine(acc, PartSum{base + j, base + j, 0}, pm);
@@ -2130,19 +2143,22 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // that agree in them (a GROUP: one type within 2^lo centres) are a few dozen; the low bits are ordered group by group
     uint32_t rs_lo = 0, rs_np = 0, rs_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (rec_mode) {
-        uint32_t T = std::max(bits_for(M >> 5), 8u);
+        uint32_t T = std::max(bits_for(M >> 3), 8u);
+        if (const char *e = getenv("DUET_RS_TBITS")) T = (uint32_t)atoi(e);                                                       // (experiments)
         T = std::min(T, key_bits);
         if (key_bits - T > 31u) T = key_bits - 31u;            // (the local stage holds the low bits in 32-bit words)
         rs_lo = key_bits - T;
-        rs_np = (T + kRsMaxW - 1u) / kRsMaxW;
+        uint32_t maxw = kRsMaxW;
+        if (const char *e = getenv("DUET_RS_MAXW")) maxw = std::min((uint32_t)kRsMaxW, std::max(4u, (uint32_t)atoi(e)));      // (experiments)
+        rs_np = (T + maxw - 1u) / maxw;
         for (uint32_t i = 0; i < rs_np; ++i) rs_w[i] = T / rs_np + (i < T % rs_np ? 1u : 0u);
     }
     const uint32_t nb_rs = (M + kRsTile - 1) / kRsTile, rs_chunks = (nb_rs + kRsChunk - 1) / kRsChunk;
     {
         const size_t hist_legacy = (size_t)256 * nb_rx * 4, hist_rec = ((size_t)nb_rs + rs_chunks + 1) * (4u << kRsMaxW);
-        const size_t sizes[15] = {rec_mode ? 16 : (size_t)M * 8, rec_mode ? 16 : (size_t)M * 8, (size_t)M * 4, rec_mode ? 16 : (size_t)M * 4,
+        const size_t sizes[15] = {rec_mode ? 16 : (size_t)M * 8, rec_mode ? 16 : (size_t)M * 8, (size_t)M * 4, rec_mode ? (size_t)M * 2 + 16 : (size_t)M * 4,
                                   rec_mode ? hist_rec : hist_legacy,
-                                  ((size_t)nb_sc + 1) * sizeof(PartSum), ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
+                                  ((size_t)nb_sc + 1) * sizeof(PartSum) + 16 + (size_t)nb_sc * kScanThreads, ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
                                   ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + 2 * kClasses * kShards), (size_t)M * 4 * kClasses,
                                   ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * ((sv || rec_mode) ? 16 : 8), (size_t)M * 16};
         for (int i = 0; i < 15; ++i)
@@ -2189,6 +2205,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint32_t *big_count = scal + 40, *big_list = valsA;          // (the value buffers are idle when the index rides in the key)
     const uint32_t loc_cap = (ctx->dbg & DUET_DBG_CLUSTER_SMALLCAP) ? 3u : (uint32_t)kLocHalo;
     PartSum *tiles = (PartSum *)tmpA;                             // the partition scan's tile summaries: 3 words per 2048 marks
+    uint8_t *hbits = (uint8_t *)tmpA + ((((size_t)nb_sc + 1) * sizeof(PartSum) + 15) & ~(size_t)15);      // ... and the head flags, a bit per mark
     p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
     if (rec_mode) {
         // the record sort (duet_recsort.hip.h): the first pass reads the caller's arrays, every pass moves 16-byte records
@@ -2198,28 +2215,33 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         src.type_bits = p.type_bits; src.idx_bits = idx_bits; src.centre_bits = p.centre_bits;
         uint4 *buf[2] = {(uint4 *)ctx->cl_ws[14].ptr, (uint4 *)recs};
         const bool rs_small = nb_rs <= kRsSmallTiles && !big_sort;
-        uint32_t *dtot = rs_small ? ctx->rx_dtot : (uint32_t *)nullptr;
-        uint32_t *partial = hist + ((size_t)nb_rs << kRsMaxW), *dbase = partial + ((size_t)rs_chunks << kRsMaxW);
+        uint32_t *dtot = ctx->rx_dtot;                             // [kRsDtotCopies][2048]
+        uint32_t *partial = hist + ((size_t)nb_rs << kRsMaxW);
+        uint16_t *dig = (uint16_t *)valsB;                        // the next pass's digit of every record (rs_scatter -> rs_hist_dig)
+        const uint32_t swz = getenv("DUET_RS_NOSWZ") ? 0u : 1u;                                                                 // (experiments)
         const uint4 *rin = nullptr;
         int at = 0;                                               // the buffer the next launch writes
         uint32_t shift = rs_lo;
         for (uint32_t ps = 0; ps < rs_np; ++ps) {
             const uint32_t w = rs_w[ps];
-            if (ps == 0) hipLaunchKernelGGL(rs_hist<true>, dim3(nb_rs), dim3(kRsHistThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, hist, dtot, big_count);
-            else hipLaunchKernelGGL(rs_hist<false>, dim3(nb_rs), dim3(kRsHistThreads), 0, st, src, rin, M, shift, w, hist, dtot, (uint32_t *)nullptr);
+            uint32_t *htot = rs_small ? dtot : (uint32_t *)nullptr;
+            if (ps == 0) hipLaunchKernelGGL(rs_hist<true>, dim3(nb_rs), dim3(kRsHistThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, hist, htot, big_count);
+            else hipLaunchKernelGGL(rs_hist_dig, dim3(nb_rs), dim3(kRsHistThreads), 0, st, (const uint16_t *)dig, M, w, hist, htot);
+            uint16_t *dig_out = ps + 1 < rs_np ? dig : (uint16_t *)nullptr;
+            const uint32_t nshift = shift + w, nmask = ps + 1 < rs_np ? (1u << rs_w[ps + 1]) - 1u : 0u;
             if (rs_small) {
                 hipLaunchKernelGGL(rs_offsets_small, dim3(std::max(1u, (1u << w) / 64u)), dim3(1024), 0, st, hist, nb_rs, w, (const uint32_t *)dtot);
             } else {
-                hipLaunchKernelGGL(rs_col_reduce, dim3(rs_chunks), dim3(256), 0, st, (const uint32_t *)hist, nb_rs, w, partial);
-                hipLaunchKernelGGL(rs_col_spine, dim3(1), dim3(1024), 0, st, partial, rs_chunks, w, dbase);
-                hipLaunchKernelGGL(rs_col_apply, dim3(rs_chunks), dim3(256), 0, st, hist, nb_rs, w, (const uint32_t *)partial, (const uint32_t *)dbase);
+                hipLaunchKernelGGL(rs_col_reduce, dim3(rs_chunks), dim3(256), 0, st, (const uint32_t *)hist, nb_rs, w, partial, dtot);
+                hipLaunchKernelGGL(rs_offsets_small, dim3(std::max(1u, (1u << w) / 64u)), dim3(1024), 0, st, partial, rs_chunks, w, (const uint32_t *)dtot);
+                hipLaunchKernelGGL(rs_col_apply, dim3(rs_chunks), dim3(256), 0, st, hist, nb_rs, w, (const uint32_t *)partial);
             }
             if (ps == 0) {
-                if (w <= 8u) hipLaunchKernelGGL((rs_scatter<8, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
-                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
+                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
             } else {
-                if (w <= 8u) hipLaunchKernelGGL((rs_scatter<8, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
-                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot);
+                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
             }
             rin = buf[at];
             at ^= 1;
@@ -2237,13 +2259,13 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         p.srec = (uint4 *)rin;
         p.rec4 = nullptr; p.ps = nullptr;
         const LoadHead<uint4, KeyOfRec> heads{rin, p.centre_bits, p.part_gap, KeyOfRec{p.centre_bits, idx_bits}};
-        hipLaunchKernelGGL((part_reduce<uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards));
+        hipLaunchKernelGGL((part_reduce<uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards), hbits);
         if (nb_sc <= kSelfSpine && !big_sort) {
-            hipLaunchKernelGGL((part_apply<true, uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+            hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal, tile_first);
         } else {
             hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
-            hipLaunchKernelGGL((part_apply<false, uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+            hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal, tile_first);
         }
     } else {
@@ -2271,13 +2293,13 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // list and their number (scal[0]); it also zeroes the work-list counters
     {
         const LoadHead<uint64_t, KeyOfU64> heads{(const uint64_t *)kin, p.centre_bits, p.part_gap, keyof};
-        hipLaunchKernelGGL((part_reduce<uint64_t, KeyOfU64>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards));
+        hipLaunchKernelGGL((part_reduce<uint64_t, KeyOfU64>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards), hbits);
         if (nb_sc <= kSelfSpine && !big_sort) {
-            hipLaunchKernelGGL((part_apply<true, uint64_t, KeyOfU64>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+            hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal, tile_first);
         } else {
             hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
-            hipLaunchKernelGGL((part_apply<false, uint64_t, KeyOfU64>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+            hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
                                part_start, scal, tile_first);
         }
     }

@@ -1302,8 +1302,8 @@ duet_ctx *duet_ctx_create(int device_id)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cl_join[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->plan_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->rx_dtot, 8 * 1024 * sizeof(uint32_t));        // kDtotCopies x 256 (key sort) / x 1024 (record sort)
-    if (e == hipSuccess) e = hipMemset(ctx->rx_dtot, 0, 8 * 1024 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->rx_dtot, 8 * 2048 * sizeof(uint32_t));        // kDtotCopies x 256 (key sort) / x 2048 (record sort)
+    if (e == hipSuccess) e = hipMemset(ctx->rx_dtot, 0, 8 * 2048 * sizeof(uint32_t));
     if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         duet_g_last_error = std::string("context resources: ") + hipGetErrorString(e);
         duet_ctx_destroy(ctx);                               // releases whatever was created

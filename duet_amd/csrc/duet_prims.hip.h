@@ -448,6 +448,7 @@ __global__ __launch_bounds__(THREADS) void rx_local(const E *in, E *out, uint32_
     __shared__ int16_t s_gs[W + 1];                        // start of the position's group inside the window (-1: it starts before the window)
     __shared__ int16_t s_ge[W + 1];                        // end of the position's group (first position behind it; kNone: beyond the window)
     __shared__ int s_carry[2][THREADS / 64];
+    __shared__ uint64_t s_edge[kIter][THREADS / 64];       // the group number of every wave's last key, per round of loads
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t0 = blockIdx.x * kLocTile;
     const uint32_t lmask = (1u << lo) - 1u;                 // (lo < 32: the callers see to it)
     // (up to 20 low bits: a key's low bits and its place in the window make ONE 32-bit number, distinct for every key -- the
@@ -459,15 +460,22 @@ __global__ __launch_bounds__(THREADS) void rx_local(const E *in, E *out, uint32_
         const uint32_t i = tid + it * THREADS;
         key[it] = (i <= (uint32_t)W && t0 + i < n) ? in[t0 + i] : rx_zero<E>();
     }
+    // (the key in front of the window leaves with the others: a lane 0 that fetched its predecessor when it got to it made
+    // every round of the loop below wait for a round trip of its own -- ten in a row per tile)
+    const E before = (tid == 0 && t0 > 0u) ? in[t0 - 1u] : rx_zero<E>();
+#pragma unroll
+    for (int it = 0; it < kIter; ++it)
+        if (lane == 63u) s_edge[it][wave] = keyof(key[it]) >> lo;
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const uint32_t i = tid + it * THREADS;
         const bool live = i <= (uint32_t)W && t0 + i < n;
         const uint64_t kk = keyof(key[it]);
         const uint64_t g = kk >> lo;
-        // the group number of the position in front: the lane in front holds it, lane 0 fetches it
+        // the group number of the position in front: the lane in front holds it; lane 0 has it from the wave in front
         uint64_t pg = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(g >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)g, 1, 64);
-        if (lane == 0 && live && t0 + i > 0u) pg = keyof(in[t0 + i - 1u]) >> lo;
+        if (lane == 0) pg = wave > 0 ? s_edge[it][wave - 1u] : (it > 0 ? s_edge[it > 0 ? it - 1 : 0][THREADS / 64 - 1] : keyof(before) >> lo);
         if (i <= (uint32_t)W) {
             s_head[i] = (!live || t0 + i == 0u || g != pg) ? 1 : 0;      // (the end of the keys closes the last group)
             const uint32_t low = (uint32_t)kk & lmask;

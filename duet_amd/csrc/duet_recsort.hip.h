@@ -17,7 +17,8 @@
 //                     its columns in 16 segments
 //   rs_col_*          (beyond) column sums per chunk of tiles -> one spine block -> exclusive offsets written back
 //   rs_scatter<WB>    stable scatter of one digit of up to WB bits: ballot-ranked per wave, the tile laid out digit-sorted in
-//                     LDS and written from there (runs leave as whole lines).  The first pass reads the caller's arrays and
+//                     LDS and written from there (runs leave as whole lines); it also leaves the next pass's digit of every
+//                     record beside it (rs_hist_dig reads 2 bytes per mark where rs_hist would read 16).  The first pass reads the caller's arrays and
 //                     builds the records (RAW).  Tiles are dealt to workgroups so that the workgroups of one XCD hold a
 //                     CONTIGUOUS range of tiles: the runs a digit receives from neighbouring tiles are neighbours in memory,
 //                     and with 1024-way digits a run is 4 records = half a line -- the halves meet in that XCD's L2.
@@ -25,15 +26,15 @@
 //                     sorted top bits are ordered by a rank count in LDS, the record stored to its place
 //
 // Passes: LSD over the key's top bits [lo, key_bits), lo chosen so that a group holds a few dozen marks (16-17 bits of a
-// 1 M-mark input's key in two 8-bit passes, 20 bits of a 2e7-mark genome's in two 10-bit passes), each pass stable, so equal
+// 1 M-mark input's key in two passes of 9 and 8 bits, 22 bits of a 2e7-mark genome's in two 11-bit passes), each pass stable, so equal
 // keys keep their input order (rule 1 of oracle/cluster_oracle.c).
 #ifndef DUET_RECSORT_HIP_H
 #define DUET_RECSORT_HIP_H
 
 constexpr int kRsTile = 4096;                          // marks per tile (rs_hist and rs_scatter)
-constexpr int kRsThreads = 256, kRsItems = kRsTile / kRsThreads;
+constexpr int kRsThreads = 512, kRsItems = kRsTile / kRsThreads;
 constexpr int kRsHistThreads = 1024;
-constexpr int kRsMaxW = 10;                            // bits of one global digit, at most
+constexpr int kRsMaxW = 11;                            // bits of one global digit, at most
 constexpr int kRsDtotCopies = 8;
 constexpr uint32_t kRsSmallTiles = 1024;               // up to this many tiles the offsets take one launch (digit totals by atomics)
 constexpr int kRsChunk = 16;                           // tiles per column chunk beyond
@@ -108,6 +109,32 @@ __global__ __launch_bounds__(kRsHistThreads) void rs_hist(const RsSrc src, const
     }
 }
 
+// ... from the digits the pass before left beside the records
+__global__ __launch_bounds__(kRsHistThreads) void rs_hist_dig(const uint16_t *dig, uint32_t n, uint32_t wbits, uint32_t *hist, uint32_t *dtot)
+{
+    __shared__ uint32_t s_h[1 << kRsMaxW];
+    const uint32_t tid = threadIdx.x, bins = 1u << wbits, tile = blockIdx.x;
+    for (uint32_t d = tid; d < bins; d += kRsHistThreads) s_h[d] = 0;
+    __syncthreads();
+    static_assert(kRsTile == kRsHistThreads * 4, "four digits (one 8-byte load) per thread");
+    const uint32_t i = tile * kRsTile + tid * 4u;
+    if (i + 3u < n) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(dig + i);
+        atomicAdd(&s_h[v.x & 0xFFFFu], 1u);
+        atomicAdd(&s_h[v.x >> 16], 1u);
+        atomicAdd(&s_h[v.y & 0xFFFFu], 1u);
+        atomicAdd(&s_h[v.y >> 16], 1u);
+    } else {
+        for (uint32_t j = i; j < n; ++j) atomicAdd(&s_h[dig[j]], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < bins; d += kRsHistThreads) {
+        const uint32_t c = s_h[d];
+        hist[(size_t)tile * bins + d] = c;
+        if (dtot && c) atomicAdd(&dtot[(tile % kRsDtotCopies) * bins + d], c);
+    }
+}
+
 // exclusive scan over a workgroup of 1024 threads (x: the thread's value); s_w: [16]
 __device__ __forceinline__ uint32_t rs_block_exscan_1024(uint32_t x, uint32_t *s_w)
 {
@@ -132,13 +159,19 @@ __global__ __launch_bounds__(1024) void rs_offsets_small(uint32_t *hist, uint32_
 {
     __shared__ uint32_t s_w[16], s_base[1 << kRsMaxW], s_seg[16][64];
     const uint32_t tid = threadIdx.x, bins = 1u << wbits;
-    uint32_t tot = 0;
-    if (tid < bins) {
+    // the digits' bases: exclusive scan of the digit totals, two consecutive digits per thread when there are 2048
+    const uint32_t dp = bins > 1024u ? 2u : 1u;
+    uint32_t tot[2] = {0, 0};
+    for (uint32_t j = 0; j < dp; ++j) {
+        const uint32_t d = tid * dp + j;
+        if (d < bins) {
 #pragma unroll
-        for (int c = 0; c < kRsDtotCopies; ++c) tot += dtot[c * bins + tid];
+            for (int c = 0; c < kRsDtotCopies; ++c) tot[j] += dtot[c * bins + d];
+        }
     }
-    const uint32_t ex = rs_block_exscan_1024(tot, s_w);
-    if (tid < bins) s_base[tid] = ex;
+    const uint32_t ex = rs_block_exscan_1024(tot[0] + tot[1], s_w);
+    if (tid * dp < bins) s_base[tid * dp] = ex;
+    if (dp == 2u && tid * 2u + 1u < bins) s_base[tid * 2u + 1u] = ex + tot[0];
     const uint32_t seg = tid >> 6, dl = tid & 63u, d = blockIdx.x * 64u + dl;
     const uint32_t per = (nb + 15u) / 16u, t_lo = min(nb, seg * per), t_hi = min(nb, t_lo + per);
     const bool on = d < bins;
@@ -159,41 +192,27 @@ __global__ __launch_bounds__(1024) void rs_offsets_small(uint32_t *hist, uint32_
 
 // more tiles: column sums per chunk of kRsChunk tiles, one block for the chunks' running sums and the digits' bases, the
 // offsets written back per chunk
-__global__ __launch_bounds__(256) void rs_col_reduce(const uint32_t *hist, uint32_t nb, uint32_t wbits, uint32_t *partial /* [chunks][bins] */)
+// (the chunks' sums then go through rs_offsets_small as if they were tiles -- a few hundred of them: the digit totals by one
+// atomic per chunk and digit)
+__global__ __launch_bounds__(256) void rs_col_reduce(const uint32_t *hist, uint32_t nb, uint32_t wbits, uint32_t *partial /* [chunks][bins] */,
+                                                     uint32_t *dtot /* [kRsDtotCopies][bins], zero on entry */)
 {
     const uint32_t bins = 1u << wbits, c = blockIdx.x, t0 = c * kRsChunk, t1 = min(nb, t0 + kRsChunk);
     for (uint32_t d = threadIdx.x; d < bins; d += 256u) {
-        uint32_t s = 0;
-        for (uint32_t t = t0; t < t1; ++t) s += hist[(size_t)t * bins + d];
+        uint32_t v[kRsChunk], s = 0;
+#pragma unroll
+        for (int j = 0; j < kRsChunk; ++j) v[j] = t0 + j < t1 ? hist[(size_t)(t0 + j) * bins + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < kRsChunk; ++j) s += v[j];
         partial[(size_t)c * bins + d] = s;
+        if (s) atomicAdd(&dtot[(c % kRsDtotCopies) * bins + d], s);
     }
 }
-__global__ __launch_bounds__(1024) void rs_col_spine(uint32_t *partial, uint32_t nchunk, uint32_t wbits, uint32_t *base /* [bins] */)
-{
-    __shared__ uint32_t s_w[16];
-    const uint32_t tid = threadIdx.x, bins = 1u << wbits;
-    uint32_t run = 0;
-    if (tid < bins) {
-        constexpr uint32_t kHold = 8;
-        for (uint32_t c0 = 0; c0 < nchunk; c0 += kHold) {
-            uint32_t v[kHold];
-#pragma unroll
-            for (uint32_t j = 0; j < kHold; ++j) v[j] = c0 + j < nchunk ? partial[(size_t)(c0 + j) * bins + tid] : 0u;
-#pragma unroll
-            for (uint32_t j = 0; j < kHold; ++j) {
-                if (c0 + j < nchunk) partial[(size_t)(c0 + j) * bins + tid] = run;
-                run += v[j];
-            }
-        }
-    }
-    const uint32_t ex = rs_block_exscan_1024(run, s_w);
-    if (tid < bins) base[tid] = ex;
-}
-__global__ __launch_bounds__(256) void rs_col_apply(uint32_t *hist, uint32_t nb, uint32_t wbits, const uint32_t *partial, const uint32_t *base)
+__global__ __launch_bounds__(256) void rs_col_apply(uint32_t *hist, uint32_t nb, uint32_t wbits, const uint32_t *partial /* the chunks' offsets */)
 {
     const uint32_t bins = 1u << wbits, c = blockIdx.x, t0 = c * kRsChunk, t1 = min(nb, t0 + kRsChunk);
     for (uint32_t d = threadIdx.x; d < bins; d += 256u) {
-        uint32_t run = partial[(size_t)c * bins + d] + base[d];
+        uint32_t run = partial[(size_t)c * bins + d];
         uint32_t v[kRsChunk];
 #pragma unroll
         for (int j = 0; j < kRsChunk; ++j) v[j] = t0 + j < t1 ? hist[(size_t)(t0 + j) * bins + d] : 0u;
@@ -205,35 +224,44 @@ __global__ __launch_bounds__(256) void rs_col_apply(uint32_t *hist, uint32_t nb,
     }
 }
 
-// stable scatter of one digit (bits [shift, shift + wbits) of the key, wbits <= WB); hist holds the offsets
+// stable scatter of one digit (bits [shift, shift + wbits) of the key, wbits <= WB); hist holds the offsets.
+// 512 threads = 8 waves, 8 marks per thread.  Each wave ranks its 512 marks on its own: ballot match inside the wave, then ONE
+// returning LDS add per round by the digit's first lane into the wave's counter row (two 16-bit counters per word) -- the adds
+// of a wave reach the LDS in program order, so the sixteen-deep read-bump-write chain of the key sort's scatter is gone and
+// the rounds' LDS trips overlap; the other lanes of the digit fetch the leader's answer with a bpermute.  The tile is then
+// laid out digit-sorted in LDS, 2048 records at a time IN THE COUNTERS' SPACE (they are dead by then: 36 KB per workgroup at
+// 10-bit digits, four workgroups per CU), and written from there: consecutive lanes hold consecutive records of one digit run.
+// dig_out (or null): the NEXT pass's digit of every record, at the record's new position -- that pass's histogram then reads
+// two bytes per mark instead of sixteen.
 template <int WB, bool RAW>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const uint4 *in, uint32_t n, uint32_t shift, uint32_t wbits, uint32_t nb,
-                                                         const uint32_t *hist, uint4 *out, uint32_t *dtot)
+                                                         const uint32_t *hist, uint4 *out, uint32_t *dtot, uint32_t swz, uint16_t *dig_out,
+                                                         uint32_t next_shift, uint32_t next_mask)
 {
-    constexpr int BINS = 1 << WB, kWaves = kRsThreads / 64, kPerWave = kRsTile / kWaves, DPT = BINS / kRsThreads > 0 ? BINS / kRsThreads : 1;
-    static_assert(BINS >= kRsThreads, "a thread per digit at least");
-    __shared__ uint4 s_rec[kRsTile];
-    __shared__ uint32_t s_gbase[BINS];                     // global position of the tile's first mark of each digit
-    __shared__ uint16_t s_start[BINS];                     // where each digit starts inside the tile
-    __shared__ uint16_t s_wloc[kWaves][BINS];              // per wave: marks of each digit so far; then the wave's offset
+    constexpr int BINS = 1 << WB, WORDS = BINS / 2, kWaves = kRsThreads / 64, kPerWave = kRsTile / kWaves, DPT = BINS / kRsThreads;
+    constexpr int kStage = 2048, kRounds = kRsTile / kStage;
+    static_assert(DPT >= 2 && DPT % 2 == 0, "a thread takes whole counter words");
+    constexpr size_t kCntBytes = (size_t)kWaves * WORDS * 4 + (size_t)BINS * 2, kStageBytes = (size_t)kStage * 16;
+    __shared__ __align__(16) unsigned char s_raw[kCntBytes > kStageBytes ? kCntBytes : kStageBytes];
+    __shared__ uint32_t s_gadj[BINS];                      // global position of the tile's first mark of each digit - the digit's start inside the tile
     __shared__ uint32_t s_wsum[kWaves];
+    uint32_t(*s_wloc)[WORDS] = reinterpret_cast<uint32_t(*)[WORDS]>(s_raw);              // per wave: marks of each digit so far; then the wave's offset
+    uint16_t *s_start = reinterpret_cast<uint16_t *>(s_raw + (size_t)kWaves * WORDS * 4);  // where each digit starts inside the tile
+    uint4 *s_rec = reinterpret_cast<uint4 *>(s_raw);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, bins = 1u << wbits, dmask = bins - 1u;
-    const uint32_t tile = rs_tile_of(blockIdx.x, nb);
-    for (uint32_t d = tid; d < (uint32_t)BINS; d += kRsThreads) {
-        s_gbase[d] = d < bins ? hist[(size_t)tile * bins + d] : 0u;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) s_wloc[w][d] = 0;
-    }
-    __syncthreads();
+    const uint32_t tile = swz ? rs_tile_of(blockIdx.x, nb) : blockIdx.x;
+    for (uint32_t d = tid; d < (uint32_t)BINS; d += kRsThreads) s_gadj[d] = d < bins ? hist[(size_t)tile * bins + d] : 0u;
+    for (uint32_t w = tid; w < (uint32_t)(kWaves * WORDS); w += kRsThreads) (&s_wloc[0][0])[w] = 0;
     const uint32_t base = tile * kRsTile, wbase = base + wave * kPerWave;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint4 rec[kRsItems];
-    uint16_t lrank[kRsItems];
+    uint32_t q[kRsItems];
 #pragma unroll
     for (int it = 0; it < kRsItems; ++it) {
         const uint32_t i = wbase + it * 64 + lane;
         rec[it] = i < n ? (RAW ? rs_make(src, i) : in[i]) : make_uint4(0u, 0u, 0u, 0u);
     }
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < kRsItems; ++it) {
         const bool valid = wbase + it * 64 + lane < n;
@@ -246,11 +274,10 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const 
             same &= bit ? bm : ~bm;
         }
         const uint32_t rank = (uint32_t)__popcll(same & lt);
-        const uint32_t seen = s_wloc[wave][d];
-        lrank[it] = (uint16_t)(seen + rank);
-        __builtin_amdgcn_wave_barrier();                   // every lane has read the count before its leader bumps it
-        if (valid && rank == 0) s_wloc[wave][d] = (uint16_t)(seen + (uint32_t)__popcll(same));
-        __builtin_amdgcn_wave_barrier();
+        uint32_t seen = 0;
+        if (valid && rank == 0) seen = (atomicAdd(&s_wloc[wave][d >> 1], (uint32_t)__popcll(same) << ((d & 1u) * 16u)) >> ((d & 1u) * 16u)) & 0xFFFFu;
+        seen = (uint32_t)__shfl((int)seen, valid ? (int)__ffsll((long long)same) - 1 : (int)lane, 64);
+        q[it] = seen + rank;
     }
     __syncthreads();
     // digit starts inside the tile (exclusive scan of the digit totals, DPT consecutive digits per thread) and, per wave, the
@@ -258,17 +285,19 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const 
     {
         uint32_t tot[DPT], sum = 0;
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) {
-            const uint32_t d = tid * DPT + j;
-            uint32_t t = 0;
+        for (int j = 0; j < DPT; j += 2) {
+            const uint32_t wd = (tid * DPT + j) >> 1;
+            uint32_t t0 = 0, t1 = 0;
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) {
-                const uint32_t c = s_wloc[w][d];
-                s_wloc[w][d] = (uint16_t)t;
-                t += c;
+                const uint32_t c = s_wloc[w][wd];
+                s_wloc[w][wd] = t0 | (t1 << 16);
+                t0 += c & 0xFFFFu;
+                t1 += c >> 16;
             }
-            tot[j] = t;
-            sum += t;
+            tot[j] = t0;
+            tot[j + 1] = t1;
+            sum += t0 + t1;
         }
         uint32_t x = sum;
 #pragma unroll
@@ -282,28 +311,38 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const 
         for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
 #pragma unroll
         for (int j = 0; j < DPT; ++j) {
-            s_start[tid * DPT + j] = (uint16_t)run;
+            const uint32_t d = tid * DPT + j;
+            s_start[d] = (uint16_t)run;
+            s_gadj[d] -= run;                              // (mod 2^32: the sum below comes out right)
             run += tot[j];
         }
         __syncthreads();
     }
 #pragma unroll
     for (int it = 0; it < kRsItems; ++it) {
-        if (wbase + it * 64 + lane < n) {
-            const uint32_t d = (uint32_t)(rs_key(rec[it], src.centre_bits, src.idx_bits) >> shift) & dmask;
-            s_rec[(uint32_t)s_start[d] + (uint32_t)s_wloc[wave][d] + (uint32_t)lrank[it]] = rec[it];
-        }
+        const uint32_t d = (uint32_t)(rs_key(rec[it], src.centre_bits, src.idx_bits) >> shift) & dmask;
+        q[it] += (uint32_t)s_start[d] + ((s_wloc[wave][d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu);
     }
-    __syncthreads();
+    __syncthreads();                                       // the counters are dead: their space takes the records
     const uint32_t count = min((uint32_t)kRsTile, n - base);
 #pragma unroll
-    for (int it = 0; it < kRsItems; ++it) {
-        const uint32_t q = it * kRsThreads + tid;
-        if (q < count) {
-            const uint4 r = s_rec[q];
-            const uint32_t d = (uint32_t)(rs_key(r, src.centre_bits, src.idx_bits) >> shift) & dmask;
-            out[s_gbase[d] + (q - (uint32_t)s_start[d])] = r;
+    for (int h = 0; h < kRounds; ++h) {
+#pragma unroll
+        for (int it = 0; it < kRsItems; ++it)
+            if (wbase + it * 64 + lane < n && (q[it] / kStage) == (uint32_t)h) s_rec[q[it] % kStage] = rec[it];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kStage / kRsThreads; ++k) {
+            const uint32_t pq = k * kRsThreads + tid, gq = h * kStage + pq;
+            if (gq < count) {
+                const uint4 r = s_rec[pq];
+                const uint64_t key = rs_key(r, src.centre_bits, src.idx_bits);
+                const uint32_t at = s_gadj[(uint32_t)(key >> shift) & dmask] + gq;
+                out[at] = r;
+                if (dig_out) dig_out[at] = (uint16_t)((uint32_t)(key >> next_shift) & next_mask);
+            }
         }
+        __syncthreads();
     }
     // rs_offsets_small is done with the totals: zero again for the next pass
     if (dtot && blockIdx.x < (uint32_t)kRsDtotCopies)
