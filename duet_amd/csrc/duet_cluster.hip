@@ -87,6 +87,7 @@ struct ClParams {
     uint32_t mergeable;                               // max_dist >= 0
     uint32_t tps;                                     // scan tiles per work-list shard (kShards shards of consecutive tiles)
     uint32_t gather_rows;                             // this launch reads its rows through the sort permutation (no cl_box before it)
+    uint32_t sym;                                     // one-partition-per-wave units evaluate every unordered pair once (0: DUET_DBG_CLUSTER_NOSYM, the column loop)
     // fused SVIM-mode pipeline (all null otherwise): cl_emit also writes the columns ef_classify reads
     const uint32_t *sv_mark_in, *sv_depth, *sv_depth_off;
     uint32_t sv_depth_bin;
@@ -507,20 +508,38 @@ constexpr int kBoxThreads = 256;
 constexpr int kBoxHalo = 128;                      // a partition has at most 128 marks: the last one of a tile ends within the halo
 // REC: the sort carried the records -- the tile's rows are p.srec[t0 ...] as they lie (no permutation, no gather), and the rows of
 // the partitions left open stay where they are for the agglomeration kernels
-template <bool REC>
+// APPLY (large inputs): the launch is also the partition scan's last stage -- it takes the tile's carry from part_spine and the head
+// flags part_reduce left, numbers the partitions that start in its tile itself and writes their starts (what part_apply does
+// for small inputs): no launch in between, and the tile's records leave together with the carry and the flags instead of
+// behind two dependent round trips (first partition of the tile -> its partitions' starts).
+template <bool REC, bool APPLY>
 __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const uint32_t *tile_first, uint32_t *lists /* [kClasses][M] */,
-                                                      uint32_t *counts /* [kClasses][kShards] */)
+                                                      uint32_t *counts /* [kClasses][kShards] */, const uint8_t *hbits, const PartSum *tiles,
+                                                      uint32_t *part_start_out, uint32_t *n_parts_out)
 {
     __shared__ uint32_t s_pos[kScanTile + kBoxHalo], s_span[kScanTile + kBoxHalo];
     __shared__ uint32_t s_ps[kScanTile + 2];               // starts of the tile's partitions (+ the end of the last one)
     __shared__ uint8_t s_done[kScanTile];                  // per partition of the tile: finished here
     __shared__ uint16_t s_pix[kScanTile + kBoxHalo];       // per position: its partition (index within the tile's partitions)
     __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
+    __shared__ PartSum s_w[kBoxThreads / 64 + 1];
+    __shared__ uint32_t s_first, s_count, s_next;
+    static_assert(!APPLY || (kBoxThreads == kScanThreads && kBoxHalo == 128), "the scan's thread layout; a partition ends within the halo");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, tile = blockIdx.x;
     const uint32_t t0 = tile * kScanTile, shard = tile / p.tps;
-    const uint32_t p_lo = tile_first[tile], p_hi = tile_first[tile + 1], np = p_hi - p_lo;
+    uint32_t p_lo = 0, np = 0;
     if (tid < kClasses) s_cnt[tid] = 0;
-    for (uint32_t j = tid; j <= np; j += kBoxThreads) s_ps[j] = p.part_start[p_lo + j];
+    uint32_t hb = 0;
+    PartSum carry{kNoHead, 0, 0};
+    if (APPLY) {
+        hb = hbits[t0 / kScanItems + tid];
+        carry = tiles[tile];
+        if (tid == 0) { s_first = 0xFFFFFFFFu; s_count = 0; }
+    } else {
+        p_lo = tile_first[tile];
+        np = tile_first[tile + 1] - p_lo;
+        for (uint32_t j = tid; j <= np; j += kBoxThreads) s_ps[j] = p.part_start[p_lo + j];
+    }
     // the marks' (pos, span), gathered through the sort permutation; each thread keeps its eight positions' mark indices
     // (and read indices) for the stores at the end.  Two rounds of loads, each round's loads side by side (the branches on the
     // layout are hoisted: with them inside, every position waited for its own two round trips in turn -- 30 us per tile)
@@ -564,6 +583,78 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
         }
         if (tid < kBoxHalo && t0 + kScanTile + tid < p.M) { s_pos[kScanTile + tid] = ps_[kScanItems]; s_span[kScanTile + tid] = sp_[kScanItems]; }
     }
+    if (APPLY) {
+        // the partitions that start in this tile: part_apply's walk, the starts into s_ps (and out to part_start[])
+        const uint32_t n = p.M, pm = p.part_max, base = t0 + tid * kScanItems;
+        bool head[kScanItems];
+        PartSum acc{kNoHead, 0, 0};
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            head[j] = (hb >> j) & 1u;
+            if (head[j]) acc = part_combine(acc, PartSum{base + j, base + j, 0}, pm);
+        }
+        const PartSum before = part_block_exscan<kBoxThreads>(acc, pm, s_w);      // (synchronises)
+        const PartSum st = part_combine(carry, before, pm);
+        const uint32_t H0 = st.f == kNoHead ? 0u : st.l, P0 = st.f == kNoHead ? 0u : st.s;
+        uint32_t H = H0, P = P0, mine = 0, first = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            const uint32_t i = base + j;
+            if (i >= n) break;
+            if (head[j]) {
+                if (i) P += parts_in(i - H, pm);
+                H = i;
+            }
+            const uint32_t d = i - H, q = d < pm ? 0u : d / pm;
+            if (d == q * pm) {
+                first = min(first, P + q);
+                ++mine;
+            }
+            if (i == n - 1) {
+                part_start_out[P + q + 1] = n;
+                *n_parts_out = P + q + 1;
+            }
+        }
+        if (mine) {
+            atomicMin(&s_first, first);
+            atomicAdd(&s_count, mine);
+        }
+        // the end of the tile's last partition: the next natural start among the 128 positions behind the tile, the next multiple
+        // of part_max in the running natural partition, or the end of the marks
+        if (tid == kBoxThreads - 1) {
+            const uint32_t e = min(t0 + (uint32_t)kScanTile, n);                 // first position behind the tile
+            uint32_t nx = n;
+            if (e < n) {
+                const uint32_t d = e - H;                                         // (H: the natural start in force at the tile's last position)
+                nx = min(nx, H + ((d + pm - 1u) / pm) * pm);
+                const uint4 hw = *reinterpret_cast<const uint4 *>(hbits + e / kScanItems);   // (e is a multiple of 2048: 16-byte aligned)
+                const uint32_t w4[4] = {hw.x, hw.y, hw.z, hw.w};
+#pragma unroll
+                for (int k = 3; k >= 0; --k)
+                    if (w4[k]) nx = min(nx, e + 32u * k + (uint32_t)__ffs((int)w4[k]) - 1u);
+            }
+            s_next = nx;
+        }
+        __syncthreads();
+        p_lo = s_first;
+        np = s_count;
+        H = H0; P = P0;
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            const uint32_t i = base + j;
+            if (i >= n) break;
+            if (head[j]) {
+                if (i) P += parts_in(i - H, pm);
+                H = i;
+            }
+            const uint32_t d = i - H, q = d < pm ? 0u : d / pm;
+            if (d == q * pm) {
+                s_ps[P + q - p_lo] = i;
+                part_start_out[P + q] = i;
+            }
+        }
+        if (tid == 0) s_ps[np] = s_next;
+    }
     __syncthreads();
     // one thread per partition
     for (uint32_t j0 = 0; j0 < np; j0 += kBoxThreads) {
@@ -593,7 +684,10 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             s_done[j] = one ? 1 : 0;
             if (one) {
                 // (floor means: see emit_prep)
-                p.e_rec[s] = make_uint4(0u | (n << 8), (uint32_t)((double)sum_p / (double)n), (uint32_t)((double)sum_s / (double)n), 0u);
+                // (w: contig | type where the sort carried the records -- the tile's rows have just been read, this word is in
+                // cache; cl_emit then needs nothing of a partition but its cluster records)
+                p.e_rec[s] = make_uint4(0u | (n << 8), (uint32_t)((double)sum_p / (double)n), (uint32_t)((double)sum_s / (double)n),
+                                        REC ? p.srec[s].w >> p.idx_bits : 0u);
                 p.pc[p_lo + j] = 1;
             } else {
                 cls = size_class(n);
@@ -784,7 +878,7 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
                 // lies strictly between the same two integers as the true one (or is that integer): no 64-bit division
                 const uint32_t ci = heads.count_below(rt[r]);
                 p.e_rec[s + ci] = make_uint4(rank | ((before[r] + size) << 8), (uint32_t)((double)s_sum[k][0] / (double)size),
-                                             (uint32_t)((double)s_sum[k][1] / (double)size), 0u);
+                                             (uint32_t)((double)s_sum[k][1] / (double)size), p.rec_mode ? p.srec[s].w >> p.idx_bits : 0u);
             }
         }
     }
@@ -1574,11 +1668,74 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
 #pragma unroll
         for (int r = 0; r < R; ++r) ambr[r] = false;
     };
+    // One partition per wave, one row per lane: every UNORDERED pair once.  In step t row i looks at row i + t (mod n), and what
+    // it finds is also row i + t's result for row i - t': the compare results are lane masks, and rotating such a mask by t
+    // within the partition's n bits hands every lane the result of the pair that ends at it -- on the scalar unit, nothing
+    // crosses lanes.  Both results enter the lanes' masks in "rotated" order (one add-with-carry each: mask = 2 mask + bit) and
+    // are turned to column order once at the end.  n / 2 steps of ~33 vector instructions where the column loop below takes
+    // n steps of 34 (the binary32 expressions are symmetric in the two rows, so both rows get the same answer, guard band
+    // included).
+    auto sym_pass = [&]() {
+        static_assert(GROUP != 64 || R != 1 || NW == 1, "one mask word");
+        const uint32_t n_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)na);
+        if (n_s < 2u) return;
+        const uint32_t half = n_s >> 1;
+        const bool actv = lane < n_s;
+        const unsigned long long nmask = n_s >= 64u ? ~0ull : (1ull << n_s) - 1ull;
+        uint32_t o0 = 0, o1 = 0, o2 = 0, r0 = 0, r1 = 0, r2 = 0;
+        unsigned long long amb_all = 0;
+        auto push = [](uint32_t x, unsigned long long bit_of_lane) -> uint32_t {     // 2 x + (this lane's bit of the mask)
+            uint32_t d;
+            asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(d) : "v"(x), "s"(bit_of_lane) : "vcc");
+            return d;
+        };
+        uint32_t j = lane;
+        for (uint32_t t = 1; t <= half; ++t) {
+            j += 1u;
+            j = j >= n_s ? j - n_s : j;
+            const uint4 q = S.ps[sub][actv ? j : 0u];
+            const uint32_t m = min(min(absdiff_u32(pk[0], q.x), absdiff_u32(ek[0], q.z)), absdiff_u32(ck[0], q.w));
+            // (a lane without a row compares against NaN bounds: false on every level, so the masks hold bits of rows only and
+            // a rotation brings nothing in from beyond them)
+            const float fm = actv ? (float)max(max(spk[0], q.y), 1u) : __builtin_nanf(""), fs = (float)absdiff_u32(spk[0], q.y);
+            const float dp = (float)m * p.inv_norm;
+            const float2v dp2 = {dp, dp}, fm2 = {fm, fm};
+            const float2v b0 = (p.t_hl[0] - dp2) * fm2, b1 = (p.t_hl[1] - dp2) * fm2, b2 = (p.t_hl[2] - dp2) * fm2;
+            const unsigned long long m0 = __ballot(fs <= b0.x), m1 = __ballot(fs <= b1.x), m2 = __ballot(fs <= b2.x);
+            // inside a guard band: the two bounds of a level disagree (scalar arithmetic on the lane masks)
+            const unsigned long long am = (m0 ^ __ballot(fs <= b0.y)) | (m1 ^ __ballot(fs <= b1.y)) | (m2 ^ __ballot(fs <= b2.y));
+            // (bits at n and beyond are not looked at: the lanes there have no row)
+            auto rot = [&](unsigned long long x) -> unsigned long long { return (x << t) | (x >> (n_s - t)); };              // (0 < t < n)
+            amb_all |= am | rot(am);
+            o0 = push(o0, m0); o1 = push(o1, m1); o2 = push(o2, m2);
+            r0 = push(r0, rot(m0)); r1 = push(r1, rot(m1)); r2 = push(r2, rot(m2));
+        }
+        // step t sits at bit half - t of both masks; own: column i + t, received: column i - t (mod n)
+        auto columns = [&](uint32_t o, uint32_t r) -> uint64_t {
+            const uint64_t X = (uint64_t)(__builtin_bitreverse32(o) >> (32u - half)) << 1;      // bit t: step t
+            const uint64_t Y = (uint64_t)r << (n_s - half);                                       // bit n - t: step t
+            const uint64_t Z = X | Y;
+            const uint64_t A = lane == 0u ? Z : ((Z << lane) | (Z >> ((n_s - lane) & 63u)));
+            return actv ? A & nmask : 0ull;
+        };
+        N0[0].w[0] = columns(o0, r0);
+        g1[0].w[0] = columns(o1, r1);
+        g2[0].w[0] = columns(o2, r2);
+        ambr[0] = actv && ((amb_all >> lane) & 1ull) != 0ull;
+    };
     using T_ = std::true_type;
     using F_ = std::false_type;
     BitSet<NW> nocols;
     nocols.clear();
-    if constexpr (kOnePass) {
+    constexpr bool kSym = GROUP == 64 && R == 1;
+    if constexpr (kSym) {
+        if (p.sym) {
+            sym_pass();
+        } else {
+            all_words(T_{}, T_{}, nocols);
+        }
+        exact_rows(T_{}, T_{}, row, nocols);
+    } else if constexpr (kOnePass) {
         all_words(T_{}, T_{}, nocols);
         exact_rows(T_{}, T_{}, row, nocols);
     } else {
@@ -1981,54 +2138,58 @@ __global__ __launch_bounds__(64) void cl_link_one(const ClParams p, const uint32
         fast_unit<GROUP, R, NCAP, kLinkOnly>(p, list, base, smem, smem_link);
 }
 
-// one thread per partition (their count lives on the device: launched over an upper bound): its clusters' records, dense from the
-// partition's start, become the candidates cbase[part] ...; neighbouring partitions write neighbouring candidates
-__global__ void cl_emit(const ClParams p)
+// One LANE PER CLUSTER: a wavefront takes 64 consecutive partitions (their count lives on the device: the grid strides over an upper
+// bound), and their clusters -- records dense from each partition's start, candidates cbase[part] ... -- are dealt to the lanes
+// 64 at a time: a lane finds its cluster's partition among the wave's 64 by bisection over the lanes' candidate bases (six
+// bpermutes, no memory), loads the record and the depth bin it selects, and writes its candidate -- neighbouring lanes write
+// neighbouring candidates, and a partition of ten clusters costs what one of one does (round 3: one thread per partition
+// walking its clusters four at a time, 76 us at 2e7 marks).
+__global__ __launch_bounds__(256) void cl_emit(const ClParams p)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) p.cand_off[0] = 0;
-    const uint32_t n_parts = *p.n_parts;
-    // (a grid of a fraction of the bound -- the marks -- strides over the partitions: see cl_classes)
-    for (uint32_t part = blockIdx.x * blockDim.x + threadIdx.x; part < n_parts; part += gridDim.x * blockDim.x) {
-        const uint32_t s = p.part_start[part], nc = p.pc[part], c0 = p.cbase[part];
-        const uint64_t hi = p.rec_mode ? (uint64_t)(p.srec[s].w >> p.idx_bits)
-                                       : (p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits;           // contig | type, straight from the sorted key / record
-        const uint32_t k = (uint32_t)(hi >> p.type_bits), type = (uint32_t)(hi & ((1ull << p.type_bits) - 1ull));
-        uint32_t d_lo = 0, nb = 0;
-        if (p.sv_svread) {
-            d_lo = p.sv_depth_off[k];
-            nb = p.sv_depth_off[k + 1] - d_lo;
-        }
-        // four clusters at a time, their loads side by side: records first, then the depth bins the records' positions select
-        // (one cluster per trip made a partition's clusters queue behind each other's two round trips)
-        for (uint32_t cb = 0; cb < nc; cb += 4) {
-            uint4 rec[4];
-            uint32_t d[4];
+    const uint32_t n_parts = *p.n_parts, lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t b0 = wave * 64u; b0 < n_parts; b0 += n_waves * 64u) {
+        const uint32_t part = b0 + lane;
+        const bool has = part < n_parts;
+        const uint32_t s = has ? p.part_start[part] : 0u, nc = has ? p.pc[part] : 0u, c0 = has ? p.cbase[part] : 0u;
+        uint32_t hi = 0;                                        // contig | type: in the cluster records (record sort), else from the sorted key
+        if (has && !p.rec_mode) hi = (uint32_t)((p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits);
+        const uint32_t base = (uint32_t)__shfl((int)c0, 0, 64);
+        const uint32_t n_has = min(64u, n_parts - b0);
+        const uint32_t tot = (uint32_t)__shfl((int)(c0 + nc), (int)n_has - 1, 64) - base;
+        const uint32_t rel = has ? c0 - base : 0xFFFFFFFFu;     // (ascending over the lanes: every partition has a cluster)
+        for (uint32_t k0 = 0; k0 < tot; k0 += 64u) {
+            const uint32_t c = k0 + lane;
+            uint32_t lo = 0;                                    // the last lane whose first cluster is <= c
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rec[j] = p.e_rec[s + min(cb + j, nc - 1u)];
-            if (p.sv_svread) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t bin = rec[j].y / p.sv_depth_bin;
-                    bin = bin < nb ? bin : nb - 1;
-                    d[j] = nb ? p.sv_depth[d_lo + bin] : 0u;
-                }
+            for (int step = 32; step > 0; step >>= 1) {
+                const uint32_t at = lo + (uint32_t)step;
+                const uint32_t v = (uint32_t)__shfl((int)rel, (int)min(at, 63u), 64);
+                lo = (at < 64u && v <= c) ? at : lo;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (cb + j >= nc) break;
-                const uint32_t info = rec[j].x, cand = c0 + cb + j;
-                p.cand_off[cand + 1] = s + (info >> 8);
-                p.cand_contig[cand] = (uint16_t)k;
-                p.cand_type[cand] = (uint8_t)type;
-                p.cand_pos[cand] = rec[j].y;
-                p.cand_span[cand] = rec[j].z;
-                if (p.sv_svread) {
-                    // what a caller VCF would have carried: support = members, reference reads = depth(contig, pos) - support
-                    const uint32_t support = (info >> 8) - (info & 0xFFu);                  // a cluster's end - its first member's rank
-                    p.sv_svread[cand] = support;
-                    p.sv_refread[cand] = d[j] > support ? d[j] - support : 0u;
-                    p.sv_gt[cand] = 1;
-                }
+            const uint32_t ps = (uint32_t)__shfl((int)s, (int)lo, 64), pr = (uint32_t)__shfl((int)rel, (int)lo, 64);
+            const uint32_t ph = (uint32_t)__shfl((int)hi, (int)lo, 64);
+            if (c >= tot) continue;
+            const uint4 rec = p.e_rec[ps + (c - pr)];
+            const uint32_t ct = p.rec_mode ? rec.w : ph;
+            const uint32_t k = ct >> p.type_bits, type = ct & ((1u << p.type_bits) - 1u);
+            const uint32_t info = rec.x, cand = base + c;
+            p.cand_off[cand + 1] = ps + (info >> 8);
+            p.cand_contig[cand] = (uint16_t)k;
+            p.cand_type[cand] = (uint8_t)type;
+            p.cand_pos[cand] = rec.y;
+            p.cand_span[cand] = rec.z;
+            if (p.sv_svread) {
+                // what a caller VCF would have carried: support = members, reference reads = depth(contig, pos) - support
+                const uint32_t d_lo = p.sv_depth_off[k], nb = p.sv_depth_off[k + 1] - d_lo;
+                uint32_t bin = rec.y / p.sv_depth_bin;
+                bin = bin < nb ? bin : nb - 1;
+                const uint32_t d = nb ? p.sv_depth[d_lo + bin] : 0u;
+                const uint32_t support = (info >> 8) - (info & 0xFFu);                  // a cluster's end - its first member's rank
+                p.sv_svread[cand] = support;
+                p.sv_refread[cand] = d > support ? d - support : 0u;
+                p.sv_gt[cand] = 1;
             }
         }
     }
@@ -2204,6 +2365,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t top_shift = hybrid ? key_bits - top_bits : 0u;
     uint32_t *big_count = scal + 40, *big_list = valsA;          // (the value buffers are idle when the index rides in the key)
     const uint32_t loc_cap = (ctx->dbg & DUET_DBG_CLUSTER_SMALLCAP) ? 3u : (uint32_t)kLocHalo;
+    // large inputs, record sort: cl_box is also the partition scan's last stage (no part_apply launch)
+    const bool box_applies = rec_mode && (!small_in || big_sort) && !getenv("DUET_NO_BOX_APPLY");
     PartSum *tiles = (PartSum *)tmpA;                             // the partition scan's tile summaries: 3 words per 2048 marks
     uint8_t *hbits = (uint8_t *)tmpA + ((((size_t)nb_sc + 1) * sizeof(PartSum) + 15) & ~(size_t)15);      // ... and the head flags, a bit per mark
     p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
@@ -2265,8 +2428,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
                                part_start, scal, tile_first);
         } else {
             hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
-            hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
-                               part_start, scal, tile_first);
+            if (!box_applies)
+                hipLaunchKernelGGL(part_apply<false>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+                                   part_start, scal, tile_first);
         }
     } else {
     hipLaunchKernelGGL(cl_keys, dim3(nb_rx), dim3(kRxHistThreads), 0, st, p, keysA, valsA, (uint2 *)recs, (uint4 *)recs, top_shift,
@@ -2323,17 +2487,19 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.scale = (double)kQOne / pr->max_dist;
     p.mergeable = pr->max_dist >= 0 ? 1u : 0u;
     p.kc = (ctx->dbg & DUET_DBG_CLUSTER_KC2) ? 2u : 64u;
+    p.sym = (ctx->dbg & DUET_DBG_CLUSTER_NOSYM) ? 0u : 1u;
     const uint32_t gridw = std::min(32768u, std::max(1024u, M / 256u));     // (a wavefront per virtual block, striding)
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max
     uint32_t *over = cnts + kClasses * kShards;                  // [kClasses][kShards] the second lists' counters
     uint32_t *l4 = lists + 4 * (size_t)M, *c4 = cnts + 4 * kShards, *o4 = over + 4 * kShards;
     // The partitions of more than 64 marks on the side stream: few, long chains.  They are listed from the partition starts
-    // alone and read their rows through the sort permutation themselves, so their launch starts beside cl_box, not after it
-    // (1.0 M marks: the chain ended 30-40 us after everything else when it started behind cl_box).
-    HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
-    {
+    // alone and read their rows through the sort permutation themselves (or where the record sort left them), so their launch
+    // starts beside cl_box, not after it (1.0 M marks: the chain ended 30-40 us after everything else when it started behind
+    // cl_box) -- except where cl_box itself numbers the partitions (large inputs: the chain is far from critical there).
+    auto launch_big = [&]() -> int {
+        HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
         ClParams pb = p;
         pb.gather_rows = rec_mode ? 0u : 1u;                     // (rec_mode: the sorted rows are there already)
         const uint32_t gb = std::min(4096u, std::max(256u, (M / 64u + 63u) / 64u));      // (partitions <= marks; 64 of them per wavefront and step)
@@ -2342,11 +2508,18 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         if (cap100) hipLaunchKernelGGL((cl_link_one<64, 2, 100>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
         else hipLaunchKernelGGL((cl_link_one<64, 2, 128>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
         HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
-    }
+        return DUET_OK;
+    };
+    if (!box_applies && (rc = launch_big())) return rc;
     const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
-    if (rec_mode) hipLaunchKernelGGL(cl_box<true>, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
-    else hipLaunchKernelGGL(cl_box<false>, dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts);
+    if (box_applies)
+        hipLaunchKernelGGL((cl_box<true, true>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)nullptr, lists, cnts, (const uint8_t *)hbits, (const PartSum *)tiles, part_start, scal);
+    else if (rec_mode)
+        hipLaunchKernelGGL((cl_box<true, false>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts, (const uint8_t *)nullptr, (const PartSum *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    else
+        hipLaunchKernelGGL((cl_box<false, false>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts, (const uint8_t *)nullptr, (const PartSum *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    if (box_applies && (rc = launch_big())) return rc;
     if (!tiers) {
         // one launch for the classes of up to 64 marks, nothing handed on
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
@@ -2374,7 +2547,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
     p.cbase = cbase;
-    hipLaunchKernelGGL(cl_emit, dim3(std::min(g256.x, std::max(1024u, g256.x / 8u))), b256, 0, st, p);
+    hipLaunchKernelGGL(cl_emit, dim3(std::min((M + 16383u) / 16384u * 8u, 4096u)), b256, 0, st, p);        // (a wave per 64 partitions, striding)
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
         uint32_t h[64 + 2 * kClasses * kShards];

@@ -144,6 +144,8 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 #define DUET_DBG_CLUSTER_NOBOX 0x800u   /* A0: no bounding-box test: every partition goes through the threshold-graph pair loops */
 #define DUET_DBG_CLUSTER_KEYSORT 0x10000u /* A0: the key-only sort of rounds 1-3 (8-byte keys, the records gathered through the permutation afterwards)
                                             also where the 16-byte mark record could travel with the key (duet_recsort.hip.h) */
+#define DUET_DBG_CLUSTER_NOSYM 0x20000u  /* A0: the contracted linkage's pair tests column by column (every ordered pair) also where a unit holds one partition and
+                                            could evaluate every unordered pair once */
 #define DUET_DBG_CLUSTER_LSD 0x8000u     /* A0: plain LSD passes over all key bits also where small inputs would sort the low bits locally */
 #define DUET_DBG_CLUSTER_SMALLCAP 0x4000u /* A0: the local sort of the low bits takes groups of at most 3 keys (default 128): the others go to the one-workgroup-per-group path */
 #define DUET_DBG_CLUSTER_TIERS 0x2000u  /* A0: small inputs take the two-tier contracted linkage of large inputs in one launch per tier */
