@@ -512,7 +512,7 @@ constexpr int kBoxHalo = 128;                      // a partition has at most 12
 // flags part_reduce left, numbers the partitions that start in its tile itself and writes their starts (what part_apply does
 // for small inputs): no launch in between, and the tile's records leave together with the carry and the flags instead of
 // behind two dependent round trips (first partition of the tile -> its partitions' starts).
-template <bool REC, bool APPLY>
+template <bool REC, bool APPLY, bool SELF = false>
 __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const uint32_t *tile_first, uint32_t *lists /* [kClasses][M] */,
                                                       uint32_t *counts /* [kClasses][kShards] */, const uint8_t *hbits, const PartSum *tiles,
                                                       uint32_t *part_start_out, uint32_t *n_parts_out)
@@ -529,11 +529,27 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     const uint32_t t0 = tile * kScanTile, shard = tile / p.tps;
     uint32_t p_lo = 0, np = 0;
     if (tid < kClasses) s_cnt[tid] = 0;
+    __shared__ PartSum s_c[kBoxThreads / 64];
     uint32_t hb = 0;
     PartSum carry{kNoHead, 0, 0};
     if (APPLY) {
         hb = hbits[t0 / kScanItems + tid];
-        carry = tiles[tile];
+        if (SELF) {
+            // (small inputs, no spine launch: tiles[] holds the tiles' own summaries and the block combines the ones before it
+            // by itself, thread t a contiguous run of them -- part_apply<true>'s way)
+            const uint32_t nbef = tile, per = (nbef + kBoxThreads - 1) / kBoxThreads;
+            const uint32_t lo = min(nbef, tid * per), hi = min(nbef, lo + per);
+            PartSum c{kNoHead, 0, 0};
+            for (uint32_t t = lo; t < hi; ++t) c = part_combine(c, tiles[t], p.part_max);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const PartSum y = part_shfl_up(c, d);
+                if ((int)lane >= d) c = part_combine(y, c, p.part_max);
+            }
+            if (lane == 63) s_c[tid >> 6] = c;
+        } else {
+            carry = tiles[tile];
+        }
         if (tid == 0) { s_first = 0xFFFFFFFFu; s_count = 0; }
     } else {
         p_lo = tile_first[tile];
@@ -593,7 +609,11 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             head[j] = (hb >> j) & 1u;
             if (head[j]) acc = part_combine(acc, PartSum{base + j, base + j, 0}, pm);
         }
-        const PartSum before = part_block_exscan<kBoxThreads>(acc, pm, s_w);      // (synchronises)
+        const PartSum before = part_block_exscan<kBoxThreads>(acc, pm, s_w);      // (synchronises: s_c is visible after it)
+        if (SELF) {
+#pragma unroll
+            for (int w = 0; w < kBoxThreads / 64; ++w) carry = part_combine(carry, s_c[w], pm);
+        }
         const PartSum st = part_combine(carry, before, pm);
         const uint32_t H0 = st.f == kNoHead ? 0u : st.l, P0 = st.f == kNoHead ? 0u : st.s;
         uint32_t H = H0, P = P0, mine = 0, first = 0xFFFFFFFFu;
@@ -1306,6 +1326,65 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
 // member (<=> every component is a clique).  Everything else gets the exact linkage (link_unit).  Both paths produce
 // the oracle's clusters; tests/test_gpu_cluster.py and tools/stress.py cover both.
 
+// The threshold graph of one (GROUP == 64) or two (GROUP == 32) partitions of a wave with every UNORDERED pair evaluated once
+// (tight_unit's sym_pass has the scheme and its cost): row i looks at row i + t (mod n) in step t, the compare mask rotated by
+// t within the partition's n bits is the result of the pair that ENDS at each lane.  -> this lane's row's neighbours at the
+// threshold as a column mask, and whether any of its pairs sits inside the guard band.  ps: the partition's rows in LDS
+// (pos, span, end, centre); n: this lane's partition's rows (0: none).
+template <int GROUP>
+__device__ __forceinline__ void sym_graph0(const ClParams &p, const uint4 *ps, uint32_t pk, uint32_t spk, uint32_t ek, uint32_t ck, uint32_t n,
+                                           uint32_t sl, uint64_t &cols, bool &amb)
+{
+    static_assert(GROUP == 64 || GROUP == 32, "one or two partitions per wave");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)n, 0), n1 = GROUP == 64 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)n, 32);
+    const uint32_t h0 = n0 >> 1, h1 = n1 >> 1, hmax = max(h0, h1);
+    cols = 0;
+    amb = false;
+    if (hmax == 0u) return;
+    const bool rowv = sl < n;
+    uint32_t o = 0, r = 0;
+    unsigned long long amb_all = 0;
+    uint32_t j = sl;
+    for (uint32_t t = 1; t <= hmax; ++t) {
+        j += 1u;
+        j = j >= n ? j - n : j;
+        const uint4 q = ps[rowv ? j : 0u];
+        const uint32_t m = min(min(absdiff_u32(pk, q.x), absdiff_u32(ek, q.z)), absdiff_u32(ck, q.w));
+        const float fm = rowv ? (float)max(max(spk, q.y), 1u) : __builtin_nanf(""), fs = (float)absdiff_u32(spk, q.y);
+        const float dp = (float)m * p.inv_norm;
+        const float2v dp2 = {dp, dp}, fm2 = {fm, fm};
+        const float2v b0 = (p.t_hl[0] - dp2) * fm2;
+        unsigned long long m0 = __ballot(fs <= b0.x), ml = __ballot(fs <= b0.y), rm0, ram;
+        if (GROUP == 64) {
+            const unsigned long long am = m0 ^ ml;
+            rm0 = (m0 << t) | (m0 >> (n0 - t));                  // (0 < t < n; bits at n and beyond belong to lanes without a row)
+            ram = (am << t) | (am >> (n0 - t));
+            amb_all |= am | ram;
+        } else {
+            const unsigned long long vm = (t <= h0 ? 0x00000000FFFFFFFFull : 0ull) | (t <= h1 ? 0xFFFFFFFF00000000ull : 0ull);
+            m0 &= vm;
+            const unsigned long long am = m0 ^ (ml & vm);
+            auto rot = [&](unsigned long long x) -> unsigned long long {
+                const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+                const uint32_t rlo = (lo << t) | (lo >> ((n0 - t) & 31u)), rhi = (hi << t) | (hi >> ((n1 - t) & 31u));
+                return (unsigned long long)rlo | ((unsigned long long)rhi << 32);
+            };
+            rm0 = rot(m0);
+            amb_all |= am | rot(am);
+        }
+        asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(o) : "v"(o), "s"(m0) : "vcc");        // 2 x + this lane's bit
+        asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(r), "s"(rm0) : "vcc");
+    }
+    // step t sits at bit hmax - t of both masks; own: column i + t, received: column i - t (mod n)
+    const uint64_t X = (uint64_t)(__builtin_bitreverse32(o) >> (32u - hmax)) << 1;
+    const uint64_t Y = n >= hmax ? (uint64_t)r << (n - hmax) : (uint64_t)r >> (hmax - n);
+    const uint64_t Z = X | Y;
+    const uint64_t A = sl == 0u ? Z : ((Z << sl) | (Z >> ((n - sl) & 63u)));
+    cols = rowv ? A & (n >= 64u ? ~0ull : (1ull << n) - 1ull) : 0ull;
+    amb = rowv && ((amb_all >> lane) & 1ull) != 0ull;
+}
+
 template <int GROUP, int R>
 struct FastSmem {
     static constexpr int SUBS = 64 / GROUP, NMAX = GROUP * R, NW = NMAX > 64 ? 2 : 1;
@@ -1399,11 +1478,22 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
 #pragma unroll
             for (int r = 0; r < R; ++r) N0[r].w[W >> 1] |= (uint64_t)acc[r] << (32u * (W & 1u));
         };
-        level0(std::integral_constant<uint32_t, 0>{});
-        if constexpr (NMAX > 32) level0(std::integral_constant<uint32_t, 1>{});
-        if constexpr (NMAX > 64) {
-            level0(std::integral_constant<uint32_t, 2>{});
-            level0(std::integral_constant<uint32_t, 3>{});
+        bool by_columns = true;
+        if constexpr ((GROUP == 64 || GROUP == 32) && R == 1) {
+            if (p.sym) {
+                // (every unordered pair once; rows whose end does not fit 32 bits are in, as in the column loop: such a
+                // partition is handed to the exact linkage whatever this finds)
+                sym_graph0<GROUP>(p, S.ps[sub], pk[0], spk[0], ek[0], ck[0], n, sl, N0[0].w[0], amb);
+                by_columns = false;
+            }
+        }
+        if (by_columns) {
+            level0(std::integral_constant<uint32_t, 0>{});
+            if constexpr (NMAX > 32) level0(std::integral_constant<uint32_t, 1>{});
+            if constexpr (NMAX > 64) {
+                level0(std::integral_constant<uint32_t, 2>{});
+                level0(std::integral_constant<uint32_t, 3>{});
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) N0[r].set_if(sl + r * GROUP < n, sl + r * GROUP);
@@ -1723,11 +1813,78 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
         g2[0].w[0] = columns(o2, r2);
         ambr[0] = actv && ((amb_all >> lane) & 1ull) != 0ull;
     };
+    // The same for two partitions per wave (GROUP == 32: lanes 0..31 and 32..63, n0 and n1 rows): the compare masks are rotated
+    // half by half, each by t within its own partition's bits; the wave steps to the larger n / 2 and a partition that is done
+    // contributes zeros.  Levels as pair_pass: L0 the threshold, L12 threshold / 2 and / 4 (the columns that do not count for
+    // L12 -- rows that are not open -- are masked out by the caller afterwards, as are their rows).
+    auto sym_pass32 = [&](auto l0, auto l12) {
+        constexpr bool L0 = decltype(l0)::value, L12 = decltype(l12)::value;
+        static_assert(L0 != L12, "one pass per kind");
+        const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)na, 0), n1 = (uint32_t)__builtin_amdgcn_readlane((int)na, 32);
+        const uint32_t h0 = n0 >> 1, h1 = n1 >> 1, hmax = max(h0, h1);
+        if (hmax == 0u) return;
+        const bool rowv = sl < na;
+        uint32_t oA = 0, oB = 0, rA = 0, rB = 0;
+        unsigned long long amb_all = 0;
+        auto push = [](uint32_t x, unsigned long long bit_of_lane) -> uint32_t {     // 2 x + (this lane's bit of the mask)
+            uint32_t d;
+            asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(d) : "v"(x), "s"(bit_of_lane) : "vcc");
+            return d;
+        };
+        uint32_t j = sl;
+        for (uint32_t t = 1; t <= hmax; ++t) {
+            j += 1u;
+            j = j >= na ? j - na : j;
+            const uint4 q = S.ps[sub][rowv ? j : 0u];
+            const uint32_t m = min(min(absdiff_u32(pk[0], q.x), absdiff_u32(ek[0], q.z)), absdiff_u32(ck[0], q.w));
+            const float fm = rowv ? (float)max(max(spk[0], q.y), 1u) : __builtin_nanf(""), fs = (float)absdiff_u32(spk[0], q.y);
+            const float dp = (float)m * p.inv_norm;
+            const float2v dp2 = {dp, dp}, fm2 = {fm, fm};
+            // (a partition that has done its n / 2 steps is out: its half of every mask is cleared)
+            const unsigned long long vm = (t <= h0 ? 0x00000000FFFFFFFFull : 0ull) | (t <= h1 ? 0xFFFFFFFF00000000ull : 0ull);
+            auto rot = [&](unsigned long long x) -> unsigned long long {
+                const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+                const uint32_t rlo = (lo << t) | (lo >> ((n0 - t) & 31u)), rhi = (hi << t) | (hi >> ((n1 - t) & 31u));
+                return (unsigned long long)rlo | ((unsigned long long)rhi << 32);
+            };
+            if constexpr (L0) {
+                const float2v b0 = (p.t_hl[0] - dp2) * fm2;
+                const unsigned long long m0 = __ballot(fs <= b0.x) & vm;
+                const unsigned long long am = (m0 ^ (__ballot(fs <= b0.y) & vm));
+                amb_all |= am | rot(am);
+                oA = push(oA, m0);
+                rA = push(rA, rot(m0));
+            } else {
+                const float2v b1 = (p.t_hl[1] - dp2) * fm2, b2 = (p.t_hl[2] - dp2) * fm2;
+                const unsigned long long m1 = __ballot(fs <= b1.x) & vm, m2 = __ballot(fs <= b2.x) & vm;
+                const unsigned long long am = (m1 ^ (__ballot(fs <= b1.y) & vm)) | (m2 ^ (__ballot(fs <= b2.y) & vm));
+                amb_all |= am | rot(am);
+                oA = push(oA, m1); oB = push(oB, m2);
+                rA = push(rA, rot(m1)); rB = push(rB, rot(m2));
+            }
+        }
+        // step t sits at bit hmax - t of both masks; own: column i + t, received: column i - t (mod n)
+        auto columns = [&](uint32_t o, uint32_t r) -> uint64_t {
+            const uint64_t X = (uint64_t)(__builtin_bitreverse32(o) >> (32u - hmax)) << 1;      // bit t: step t
+            const uint64_t Y = na >= hmax ? (uint64_t)r << (na - hmax) : (uint64_t)r >> (hmax - na);     // bit n - t: step t
+            const uint64_t Z = X | Y;
+            const uint64_t A = sl == 0u ? Z : ((Z << sl) | (Z >> ((na - sl) & 63u)));
+            return rowv ? A & ((1ull << na) - 1ull) : 0ull;
+        };
+        if constexpr (L0) {
+            N0[0].w[0] = columns(oA, rA);
+        } else {
+            g1[0].w[0] = columns(oA, rA);
+            g2[0].w[0] = columns(oB, rB);
+        }
+        ambr[0] = ambr[0] || (rowv && ((amb_all >> lane) & 1ull) != 0ull);
+    };
     using T_ = std::true_type;
     using F_ = std::false_type;
     BitSet<NW> nocols;
     nocols.clear();
     constexpr bool kSym = GROUP == 64 && R == 1;
+    constexpr bool kSym32 = GROUP == 32 && R == 1;
     if constexpr (kSym) {
         if (p.sym) {
             sym_pass();
@@ -1739,7 +1896,12 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
         all_words(T_{}, T_{}, nocols);
         exact_rows(T_{}, T_{}, row, nocols);
     } else {
-        all_words(T_{}, F_{}, nocols);
+        if constexpr (kSym32) {
+            if (p.sym) sym_pass32(T_{}, F_{});
+            else all_words(T_{}, F_{}, nocols);
+        } else {
+            all_words(T_{}, F_{}, nocols);
+        }
         exact_rows(T_{}, F_{}, row, nocols);
     }
 #pragma unroll
@@ -1791,7 +1953,12 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
         // the open rows' neighbourhoods among themselves at threshold / 2 and / 4 (the rows within threshold / 2 of an open
         // row are open themselves: they are in its component)
         if constexpr (!kOnePass) {
-            all_words(F_{}, T_{}, omask);
+            if constexpr (kSym32) {
+                if (p.sym) sym_pass32(F_{}, T_{});
+                else all_words(F_{}, T_{}, omask);
+            } else {
+                all_words(F_{}, T_{}, omask);
+            }
             exact_rows(F_{}, T_{}, open, omask);
         }
 #pragma unroll
@@ -2366,7 +2533,10 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     uint32_t *big_count = scal + 40, *big_list = valsA;          // (the value buffers are idle when the index rides in the key)
     const uint32_t loc_cap = (ctx->dbg & DUET_DBG_CLUSTER_SMALLCAP) ? 3u : (uint32_t)kLocHalo;
     // large inputs, record sort: cl_box is also the partition scan's last stage (no part_apply launch)
-    const bool box_applies = rec_mode && (!small_in || big_sort) && !getenv("DUET_NO_BOX_APPLY");
+    // (small inputs keep part_apply: there the chain of the partitions of more than 64 marks is the critical path and has to start
+    // beside the box test, not behind it -- measured: 315 us against 287 at 1.0 M marks)
+    const bool box_applies = rec_mode && (!small_in || big_sort);
+    const bool box_self = nb_sc <= kSelfSpine && !big_sort;     // (no spine launch: the box kernel combines the tiles' summaries itself)
     PartSum *tiles = (PartSum *)tmpA;                             // the partition scan's tile summaries: 3 words per 2048 marks
     uint8_t *hbits = (uint8_t *)tmpA + ((((size_t)nb_sc + 1) * sizeof(PartSum) + 15) & ~(size_t)15);      // ... and the head flags, a bit per mark
     p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
@@ -2424,8 +2594,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         const LoadHead<uint4, KeyOfRec> heads{rin, p.centre_bits, p.part_gap, KeyOfRec{p.centre_bits, idx_bits}};
         hipLaunchKernelGGL((part_reduce<uint4, KeyOfRec>), dim3(nb_sc), dim3(kScanThreads), 0, st, heads, M, p.part_max, tiles, scal + 64, (uint32_t)(2 * kClasses * kShards), hbits);
         if (nb_sc <= kSelfSpine && !big_sort) {
-            hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
-                               part_start, scal, tile_first);
+            if (!box_applies)
+                hipLaunchKernelGGL(part_apply<true>, dim3(nb_sc), dim3(kScanThreads), 0, st, (const uint8_t *)hbits, M, p.part_max, (const PartSum *)tiles, (uint32_t *)nullptr,
+                                   part_start, scal, tile_first);
         } else {
             hipLaunchKernelGGL(part_spine, dim3(1), dim3(1024), 0, st, tiles, nb_sc, p.part_max);
             if (!box_applies)
@@ -2513,7 +2684,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     if (!box_applies && (rc = launch_big())) return rc;
     const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
-    if (box_applies)
+    if (box_applies && box_self)
+        hipLaunchKernelGGL((cl_box<true, true, true>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)nullptr, lists, cnts, (const uint8_t *)hbits, (const PartSum *)tiles, part_start, scal);
+    else if (box_applies)
         hipLaunchKernelGGL((cl_box<true, true>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)nullptr, lists, cnts, (const uint8_t *)hbits, (const PartSum *)tiles, part_start, scal);
     else if (rec_mode)
         hipLaunchKernelGGL((cl_box<true, false>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts, (const uint8_t *)nullptr, (const PartSum *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
