@@ -512,7 +512,7 @@ constexpr int kBoxHalo = 128;                      // a partition has at most 12
 // flags part_reduce left, numbers the partitions that start in its tile itself and writes their starts (what part_apply does
 // for small inputs): no launch in between, and the tile's records leave together with the carry and the flags instead of
 // behind two dependent round trips (first partition of the tile -> its partitions' starts).
-template <bool REC, bool APPLY, bool SELF = false>
+template <bool REC, bool APPLY>
 __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const uint32_t *tile_first, uint32_t *lists /* [kClasses][M] */,
                                                       uint32_t *counts /* [kClasses][kShards] */, const uint8_t *hbits, const PartSum *tiles,
                                                       uint32_t *part_start_out, uint32_t *n_parts_out)
@@ -529,27 +529,11 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     const uint32_t t0 = tile * kScanTile, shard = tile / p.tps;
     uint32_t p_lo = 0, np = 0;
     if (tid < kClasses) s_cnt[tid] = 0;
-    __shared__ PartSum s_c[kBoxThreads / 64];
     uint32_t hb = 0;
     PartSum carry{kNoHead, 0, 0};
     if (APPLY) {
         hb = hbits[t0 / kScanItems + tid];
-        if (SELF) {
-            // (small inputs, no spine launch: tiles[] holds the tiles' own summaries and the block combines the ones before it
-            // by itself, thread t a contiguous run of them -- part_apply<true>'s way)
-            const uint32_t nbef = tile, per = (nbef + kBoxThreads - 1) / kBoxThreads;
-            const uint32_t lo = min(nbef, tid * per), hi = min(nbef, lo + per);
-            PartSum c{kNoHead, 0, 0};
-            for (uint32_t t = lo; t < hi; ++t) c = part_combine(c, tiles[t], p.part_max);
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const PartSum y = part_shfl_up(c, d);
-                if ((int)lane >= d) c = part_combine(y, c, p.part_max);
-            }
-            if (lane == 63) s_c[tid >> 6] = c;
-        } else {
-            carry = tiles[tile];
-        }
+        carry = tiles[tile];
         if (tid == 0) { s_first = 0xFFFFFFFFu; s_count = 0; }
     } else {
         p_lo = tile_first[tile];
@@ -609,11 +593,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             head[j] = (hb >> j) & 1u;
             if (head[j]) acc = part_combine(acc, PartSum{base + j, base + j, 0}, pm);
         }
-        const PartSum before = part_block_exscan<kBoxThreads>(acc, pm, s_w);      // (synchronises: s_c is visible after it)
-        if (SELF) {
-#pragma unroll
-            for (int w = 0; w < kBoxThreads / 64; ++w) carry = part_combine(carry, s_c[w], pm);
-        }
+        const PartSum before = part_block_exscan<kBoxThreads>(acc, pm, s_w);      // (synchronises)
         const PartSum st = part_combine(carry, before, pm);
         const uint32_t H0 = st.f == kNoHead ? 0u : st.l, P0 = st.f == kNoHead ? 0u : st.s;
         uint32_t H = H0, P = P0, mine = 0, first = 0xFFFFFFFFu;
@@ -2536,7 +2516,6 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // (small inputs keep part_apply: there the chain of the partitions of more than 64 marks is the critical path and has to start
     // beside the box test, not behind it -- measured: 315 us against 287 at 1.0 M marks)
     const bool box_applies = rec_mode && (!small_in || big_sort);
-    const bool box_self = nb_sc <= kSelfSpine && !big_sort;     // (no spine launch: the box kernel combines the tiles' summaries itself)
     PartSum *tiles = (PartSum *)tmpA;                             // the partition scan's tile summaries: 3 words per 2048 marks
     uint8_t *hbits = (uint8_t *)tmpA + ((((size_t)nb_sc + 1) * sizeof(PartSum) + 15) & ~(size_t)15);      // ... and the head flags, a bit per mark
     p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
@@ -2684,9 +2663,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     if (!box_applies && (rc = launch_big())) return rc;
     const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
-    if (box_applies && box_self)
-        hipLaunchKernelGGL((cl_box<true, true, true>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)nullptr, lists, cnts, (const uint8_t *)hbits, (const PartSum *)tiles, part_start, scal);
-    else if (box_applies)
+    if (box_applies)
         hipLaunchKernelGGL((cl_box<true, true>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)nullptr, lists, cnts, (const uint8_t *)hbits, (const PartSum *)tiles, part_start, scal);
     else if (rec_mode)
         hipLaunchKernelGGL((cl_box<true, false>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts, (const uint8_t *)nullptr, (const PartSum *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
