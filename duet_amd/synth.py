@@ -220,8 +220,9 @@ def bench_contig(label, n_reads, n_cands, seed, spelled=None, length=None, deg_l
     return c
 
 
-def bench_genome(n_marks_target, seed, labels=None, reads_per_mark=0.2, mean_deg=10):
-    """Config-3 style set: contigs with hg19 lengths, work split in proportion to length."""
+def bench_genome(n_marks_target, seed, labels=None, reads_per_mark=0.2, mean_deg=10, deg_lo=2, deg_hi=18):
+    """Config-3 style set: contigs with hg19 lengths, work split in proportion to length.  (deg_lo == deg_hi: every candidate
+    with the same number of marks -- tools/prof_ef.py's upper bound for a load-balanced walk.)"""
     labels = DEFAULT_CONTIGS if labels is None else labels
     tot = float(sum(HG19_LENGTHS[l] for l in labels))
     out = []
@@ -229,7 +230,7 @@ def bench_genome(n_marks_target, seed, labels=None, reads_per_mark=0.2, mean_deg
         frac = HG19_LENGTHS[l] / tot
         C = max(2, int(round(n_marks_target * frac / mean_deg)))
         R = max(32, int(round(n_marks_target * frac * reads_per_mark)))
-        out.append(bench_contig(l, R, C, seed * 1000003 + i))
+        out.append(bench_contig(l, R, C, seed * 1000003 + i, deg_lo=deg_lo, deg_hi=deg_hi))
     return out
 
 

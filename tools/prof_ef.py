@@ -3,7 +3,9 @@
 HBM, a fixed number of steps -- the command rocprofv3 wraps for the per-size kernel statistics and the FETCH_SIZE / WRITE_SIZE
 counter passes under profiles/.
 
-    python3 tools/prof_ef.py <marks> [steps=20]      marks <= 1.1e6: BASELINE configs[1] (one contig); else the 24-contig genome
+    python3 tools/prof_ef.py <marks> [steps=20] [deg=D]     marks <= 1.1e6: BASELINE configs[1] (one contig); else the 24-contig genome
+                                                            deg=D: every candidate with exactly D marks (the walk's lanes all
+                                                            loop D times: what a perfectly load-balanced walk would cost)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,11 +14,12 @@ from duet_amd import _lib, engine, synth
 from duet_amd.devmem import DeviceProblem
 
 marks = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+steps = int(sys.argv[2]) if len(sys.argv) > 2 and '=' not in sys.argv[2] else 20
+deg = [int(a[4:]) for a in sys.argv[1:] if a.startswith('deg=')]
 if marks <= 1100000:
     contigs = [synth.bench_contig('1', 200000, 100000, 1, spelled='chr1')]
 else:
-    contigs = synth.bench_genome(marks, 3)
+    contigs = synth.bench_genome(marks, 3, mean_deg=deg[0], deg_lo=deg[0], deg_hi=deg[0]) if deg else synth.bench_genome(marks, 3)
 soa = engine.soa_from_synth(contigs)
 del contigs
 ctx = _lib.Context(0)
