@@ -23,8 +23,9 @@ KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
 # every symbol include/duet_ef.h declares (checked by tests/test_abi.py)
 EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last_error',
            'duet_ctx_set_profiling', 'duet_ctx_set_debug', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
-           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_rows_run_device',
-           'duet_ef_rows_run_host', 'duet_eval_run_host')
+           'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_svim_phase_host', 'duet_rows_run_device',
+           'duet_ef_rows_run_host', 'duet_eval_run_host', 'duet_comm_unique_id', 'duet_comm_create', 'duet_comm_allgather_device',
+           'duet_comm_allgather_host', 'duet_comm_destroy')
 
 
 class EfProblem(ctypes.Structure):
@@ -103,10 +104,13 @@ def load():
     # them by unversioned name, so if this library pulled in /opt/rocm's copy first, torch would load a
     # second runtime and find no GPU.  Importing torch first makes the loader bind our DT_NEEDED
     # libamdhip64.so.7 to the copy torch already mapped (same SONAME).
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # (DUET_NO_TORCH=1: a process that will never import torch -- the rank processes of `duet --gpus N`, duet_amd/multi.py --
+    # skips this: the library then binds /opt/rocm's runtime, as RCCL does)
+    if os.environ.get('DUET_NO_TORCH') != '1':
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.duet_abi_version.restype = ctypes.c_int
     lib.duet_ctx_create.restype = ctypes.c_void_p
@@ -134,6 +138,15 @@ def load():
     lib.duet_eval_run_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(EvalProblem), ctypes.POINTER(EvalCounts)]
     lib.duet_svim_phase_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(SvimProblem), ctypes.POINTER(ClusterResult),
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
+    lib.duet_svim_phase_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(SvimProblem), ctypes.POINTER(ClusterResult),
+                                         ctypes.c_void_p, ctypes.c_void_p]
+    lib.duet_comm_unique_id.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.duet_comm_create.restype = ctypes.c_void_p
+    lib.duet_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.duet_comm_allgather_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    lib.duet_comm_allgather_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.duet_comm_destroy.restype = None
+    lib.duet_comm_destroy.argtypes = [ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -168,6 +181,9 @@ class Context(object):
             self.close()
         except Exception:
             pass
+
+    def last_error(self):
+        return self.lib.duet_last_error(self.handle).decode('utf-8', 'replace')
 
     def _raise(self, rc):
         msg = self.lib.duet_last_error(self.handle).decode('utf-8', 'replace')
@@ -287,6 +303,49 @@ class Context(object):
         N = n.value
         return dict(order=out['order'][:M], cand_off=out['cand_off'][:N + 1], cand_contig=out['cand_contig'][:N],
                     cand_type=out['cand_type'][:N], cand_pos=out['cand_pos'][:N], cand_span=out['cand_span'][:N])
+
+    def svim_host(self, marks, read_tag, depth, depth_off, depth_bin, svlen_thres, suppread_thres, max_dist=0.9, part_gap=1000,
+                  part_max=100, normalizer=900.0):
+        """The fused SVIM-mode pipeline on host arrays (duet_svim_phase_host): raw marks dict(contig, type, pos, span, read) ->
+        dict(cand_off, cand_contig, cand_type, cand_pos, cand_span, pred, ps) trimmed to the candidate count."""
+        arr = {k: np.ascontiguousarray(marks[k], dtype=dt) for k, dt in (('contig', np.uint16), ('type', np.uint8), ('pos', np.uint32),
+                                                                        ('span', np.uint32), ('read', np.uint32))}
+        read_tag = np.ascontiguousarray(read_tag, dtype=np.uint64)
+        depth = np.ascontiguousarray(depth, dtype=np.uint32)
+        depth_off = np.ascontiguousarray(depth_off, dtype=np.uint32)
+        M = len(arr['pos'])
+        p = SvimProblem()
+        p.marks.n_marks, p.marks.part_gap, p.marks.part_max = M, int(part_gap), int(part_max)
+        p.marks.max_dist, p.marks.normalizer = float(max_dist), float(normalizer)
+        if M:
+            p.marks.n_contigs_hint = int(arr['contig'].max()) + 1
+            p.marks.n_types_hint = int(arr['type'].max()) + 1
+            p.marks.max_pos_hint = int(arr['pos'].max())
+            p.marks.max_span_hint = max(int(arr['span'].max()), 1)
+        p.marks.mark_contig, p.marks.mark_type = arr['contig'].ctypes.data, arr['type'].ctypes.data
+        p.marks.mark_pos, p.marks.mark_span = arr['pos'].ctypes.data, arr['span'].ctypes.data
+        p.mark_read = arr['read'].ctypes.data
+        p.read_tag = read_tag.ctypes.data if read_tag.size else None
+        p.n_reads, p.n_contigs = len(read_tag), len(depth_off) - 1
+        p.depth = depth.ctypes.data if depth.size else None
+        p.depth_off = depth_off.ctypes.data
+        p.depth_bin, p.svlen_thres, p.suppread_thres = int(depth_bin), int(svlen_thres), int(suppread_thres)
+        out = dict(cand_off=np.zeros(M + 1, dtype=np.uint32), cand_contig=np.zeros(max(M, 1), dtype=np.uint16),
+                   cand_type=np.zeros(max(M, 1), dtype=np.uint8), cand_pos=np.zeros(max(M, 1), dtype=np.uint32),
+                   cand_span=np.zeros(max(M, 1), dtype=np.uint32))
+        pred, ps = np.zeros(max(M, 1), dtype=np.uint8), np.zeros(max(M, 1), dtype=np.uint32)
+        n = ctypes.c_uint32(0)
+        res = ClusterResult()
+        for k in out:
+            setattr(res, k, out[k].ctypes.data)
+        res.order = None
+        res.n_cands = ctypes.addressof(n)
+        rc = self.lib.duet_svim_phase_host(self.handle, ctypes.byref(p), ctypes.byref(res), _ptr(pred), _ptr(ps))
+        if rc:
+            self._raise(rc)
+        N = n.value
+        return dict(cand_off=out['cand_off'][:N + 1], cand_contig=out['cand_contig'][:N], cand_type=out['cand_type'][:N],
+                    cand_pos=out['cand_pos'][:N], cand_span=out['cand_span'][:N], pred=pred[:N], ps=ps[:N])
 
     def eval_counts(self, arrays, refdist, ratio):
         """duet_eval_run_host: `arrays` = dict of the flat host arrays (duet_amd/evaluation.py: flatten) -> EvalCounts."""

@@ -1,0 +1,199 @@
+# coding=utf-8
+"""How the ranks of `duet --gpus N` talk to each other without torch (round 4).
+
+The product's data-path exchange is ONE all-gather of fixed-size record blocks.  Round 3 did it
+through torch.distributed, which made every rank import torch and wait for its rendezvous: about a second before any work
+started.  Now a rank needs numpy and the native libraries only:
+
+  * `TcpStar` -- a star of TCP connections on MASTER_ADDR:MASTER_PORT (rank 0 listens, the environment is what
+    duet_amd/launch.py or torchrun sets): broadcast of a small blob from rank 0 and a host-side all-gather.  It carries the
+    RCCL unique id, and in the one-GPU plumbing mode (DUET_ONE_GPU=1: every rank on device 0, where RCCL cannot run two ranks)
+    the record blocks themselves.
+  * `RcclGather` -- the collective inside libduet_ef.so (duet_comm_*): ncclCommInitRank from rank 0's id, ncclAllGather over
+    xGMI on device buffers of the rank's context.
+  * `HostGather` -- the same interface over the TCP star alone.
+
+Every blocking step is bounded by `timeout` seconds (DUET_RDZV_TIMEOUT): a rank that never arrives makes the others fail,
+not hang."""
+
+import os
+import socket
+import struct
+import time
+
+import numpy as np
+
+
+class CommError(RuntimeError):
+    pass
+
+
+def _recv_exact(sock, n):
+    buf = bytearray(n)
+    view = memoryview(buf)
+    got = 0
+    while got < n:
+        k = sock.recv_into(view[got:], n - got)
+        if k == 0:
+            raise CommError('peer closed the connection')
+        got += k
+    return bytes(buf)
+
+
+def _send_blob(sock, data):
+    sock.sendall(struct.pack('<Q', len(data)))
+    sock.sendall(data)
+
+
+def _recv_blob(sock):
+    (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class TcpStar(object):
+    def __init__(self, rank, world, addr=None, port=None, timeout=300.0):
+        self.rank, self.world = int(rank), int(world)
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(port if port is not None else os.environ['MASTER_PORT'])
+        self.timeout = float(timeout)
+        self.peers = {}
+        self.sock = None
+        if self.world == 1:
+            return
+        deadline = time.time() + self.timeout
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            try:
+                while len(self.peers) < self.world - 1:
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise CommError('rendezvous: %d of %d ranks arrived within %.0f s' % (len(self.peers) + 1, self.world, self.timeout))
+                    srv.settimeout(left)
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        continue
+                    conn.settimeout(self.timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    (r,) = struct.unpack('<I', _recv_exact(conn, 4))
+                    self.peers[r] = conn
+            finally:
+                srv.close()
+        else:
+            while True:
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                try:
+                    s.settimeout(max(0.05, min(2.0, deadline - time.time())))
+                    s.connect((addr, port))
+                    break
+                except (ConnectionRefusedError, socket.timeout, OSError):
+                    s.close()
+                    if time.time() > deadline:
+                        raise CommError('rendezvous: rank 0 did not answer on %s:%d within %.0f s' % (addr, port, self.timeout))
+                    time.sleep(0.01)
+            s.settimeout(self.timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack('<I', self.rank))
+            self.sock = s
+
+    def bcast(self, data=None):
+        """rank 0's bytes -> every rank"""
+        if self.world == 1:
+            return data
+        try:
+            if self.rank == 0:
+                for r in sorted(self.peers):
+                    _send_blob(self.peers[r], data)
+                return data
+            return _recv_blob(self.sock)
+        except socket.timeout:
+            raise CommError('broadcast timed out after %.0f s' % self.timeout)
+
+    def allgather(self, data):
+        """every rank's bytes -> list in rank order, on every rank"""
+        if self.world == 1:
+            return [data]
+        try:
+            if self.rank == 0:
+                parts = [data] + [None] * (self.world - 1)
+                for r in sorted(self.peers):
+                    parts[r] = _recv_blob(self.peers[r])
+                packed = b''.join(struct.pack('<Q', len(p)) + p for p in parts)
+                for r in sorted(self.peers):
+                    _send_blob(self.peers[r], packed)
+                return parts
+            _send_blob(self.sock, data)
+            packed = _recv_blob(self.sock)
+        except socket.timeout:
+            raise CommError('all-gather timed out after %.0f s' % self.timeout)
+        parts, at = [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from('<Q', packed, at)
+            parts.append(packed[at + 8:at + 8 + n])
+            at += 8 + n
+        return parts
+
+    def close(self):
+        for c in self.peers.values():
+            c.close()
+        if self.sock is not None:
+            self.sock.close()
+        self.peers, self.sock = {}, None
+
+
+class HostGather(object):
+    """blocks (numpy uint8, the same size on every rank) -> [world, size] over the TCP star"""
+    name = 'tcp'
+
+    def __init__(self, star):
+        self.star = star
+
+    def allgather(self, block):
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        parts = self.star.allgather(block.tobytes())
+        if any(len(p) != block.size for p in parts):
+            raise CommError('all-gather: blocks of different sizes')
+        return np.frombuffer(b''.join(parts), dtype=np.uint8).reshape(self.star.world, block.size).copy()
+
+    def close(self):
+        pass
+
+
+class RcclGather(object):
+    """The in-library collective: ncclAllGather on device buffers of `ctx`'s device (duet_comm_* of include/duet_ef.h)."""
+    name = 'rccl'
+
+    def __init__(self, ctx, star):
+        import ctypes
+        self.ctx, self.star = ctx, star
+        lib = ctx.lib
+        ident = None
+        if star.rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            rc = lib.duet_comm_unique_id(ctx.handle, buf)
+            if rc:
+                ctx._raise(rc)
+            ident = bytes(buf)
+        ident = star.bcast(ident)
+        arr = (ctypes.c_ubyte * 128).from_buffer_copy(ident)
+        self.handle = lib.duet_comm_create(ctx.handle, arr, star.rank, star.world)
+        if not self.handle:
+            raise CommError('duet_comm_create: %s' % ctx.last_error())
+
+    def allgather(self, block):
+        import ctypes
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        out = np.empty((self.star.world, block.size), dtype=np.uint8)
+        rc = self.ctx.lib.duet_comm_allgather_host(self.handle, block.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(block.size),
+                                                   out.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            self.ctx._raise(rc)
+        return out
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.duet_comm_destroy(self.handle)
+            self.handle = None

@@ -2839,4 +2839,61 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     return duet_ef_run_device(ctx, &ef, out_pred, out_ps, st);
 }
 
+int duet_svim_phase_host(duet_ctx *ctx, const duet_svim_problem *pr, const duet_cluster_result *res, uint8_t *out_pred, uint32_t *out_ps)
+{
+    if (!ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null context");
+    if (!pr || !res || !res->n_cands || !out_pred || !out_ps) return duet_fail(ctx, DUET_ERR_INVALID, "null argument");
+    if (!pr->depth_off || pr->n_contigs == 0) return duet_fail(ctx, DUET_ERR_INVALID, "bad depth / contig description");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t M = pr->marks.n_marks;
+    *res->n_cands = 0;
+    if (M == 0) return DUET_OK;
+    hipStream_t s = ctx->own_stream;
+    int rc;
+    const size_t n_depth = pr->depth_off[pr->n_contigs];
+    const void *src[7] = {pr->marks.mark_contig, pr->marks.mark_type, pr->marks.mark_pos, pr->marks.mark_span, pr->mark_read, pr->read_tag, pr->depth};
+    const size_t ib[7] = {(size_t)M * 2, (size_t)M, (size_t)M * 4, (size_t)M * 4, (size_t)M * 4, (size_t)pr->n_reads * 8, n_depth * 4};
+    DevBuf *in[7] = {&ctx->cl_in[0], &ctx->cl_in[1], &ctx->cl_in[2], &ctx->cl_in[3], &ctx->sv_in[0], &ctx->sv_in[1], &ctx->sv_in[2]};
+    for (int i = 0; i < 7; ++i) {
+        if (!src[i] && ib[i]) return duet_fail(ctx, DUET_ERR_INVALID, "null array");
+        if ((rc = duet_reserve(ctx, *in[i], ib[i] + 16))) return rc;           // (+16: a readable word even for an empty table)
+        if (ib[i]) HIP_TRY(ctx, hipMemcpyAsync(in[i]->ptr, src[i], ib[i], hipMemcpyHostToDevice, s));
+    }
+    const size_t ob[6] = {(size_t)M * 4, ((size_t)M + 1) * 4 + 16, (size_t)M * 2, (size_t)M, (size_t)M * 4, (size_t)M * 4};
+    for (int i = 0; i < 6; ++i)
+        if ((rc = duet_reserve(ctx, ctx->cl_out[i], ob[i]))) return rc;
+    if ((rc = duet_reserve(ctx, ctx->sv_out[0], (size_t)M + 16))) return rc;
+    if ((rc = duet_reserve(ctx, ctx->sv_out[1], (size_t)M * 4 + 16))) return rc;
+    duet_svim_problem d = *pr;
+    d.marks.mark_contig = (const uint16_t *)ctx->cl_in[0].ptr;
+    d.marks.mark_type = (const uint8_t *)ctx->cl_in[1].ptr;
+    d.marks.mark_pos = (const uint32_t *)ctx->cl_in[2].ptr;
+    d.marks.mark_span = (const uint32_t *)ctx->cl_in[3].ptr;
+    d.mark_read = (const uint32_t *)ctx->sv_in[0].ptr;
+    d.read_tag = (const uint64_t *)ctx->sv_in[1].ptr;
+    d.depth = (const uint32_t *)ctx->sv_in[2].ptr;
+    duet_cluster_result r;
+    r.order = (uint32_t *)ctx->cl_out[0].ptr;
+    r.cand_off = (uint32_t *)ctx->cl_out[1].ptr;
+    r.cand_contig = (uint16_t *)ctx->cl_out[2].ptr;
+    r.cand_type = (uint8_t *)ctx->cl_out[3].ptr;
+    r.cand_pos = (uint32_t *)ctx->cl_out[4].ptr;
+    r.cand_span = (uint32_t *)ctx->cl_out[5].ptr;
+    r.n_cands = (uint32_t *)((char *)ctx->cl_out[1].ptr + ((size_t)M + 1) * 4);        // spare word after cand_off
+    uint32_t n = 0;
+    if ((rc = duet_svim_phase_device(ctx, &d, &r, (uint8_t *)ctx->sv_out[0].ptr, (uint32_t *)ctx->sv_out[1].ptr, &n, s))) return rc;
+    if ((rc = duet_ef_check(ctx, s))) return rc;                                        // (synchronises; DUET_ERR_DIV_ZERO comes out here)
+    *res->n_cands = n;
+    if (res->order) HIP_TRY(ctx, hipMemcpy(res->order, r.order, (size_t)M * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_off, r.cand_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_contig, r.cand_contig, (size_t)n * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_type, r.cand_type, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_pos, r.cand_pos, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(res->cand_span, r.cand_span, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out_pred, ctx->sv_out[0].ptr, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out_ps, ctx->sv_out[1].ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return DUET_OK;
+}
+
+
 }  // extern "C"

@@ -1326,6 +1326,8 @@ void duet_ctx_destroy(duet_ctx *ctx)
     for (DevBuf &b : ctx->cl_in) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->cl_out) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->sv_ws) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->sv_in) if (b.ptr) (void)hipFree(b.ptr);
+    for (DevBuf &b : ctx->sv_out) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->rows_ws) if (b.ptr) (void)hipFree(b.ptr);
     for (DevBuf &b : ctx->rows_in) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->eval_ws.ptr) (void)hipFree(ctx->eval_ws.ptr);

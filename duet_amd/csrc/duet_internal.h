@@ -43,6 +43,7 @@ struct duet_ctx {
     DevBuf rows_in[5];                     // host-array entry: uploaded text pool, offsets, ranks, sign flags; the rows
     DevBuf eval_ws;                        // evaluator (duet_eval.hip): one arena
     DevBuf sv_ws[5];
+    DevBuf sv_in[3], sv_out[2];            // duet_svim_phase_host: mark read indices, read tags, depth bins; pred, ps
     std::vector<uint32_t> sv_depth_off;    // the depth offsets the device copy in sv_ws[0] holds (uploaded only when they change)
     hipStream_t sv_depth_off_stream = nullptr;             // ... and the stream that upload is ordered on
     void *sv_depth_off_at = nullptr;                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks

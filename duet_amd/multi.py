@@ -71,13 +71,39 @@ def hip_compute(device_id):
     return compute
 
 
-def block_from_arrays(pred, ps, n_max, n_contigs=0):
-    """Host (pred, ps) -> the record block as a CPU torch tensor (used by the CPU tests' stand-in compute)."""
-    import torch
+def block_np(pred, ps, n_max, n_contigs=0):
+    """Host (pred, ps) -> the record block `ps u32[n_max] | pred u8[n_max] | trailer` as a numpy uint8 array."""
     block = np.zeros(D.record_bytes(n_max) + trailer_bytes(n_contigs), dtype=np.uint8)
     block[:4 * len(ps)] = np.ascontiguousarray(ps, dtype=np.uint32).view(np.uint8)
     block[4 * n_max:4 * n_max + len(pred)] = pred
-    return torch.from_numpy(block)
+    return block
+
+
+def block_from_arrays(pred, ps, n_max, n_contigs=0):
+    """... as a CPU torch tensor (used by the CPU tests' stand-in compute)."""
+    import torch
+    return torch.from_numpy(block_np(pred, ps, n_max, n_contigs))
+
+
+def hip_compute_np(device_id):
+    """The rank compute without torch: host arrays through duet_ef_run_host (upload, the three kernels, download).
+    -> compute(sub_soa, svlen_thres, suppread_thres, n_max) -> (numpy uint8 block, status)"""
+    from duet_amd import _lib
+    ctx = _lib.Context(device_id)
+
+    def compute(sub, svlen_thres, suppread_thres, n_max):
+        status = 0
+        pred, ps = np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint32)
+        if sub.n_cands:
+            try:
+                pred, ps = ctx.run_host(sub, svlen_thres, suppread_thres)
+            except ZeroDivisionError:
+                status = RC_DIV_ZERO
+                pred, ps = np.zeros(sub.n_cands, dtype=np.uint8), np.zeros(sub.n_cands, dtype=np.uint32)
+        return block_np(pred, ps, n_max, sub.n_contigs), status
+
+    compute.ctx = ctx
+    return compute
 
 
 def part_path(home, rank):
@@ -104,9 +130,11 @@ def plan_shards(caller_vcf, chrom_list, world):
 
 
 def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, rank, world, compute, backend,
-              device_rows_ctx=None, device_id=0):
-    """What one rank does once the process group exists.  -> exit code."""
-    import torch
+              device_rows_ctx=None, device_id=0, gather=None):
+    """What one rank does once the ranks can talk to each other.  -> exit code.
+    gather: an object with allgather(numpy uint8 block) -> numpy [world, bytes] (duet_amd/comm.py: the in-library RCCL
+    collective, or the TCP star of the one-GPU plumbing mode); None: torch.distributed's default process group (`backend`
+    "nccl" / "gloo": what the CPU tests and DUET_COMM=torch use)."""
     from duet_amd import sv_phasing as S
     from duet_amd.native import NativeIngest
     from duet_amd.read_file import init_chrom_list
@@ -144,19 +172,28 @@ def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, rank,
         block, status = compute(soa, svlen_thres, suppread_thres, n_max)
         rb = D.record_bytes(n_max)
         tb = trailer_bytes(K)
-        if block.numel() != rb + tb:
-            raise RuntimeError('record block of %d bytes, expected %d' % (block.numel(), rb + tb))
-        mine = block.cpu().numpy()
+        is_np = isinstance(block, np.ndarray)
+        if (block.size if is_np else block.numel()) != rb + tb:
+            raise RuntimeError('record block of %d bytes, expected %d' % (block.size if is_np else block.numel(), rb + tb))
+        mine = block if is_np else block.cpu().numpy()
         pred, ps = D.unpack_block(mine, n_max, soa.n_cands)
         kept = ing.count_kept(pred) if status == 0 else np.zeros(2 * K, dtype=np.int64)
         trailer = np.zeros(tb, dtype=np.uint8)
         trailer[:4] = np.array([status], dtype=np.uint32).view(np.uint8)
         trailer[STATUS_BYTES:] = kept.astype(np.uint64).view(np.uint8)
-        block[rb:] = torch.from_numpy(trailer).to(block.device)
-        if backend == 'gloo' and block.device.type != 'cpu':
-            block = block.cpu()
-        gathered = D.allgather_records(block, world)                    # the ONE collective of the path
-        g = gathered.cpu().numpy()
+        if gather is not None:
+            mine = mine.copy() if not mine.flags.writeable else mine
+            mine[rb:] = trailer
+            g = gather.allgather(mine)                                      # the ONE collective of the path
+        else:
+            import torch
+            if is_np:
+                block = torch.from_numpy(block)
+            block[rb:] = torch.from_numpy(trailer).to(block.device)
+            if backend == 'gloo' and block.device.type != 'cpu':
+                block = block.cpu()
+            gathered = D.allgather_records(block, world)                    # the ONE collective of the path
+            g = gathered.cpu().numpy()
         total = np.zeros(2 * K, dtype=np.int64)
         for r in range(world):
             if int(g[r, rb:rb + 4].view(np.uint32)[0]) == RC_DIV_ZERO:
@@ -212,6 +249,26 @@ def rank_main(argv):
     local_rank = int(os.environ.get('LOCAL_RANK', rank))
     one_gpu = os.environ.get('DUET_ONE_GPU') == '1'
     device_id = 0 if one_gpu else local_rank
+    if os.environ.get('DUET_COMM', '') != 'torch':
+        # No torch in this process: numpy, the native libraries, and for the collective either RCCL inside libduet_ef.so
+        # (duet_comm_*: ncclAllGather over xGMI) or, in the one-GPU plumbing mode, the TCP star that also carries RCCL's id.
+        os.environ['DUET_NO_TORCH'] = '1'
+        from duet_amd import comm
+        if rank == 0:
+            from duet_amd.utils import add_stream_logging
+            add_stream_logging(home)
+        limit = float(os.environ.get('DUET_RDZV_TIMEOUT', '300'))
+        compute = hip_compute_np(device_id)            # raises when libduet_ef.so / the GPU is missing: no fallback
+        star = comm.TcpStar(rank, world, timeout=limit)
+        gather = None
+        try:
+            gather = comm.HostGather(star) if one_gpu else comm.RcclGather(compute.ctx, star)
+            return rank_body(home, svlen_thres, suppread_thres, thread, all_ctgs, rank, world, compute, gather.name,
+                             device_rows_ctx=compute.ctx, device_id=device_id, gather=gather)
+        finally:
+            if gather is not None:
+                gather.close()
+            star.close()
     import torch
     import torch.distributed as td
     if rank == 0:

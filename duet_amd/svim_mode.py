@@ -32,6 +32,15 @@ def device_compute(ctx):
     return compute
 
 
+def host_compute(ctx):
+    """The same through host arrays (duet_svim_phase_host): what a rank of `-b svim-gpu --gpus N` uses -- no torch in the process."""
+    def compute(got, svlen_thres, suppread_thres, max_dist, depth_bin):
+        out = ctx.svim_host(got, got['read_tag'], got['depth'], got['depth_off'], depth_bin, svlen_thres, suppread_thres, max_dist=max_dist)
+        return dict(cand_contig=out['cand_contig'], cand_type=out['cand_type'], cand_pos=out['cand_pos'], cand_span=out['cand_span'],
+                    support=np.diff(out['cand_off'].astype(np.int64)), pred=out['pred'], ps=out['ps'])
+    return compute
+
+
 def phase_from_bams(home, svlen_thres=50, suppread_thres=2, thread=4, include_all_ctgs=False, max_dist=0.9,
                     min_sv_size=40, min_mapq=20, depth_bin=1000, ctx=None, only=None, compute=None):
     """-> dict(chroms, cand_contig u16[N], cand_type u8[N] (1 INS / 0 DEL), cand_pos, cand_span, support, pred, ps).
@@ -134,12 +143,15 @@ def unpack_records(rec):
                 support=rec[:, 3].astype(np.int64), ps=rec[:, 4].copy())
 
 
-def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, max_dist, rank, world, compute, to_device=None):
-    """One rank of the sharded SVIM mode, inside an initialised process group.  compute as in phase_from_bams;
-    to_device: where the collective's tensors live (None = CPU, for gloo).  Rank 0 appends the rows to the file that
-    already holds the header.  -> exit code (5: division by zero on some rank)."""
-    import torch
-    import torch.distributed as td
+def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, max_dist, rank, world, compute, to_device=None,
+              star=None, gather=None):
+    """One rank of the sharded SVIM mode.  compute as in phase_from_bams.  Rank 0 appends the rows to the file that
+    already holds the header.  -> exit code (5: division by zero on some rank).
+    star / gather (duet_amd/comm.py; round 4): how many candidates a rank finds is a result, not an input, so the ranks first
+    tell each other their counts -- 16 bytes each, a control message over the TCP star that also carried RCCL's id -- and then
+    ONE all-gather (gather.allgather: RCCL inside libduet_ef.so, or the star in the one-GPU plumbing mode) moves the fixed-size
+    candidate records.  Without them: torch.distributed's default group for both (the CPU tests over gloo, DUET_COMM=torch);
+    to_device: where its tensors live."""
     from duet_amd import dist as D
     chroms = init_chrom_list(include_all_ctgs, home)
     owned = D.lpt_assign(bam_weights(home, chroms), world)
@@ -150,6 +162,21 @@ def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, max_d
     except ZeroDivisionError:
         status = 5
     rec = pack_records(res) if res is not None else np.zeros((0, REC_WORDS), dtype=np.uint32)
+    if gather is not None:
+        mine = np.array([len(rec), status, res['n_marks'] if res is not None else 0, 0], dtype=np.int32)
+        counts = np.frombuffer(b''.join(star.allgather(mine.tobytes())), dtype=np.int32).reshape(world, 4)
+        if int(counts[:, 1].max()) != 0:
+            return 5
+        n_max = max(int(counts[:, 0].max()), 1)
+        slot = np.zeros(n_max * REC_WORDS, dtype=np.uint32)
+        slot[:rec.size] = rec.reshape(-1)
+        g = gather.allgather(slot.view(np.uint8))                 # the ONE data-path collective: fixed-size candidate records
+        if rank != 0:
+            return 0
+        g = np.ascontiguousarray(g).view(np.uint32).reshape(world, n_max, REC_WORDS)
+        return _merge_and_write(home, chroms, g, counts, world)
+    import torch
+    import torch.distributed as td
     dev = to_device if to_device is not None else torch.device('cpu')
     mine = torch.tensor([len(rec), status, res['n_marks'] if res is not None else 0, 0], dtype=torch.int32, device=dev)
     counts = torch.empty(4 * world, dtype=torch.int32, device=dev)
@@ -166,6 +193,11 @@ def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, max_d
     if rank != 0:
         return 0
     g = gathered.cpu().numpy().view(np.uint32).reshape(world, n_max, REC_WORDS)
+    return _merge_and_write(home, chroms, g, counts, world)
+
+
+def _merge_and_write(home, chroms, g, counts, world):
+    """rank 0: the gathered records [world, n_max, REC_WORDS] -> rows appended to phased_sv.vcf"""
     parts = [unpack_records(g[r, :int(counts[r, 0])]) for r in range(world)]
     merged = {k: np.concatenate([p_[k] for p_ in parts]) for k in parts[0]}
     # contigs are owned whole and a rank's candidates come contig-major: a stable sort by contig is the single-GPU order
@@ -188,6 +220,24 @@ def rank_main(argv):
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     one_gpu = os.environ.get('DUET_ONE_GPU') == '1'
     device_id = 0 if one_gpu else int(os.environ.get('LOCAL_RANK', rank))
+    if os.environ.get('DUET_COMM', '') != 'torch':
+        # (no torch in this process: see duet_amd/multi.py rank_main)
+        os.environ['DUET_NO_TORCH'] = '1'
+        from duet_amd import _lib, comm
+        if rank == 0:
+            from duet_amd.utils import add_stream_logging
+            add_stream_logging(home)
+        ctx = _lib.Context(device_id)                    # raises when libduet_ef.so / the GPU is missing: no fallback
+        star = comm.TcpStar(rank, world, timeout=float(os.environ.get('DUET_RDZV_TIMEOUT', '300')))
+        gather = None
+        try:
+            gather = comm.HostGather(star) if one_gpu else comm.RcclGather(ctx, star)
+            return rank_body(home, svlen_thres, suppread_thres, thread, all_ctgs, max_dist, rank, world, host_compute(ctx),
+                             star=star, gather=gather)
+        finally:
+            if gather is not None:
+                gather.close()
+            star.close()
     import torch
     import torch.distributed as td
     from duet_amd import _lib

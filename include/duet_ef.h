@@ -238,6 +238,13 @@ typedef struct duet_svim_problem {
 DUET_API int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *prob, const duet_cluster_result *res,
                            uint8_t *out_pred, uint32_t *out_ps, uint32_t *n_cands_host, void *stream);
 
+/* Host convenience (what a rank of `duet -b svim-gpu --gpus N` calls: no device-memory framework in the process): every
+ * array of *prob and *res is HOST memory (res->order may be NULL; res->n_cands a host word; the arrays need room for M
+ * entries, cand_off M + 1), out_pred[M] / out_ps[M] host; uploads, runs the fused pipeline, downloads, synchronises.
+ * Returns DUET_ERR_DIV_ZERO like duet_ef_run_host. */
+DUET_API int duet_svim_phase_host(duet_ctx *ctx, const duet_svim_problem *prob, const duet_cluster_result *res,
+                         uint8_t *out_pred, uint32_t *out_ps);
+
 /* ---------------------------------------------------------------------------------------------
  * Rows of phased_sv.vcf on the device: from (pred, ps) to the text of the data rows.
  * Replaces, for the rows: the emission order of src/duet/sv_phasing_fn.py:204-228 (contig order, PS-class 0/1/2,
@@ -308,6 +315,24 @@ typedef struct duet_eval_counts {
 
 /* All arrays are HOST pointers; uploads, runs four small kernels, synchronises. */
 DUET_API int duet_eval_run_host(duet_ctx *ctx, const duet_eval_problem *prob, duet_eval_counts *counts);
+
+/* ---------------------------------------------------------------------------------------------
+ * The collective of the contig-sharded path: candidates shard by contig over the GPUs of one node,
+ * one process and one context per GPU, and ONE all-gather of fixed-size record blocks reassembles the call set
+ * (src/duet/sv_phasing_fn.py:15-18, 195-210: nothing crosses contigs before the final sort at :229).  RCCL over xGMI,
+ * loaded at run time (the library has no link-time dependency on it; these calls fail with DUET_ERR_NO_DEVICE where it is
+ * missing).  The caller hands the 128-byte unique id of rank 0 to every rank by its own means (duet_amd/comm.py: a TCP
+ * star on MASTER_ADDR:MASTER_PORT); duet_comm_create is collective (ncclCommInitRank) and returns NULL on failure
+ * (duet_last_error(ctx)). */
+#define DUET_COMM_ID_BYTES 128
+typedef struct duet_comm duet_comm;
+DUET_API int duet_comm_unique_id(duet_ctx *ctx, unsigned char *id /* [DUET_COMM_ID_BYTES] */);
+DUET_API duet_comm *duet_comm_create(duet_ctx *ctx, const unsigned char *id, int rank, int world);
+/* every rank contributes `bytes` bytes, every rank receives world * bytes (rank-major).  _device: device pointers,
+ * asynchronous on `stream`; _host: host pointers, staged through device buffers of the communicator, synchronises. */
+DUET_API int duet_comm_allgather_device(duet_comm *comm, const void *send, uint64_t bytes, void *recv, void *stream);
+DUET_API int duet_comm_allgather_host(duet_comm *comm, const void *send, uint64_t bytes, void *recv);
+DUET_API void duet_comm_destroy(duet_comm *comm);
 
 #ifdef __cplusplus
 }

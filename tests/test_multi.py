@@ -9,6 +9,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -177,3 +178,69 @@ def test_bench_parent_spawns_before_touching_the_gpu():
     out = subprocess.check_output([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--launch-dry-run'],
                                   env=env, timeout=120).decode()
     assert out.strip() == '{"launch_dry_run": true, "rank": 0, "world": 2, "torch_imported_by_parent": false}'
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 4: the ranks without torch -- duet_amd/comm.py's TCP star carries the blocks (what the one-GPU plumbing mode uses, and
+# what hands RCCL's unique id around for the in-library collective on real multi-GPU nodes)
+# ---------------------------------------------------------------------------------------------------------
+
+def oracle_compute_np(sub, svlen_thres, suppread_thres, n_max):
+    rc, pred, ps = c_oracle.ef(sub, svlen_thres, suppread_thres)
+    return multi.block_np(pred, ps, n_max, sub.n_contigs), (multi.RC_DIV_ZERO if rc == -5 else 0)
+
+
+def _worker_tcp(rank, world, port, home, svlen_thres, suppread_thres, out_dir):
+    from duet_amd import comm
+    star = comm.TcpStar(rank, world, '127.0.0.1', port, timeout=60)
+    try:
+        rc = multi.rank_body(home, svlen_thres, suppread_thres, 4, False, rank, world, oracle_compute_np, 'tcp',
+                             gather=comm.HostGather(star))
+        with open(os.path.join(out_dir, 'rc%d' % rank), 'w') as f:
+            f.write(str(rc))
+    finally:
+        star.close()
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_ranks_over_the_tcp_star(world, tmp_path):
+    """24 contigs through `world` torch-free ranks: rendezvous, ONE host all-gather of the record blocks, per-rank rows."""
+    from duet_amd import synth
+    from oracle import ef_oracle
+    home = str(tmp_path / 'g')
+    synth.write_workdir(home, synth.bench_genome(50000, 11), dialect='cutesv', seed=11, write_sam=True)
+    want = ef_oracle.sv_phasing_text(home, 50, 2)
+    mp.spawn(_worker_tcp, args=(world, launch.free_port(), home, 50, 2, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), 'rc%d' % r)).read() == '0'
+    multi.assemble(home, False, world)
+    assert open(os.path.join(home, 'phased_sv.vcf')).read() == want
+
+
+def test_tcp_star_primitives_and_timeout():
+    import threading
+    from duet_amd import comm
+    port = launch.free_port()
+    out = {}
+
+    def run(rank):
+        star = comm.TcpStar(rank, 3, '127.0.0.1', port, timeout=30)
+        try:
+            out[rank] = (star.bcast(b'id-of-rank-0' if rank == 0 else None), star.allgather(bytes([rank]) * (rank + 1)))
+        finally:
+            star.close()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    for r in range(3):
+        assert out[r] == (b'id-of-rank-0', [bytes([0]), bytes([1, 1]), bytes([2, 2, 2])])
+    # a rank that never arrives: rank 0 gives up after its timeout instead of hanging; so does a rank without a rank 0
+    t0 = time.time()
+    with pytest.raises(comm.CommError):
+        comm.TcpStar(0, 2, '127.0.0.1', launch.free_port(), timeout=1.0)
+    with pytest.raises(comm.CommError):
+        comm.TcpStar(1, 2, '127.0.0.1', launch.free_port(), timeout=1.0)
+    assert time.time() - t0 < 20

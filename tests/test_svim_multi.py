@@ -79,3 +79,30 @@ def test_contigs_are_assigned_by_bam_size(tmp_path):
     assert sorted(k for o in owned for k in o) == list(range(24))
     loads = [sum(w[k] for k in o) for o in owned]
     assert max(loads) < 1.25 * (sum(w) / 8.0)
+
+
+def _worker_tcp(rank, world, port, home, out_dir):
+    """round 4: the torch-free rank -- counts as a control message over the TCP star, ONE gather of the records"""
+    from duet_amd import comm
+    star = comm.TcpStar(rank, world, '127.0.0.1', port, timeout=60)
+    try:
+        rc = svim_mode.rank_body(home, 50, 2, 4, False, 0.9, rank, world, oracle_compute, star=star, gather=comm.HostGather(star))
+        with open(os.path.join(out_dir, 'rc%d' % rank), 'w') as f:
+            f.write(str(rc))
+    finally:
+        star.close()
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_svim_mode_over_the_tcp_star(world, tmp_path):
+    home = str(tmp_path / 'w')
+    synth.write_svim_workdir(home, H.case_contigs('genome_small', 5), 5)
+    chroms = svim_mode.init_chrom_list(False, home)
+    one = svim_mode.phase_from_bams(home, 50, 2, 2, compute=oracle_compute)
+    want = svim_mode.header_text(home, chroms) + svim_mode.rows_text(home, one)
+    with open(home + '/phased_sv.vcf', 'w') as f:
+        f.write(svim_mode.header_text(home, chroms))
+    mp.spawn(_worker_tcp, args=(world, launch.free_port(), home, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), 'rc%d' % r)).read() == '0'
+    assert open(home + '/phased_sv.vcf').read() == want
