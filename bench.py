@@ -72,6 +72,24 @@ def pmc_traffic(soa):
     return pmc_traffic_entry(soa)[0]
 
 
+def fused_traffic(marks):
+    """Counter traffic of ONE run of the fused clustered + phased pipeline (every kernel's FETCH_SIZE doubled + WRITE_SIZE,
+    summed) from the committed collection profiles/*fused_traffic*.json -> (bytes per run, per-kernel table, source) or
+    (None, None, None).  Like pmc_traffic_entry: a --pmc pass is a separate profiler run, not part of this one."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*fused_traffic*.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for e in d:
+                if abs(int(e['marks']) - int(marks)) <= max(2000, int(marks) // 500):
+                    return e['traffic_bytes_per_run'], e['per_kernel'], {'file': 'profiles/' + os.path.basename(path),
+                                                                         'collected': e.get('collected'), 'command': e.get('command')}
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None, None
+
+
 def roofline_block(kernel, soa, launch_ms, launches, source, note=None, workload=None):
     """roofline for ef_classify on `soa`: achieved = algorithmic bytes / launch time; real_hbm_frac = committed counter
     bytes / the SAME launch time / 8 TB/s (the 2x gap between the two is the convention: SURVEY 8d charges 8 B per gathered
@@ -390,6 +408,9 @@ def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
             'per_rank': per_rank,
             'topology': topo,
             'same_problem_on_1_gpu': same,
+            # (what a scaling curve should be read against: the SAME call set on one GPU of this run -- the N = 1 line of
+            # bench.py is BASELINE configs[1], a different workload; its `scaling_point_1gpu` is this problem too)
+            'value_vs_1gpu_same_problem': (soa.n_marks * args.steps / dt) / same['marks_per_s'],
         }
     dist_mod.barrier()
     return out
@@ -593,6 +614,20 @@ def single_gpu_run(args, ctx, torch):
         out['same_problem_as_multi_gpu_runs'] = {'workload': 'BASELINE configs[2] on one GPU (what --gpus N shards)',
                                                  'marks_per_s': ex['config3_1gpu_2e7_marks']['marks_per_s'],
                                                  'ms_per_step': ex['config3_1gpu_2e7_marks']['ms_per_step']}
+        # the 1-GPU point of the strong-scaling curve that `--gpus N` lines continue (their `value` is this workload's; this
+        # line's `value` is configs[1]'s): compare value(N) with scaling_point_1gpu.value, not with this line's value
+        out['scaling_point_1gpu'] = {'workload': 'BASELINE configs[2]: 24 contigs, %d marks, one GPU, no collective' % ex['config3_1gpu_2e7_marks']['marks'],
+                                     'value': ex['config3_1gpu_2e7_marks']['marks_per_s'], 'unit': 'marks/s',
+                                     'ms_per_step': ex['config3_1gpu_2e7_marks']['ms_per_step']}
+        # BASELINE.md section 3's definition: B_EF = 12 M + 27 C + 8 R over the SUM of the three kernels' times, of 8 TB/s
+        sk = {'config2': {'B_EF': soa.algorithmic_bytes(), 'kernels_ms_sum': float(sum(iso.kernel_ms[i] for i in range(3)))}}
+        for name, key in (('2e7_marks', 'config3_1gpu_2e7_marks'), ('2e8_marks', '1gpu_2e8_marks')):
+            if key in ex:
+                sk[name] = {'B_EF': 12 * ex[key]['marks'] + 27 * ex[key]['candidates'] + 8 * ex[key]['reads'],
+                            'kernels_ms_sum': float(sum(ex[key]['kernels_ms'].values()))}
+        for v in sk.values():
+            v['frac_of_8TBs'] = v['B_EF'] / (v['kernels_ms_sum'] * 1e-3) / 1e9 / HBM_PEAK_GBS if v['kernels_ms_sum'] > 0 else None
+        out['summed_kernels_frac_B_EF'] = sk
         ex['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
         ex['fused_clustered_and_phased_config2'] = fused
         ex['fused_clustered_and_phased_2e7_marks'] = fused_point(ctx, torch, engine, synth,
@@ -738,6 +773,17 @@ def abi_and_e2e(ctx, soa, contig, kernels_ms):
         for _ in range(3):
             sv_phasing(home, 50, 2, 4, False)
         t_e2e = (time.perf_counter() - t0) / 3
+        # ... with -t as a hard bound on the ingest's workers (default: the VCF's first half runs beside the BAM loop, each
+        # with `-t` workers -- up to 2 x 4 alive at once)
+        os.environ['DUET_INGEST_STRICT_THREADS'] = '1'
+        try:
+            sv_phasing(home, 50, 2, 4, False)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sv_phasing(home, 50, 2, 4, False)
+            t_e2e_strict = (time.perf_counter() - t0) / 3
+        finally:
+            del os.environ['DUET_INGEST_STRICT_THREADS']
         size = os.path.getsize(os.path.join(home, 'phased_sv.vcf'))
         # the last step alone: (pred, ps) -> text of the rows, on the device vs on the host (one thread)
         from duet_amd.native import NativeIngest
@@ -767,6 +813,7 @@ def abi_and_e2e(ctx, soa, contig, kernels_ms):
     return {'t_kernels_ms': kernels_ms, 'marks_per_s_kernels': M / (kernels_ms * 1e-3) if kernels_ms else None,
             't_abi_ms': t_abi * 1e3, 'marks_per_s_abi': M / t_abi,
             't_e2e_ms': t_e2e * 1e3, 'marks_per_s_e2e': M / t_e2e, 'phased_sv_vcf_bytes': size,
+            't_e2e_ms_strict_threads': t_e2e_strict * 1e3, 'marks_per_s_e2e_strict_threads': M / t_e2e_strict,
             'rows': {'n_rows': int(n_rows), 't_device_ms_incl_upload_and_download': t_rows_dev * 1e3,
                      't_host_ms_1_thread': t_rows_host * 1e3, 'identical': rows_ok},
             'note': 't_abi = duet_ef_run_host on pageable host arrays (PCIe both ways); t_e2e = duet_amd.sv_phasing.sv_phasing '
@@ -843,12 +890,15 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False):
     M = len(marks['pos'])
     b_a0, b_ef = 18 * M, 12 * M + 27 * int(ds.n_found) + 8 * soa.n_reads
     gbs = (b_a0 + b_ef) / dt / 1e9
+    traffic, per_kernel, tsrc = fused_traffic(M)
     return {'marks': M, 'candidates_found': int(ds.n_found), 'phased': int((got['pred'] != 0).sum()),
             'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'ms_per_run_with_count_returned': dt_wait * 1e3,
             'parity_vs_composed_oracles': ok,
             'roofline': {'kernels': 'duet_svim_phase_device: A0 (sort, partitions, linkage, emit) + E/F, ~25 launches',
                          'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                         'traffic': None, 'algorithmic_bytes_per_run': b_a0 + b_ef, 'B_A0_18_per_mark': b_a0, 'B_EF': b_ef,
+                         'traffic': traffic, 'traffic_source': tsrc, 'traffic_per_kernel_bytes': per_kernel,
+                         'real_hbm_frac': (traffic / dt / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         'algorithmic_bytes_per_run': b_a0 + b_ef, 'B_A0_18_per_mark': b_a0, 'B_EF': b_ef,
                          'run_ms': dt * 1e3,
                          'note': 'whole pipeline: (B_A0 + B_EF) / wall time per run, back-to-back runs resident in HBM; the '
                                  'sort passes and the pair distances of the agglomeration are not credited (SURVEY 8d)'},

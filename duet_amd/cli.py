@@ -50,8 +50,13 @@ def main(argv):
         launch.probe_devices(1 if os.environ.get('DUET_ONE_GPU') == '1' else a.gpus)
     for fn, args in todo[:-1]:
         fn(*args)
-    if a.gpus <= 1:
+    if a.gpus <= 1 and os.environ.get('DUET_FORCE_RANKS') != '1':
         engine.default_context(a.device)      # fail before the last stage if there is no MI355X / no library
+    elif a.gpus <= 1:
+        # (DUET_FORCE_RANKS=1: the last stage starts a rank process even for one GPU -- this process must stay GPU-free,
+        # so the device is probed in a child)
+        from duet_amd import launch
+        launch.probe_devices(1)
     fn, args = todo[-1]
     fn(*args)
     logging.info('%s DUET FINISHED IN %ss %s' % (_BAR, round(time.time() - began, 3), _BAR))

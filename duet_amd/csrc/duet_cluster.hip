@@ -2793,10 +2793,13 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     // stream, whose pageable copy may still be reading the host vector)
     if (ctx->sv_depth_off_at != (void *)d_depth_off || ctx->sv_depth_off.size() != (size_t)K + 1 || ctx->sv_depth_off_stream != st ||
         memcmp(ctx->sv_depth_off.data(), pr->depth_off, ((size_t)K + 1) * 4) != 0) {
-        if (ctx->sv_depth_off_at && ctx->sv_depth_off_stream != st) HIP_TRY(ctx, hipStreamSynchronize(ctx->sv_depth_off_stream));
-        HIP_TRY(ctx, hipStreamSynchronize(st));                  // the previous copy's source is about to change
+        // (the previous copy's source is about to change: wait for THAT COPY -- an event recorded behind it, not the stream it
+        // was issued on, which the caller may have destroyed in the meantime)
+        if (!ctx->sv_depth_off_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->sv_depth_off_ev, hipEventDisableTiming));
+        if (ctx->sv_depth_off_at) HIP_TRY(ctx, hipEventSynchronize(ctx->sv_depth_off_ev));
         ctx->sv_depth_off.assign(pr->depth_off, pr->depth_off + K + 1);
         HIP_TRY(ctx, hipMemcpyAsync(d_depth_off, ctx->sv_depth_off.data(), ((size_t)K + 1) * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipEventRecord(ctx->sv_depth_off_ev, st));
         ctx->sv_depth_off_at = (void *)d_depth_off;
         ctx->sv_depth_off_stream = st;
     }

@@ -1338,6 +1338,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
         if (ctx->cl_join[i]) (void)hipEventDestroy(ctx->cl_join[i]);
     }
     if (ctx->cl_fork) (void)hipEventDestroy(ctx->cl_fork);
+    if (ctx->sv_depth_off_ev) (void)hipEventDestroy(ctx->sv_depth_off_ev);
     if (ctx->plan_ev) (void)hipEventDestroy(ctx->plan_ev);
     if (ctx->plan_stage) (void)hipHostFree(ctx->plan_stage);
     delete ctx;

@@ -45,7 +45,9 @@ struct duet_ctx {
     DevBuf sv_ws[5];
     DevBuf sv_in[3], sv_out[2];            // duet_svim_phase_host: mark read indices, read tags, depth bins; pred, ps
     std::vector<uint32_t> sv_depth_off;    // the depth offsets the device copy in sv_ws[0] holds (uploaded only when they change)
-    hipStream_t sv_depth_off_stream = nullptr;             // ... and the stream that upload is ordered on
+    hipStream_t sv_depth_off_stream = nullptr;             // ... and the stream that upload is ordered on (compared, never used: the
+                                                           // caller may have destroyed it since)
+    hipEvent_t sv_depth_off_ev = nullptr;                  // ... recorded behind that upload: what a run on another stream waits for
     void *sv_depth_off_at = nullptr;                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};

@@ -145,13 +145,21 @@ def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, rank,
     chrom_list = init_chrom_list(include_all_ctgs, home)
     if os.environ.get('DUET_NATIVE_INGEST') == '0' or os.environ.get('DUET_USE_SAMTOOLS') == '1':
         return RC_DECLINED
-    plan = plan_shards(caller_vcf, chrom_list, world)
-    if plan is None:
+    # the pre-count (records and line bytes per listed contig: one memchr pass, the same numbers on every rank) on the handle that
+    # then parses: contigs -> ranks longest-processing-time-first on the line bytes, every rank's candidate count known up front
+    shard = {}
+
+    def plan(n_rec, n_bytes):
+        shard['owned'] = D.lpt_assign(n_bytes, world)
+        shard['n_rec'] = n_rec
+        return shard['owned'][rank]
+
+    ing = NativeIngest.load(caller_vcf, home + '/snp_phasing/', chrom_list, max(1, int(thread) // world), plan=plan)
+    if ing is None or 'owned' not in shard:
         return RC_DECLINED
-    owned, n_rec = plan
+    owned, n_rec = shard['owned'], shard['n_rec']
     sizes = [int(sum(int(n_rec[k]) for k in o)) for o in owned]
     n_max = max(max(sizes), 1)
-    ing = NativeIngest.load(caller_vcf, home + '/snp_phasing/', chrom_list, max(1, int(thread) // world), owned=owned[rank])
     if ing is None or ing.handle is None:
         if rank == 0 and ing is not None:
             logging.info('native ingest declined (%s); using the Python path' % ing.why)

@@ -128,11 +128,14 @@ class NativeIngest(object):
             lib.duet_ingest_destroy(h)
 
     @classmethod
-    def load(cls, vcf_path, sam_home, chrom_list, thread=4, owned=None):
+    def load(cls, vcf_path, sam_home, chrom_list, thread=4, owned=None, plan=None):
         """-> NativeIngest, or None when the native library is missing / declines the input (reason logged by
         the caller through .why of the returned tuple).  owned (sharded runs): the contig indices this rank reads --
         the other listed contigs' BAMs are not opened and their records are dropped at their first token (their rank
-        vouches for them); header lines and the contig list stay complete."""
+        vouches for them); header lines and the contig list stay complete.
+        plan (sharded runs, instead of owned): a callable (records per contig, line bytes per contig) -> owned, called with the
+        pre-count taken on THIS handle -- the file the pre-count read stays loaded for the parse that follows (a rank that
+        pre-counted through NativeIngest.precount read the caller VCF twice)."""
         lib = load()
         if lib is None:
             return None
@@ -146,6 +149,12 @@ class NativeIngest(object):
             lib.duet_ingest_destroy(h)
             return cls(None, lib, None, why)
 
+        if plan is not None:
+            rec = np.zeros(max(len(chrom_list), 1), dtype=np.uint64)
+            byt = np.zeros(max(len(chrom_list), 1), dtype=np.uint64)
+            if lib.duet_ingest_vcf_precount(h, vcf_path.encode(), rec.ctypes.data, byt.ctypes.data) != OK:
+                return decline()
+            owned = plan(rec[:len(chrom_list)].astype(np.int64), byt[:len(chrom_list)].astype(np.int64))
         mine = None
         if owned is not None:
             mine = np.zeros(max(len(chrom_list), 1), dtype=np.uint8)

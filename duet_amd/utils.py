@@ -13,7 +13,9 @@ import sys
 
 _OPTIONS = (
     # short, long, type, default, help
-    ('-t', '--thread', int, 4, 'number of threads to use [%(default)s]'),
+    ('-t', '--thread', int, 4, 'number of threads to use [%(default)s] (SV phasing: while the caller VCF is first read beside the '
+                               'BAM loop both use this many workers -- up to twice the number for a few milliseconds; '
+                               'DUET_INGEST_STRICT_THREADS=1 splits the budget instead and keeps it a hard bound)'),
     ('-m', '--min_allele_frequency', float, 0.25,
      'minimum allele frequency required to call a candidate SNP [%(default)s]'),
     ('-c', '--cluster_max_distance', float, 0.9,
