@@ -2451,7 +2451,10 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // that agree in them (a GROUP: one type within 2^lo centres) are a few dozen; the low bits are ordered group by group
     uint32_t rs_lo = 0, rs_np = 0, rs_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (rec_mode) {
-        uint32_t T = std::max(bits_for(M >> 3), 8u);
+        // (measured at 2e7 marks, 34-bit keys: 20 top bits in two 10-bit passes leave groups of 53 marks on average and the local
+        // stage takes 285 + 33 us; 21 bits 235 us; 22 bits, two 11-bit passes, 212 us but 33 us more in the second scatter and
+        // its offsets: 21 it is.  1.0 M marks: 16 bits in two 8-bit passes, groups of 32)
+        uint32_t T = std::max(bits_for(M >> 4), 8u);
         if (const char *e = getenv("DUET_RS_TBITS")) T = (uint32_t)atoi(e);                                                       // (experiments)
         T = std::min(T, key_bits);
         if (key_bits - T > 31u) T = key_bits - 31u;            // (the local stage holds the low bits in 32-bit words)
