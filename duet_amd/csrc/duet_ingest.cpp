@@ -682,7 +682,8 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     }
     lap("records");
     if (g->extract && !segs.empty()) {
-        // split-read marks (oracle/svim_oracle.py, SVIM_inter.py's insertion / deletion cases): reads in order of first
+        // split-read marks (oracle/svim_oracle.py: SVIM_inter.py's insertion / deletion cases and, round 4, its tandem-duplication
+        // and inversion cases -- type codes DEL 0 / INS 1 / INV 2 / DUP 3): reads in order of first
         // appearance, their segments sorted by (qs, qe, line); consecutive segments on one strand whose gaps on the read
         // and on the reference differ by at least min_sv_size
         std::unordered_map<std::string, uint32_t> group_of;
@@ -703,10 +704,23 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
             });
             for (size_t i = 0; i + 1 < gr.size(); ++i) {
                 const Seg &a = segs[gr[i]], &c = segs[gr[i + 1]];
-                if (a.rev != c.rev) continue;
                 const int64_t dread = (int64_t)c.qs - (int64_t)a.qe;
+                if (a.rev != c.rev) {
+                    // opposite strands: the segments meet at their right ends (forward, then reverse) or at their left ends: INV
+                    if (dread < -tol) continue;
+                    const int64_t p1 = a.rev ? (int64_t)a.rs : (int64_t)a.re, p2 = a.rev ? (int64_t)c.rs : (int64_t)c.re;
+                    const int64_t lo = p1 < p2 ? p1 : p2, sp = p1 < p2 ? p2 - p1 : p1 - p2;
+                    if (sp >= min_sv && sp <= max_del && lo < 0xFFFFFFFEll) pend.push_back({a.name, a.len, 2, (uint32_t)lo + 1u, (uint32_t)sp});
+                    continue;
+                }
                 const int64_t dref = a.rev ? (int64_t)a.rs - (int64_t)c.re : (int64_t)c.rs - (int64_t)a.re;
-                if (dread < -tol || dref < -tol) continue;
+                if (dread < -tol) continue;
+                if (dref < -tol) {
+                    // the read goes back on the reference: a tandem duplication of the stretch both segments cover: DUP
+                    const int64_t s0 = a.rev ? (int64_t)a.rs : (int64_t)c.rs, e0 = a.rev ? (int64_t)c.re : (int64_t)a.re;
+                    if (e0 - s0 >= min_sv && e0 - s0 <= max_del && s0 < 0xFFFFFFFEll) pend.push_back({a.name, a.len, 3, (uint32_t)s0 + 1u, (uint32_t)(e0 - s0)});
+                    continue;
+                }
                 const int64_t dev = dread - dref;
                 const uint64_t anchor = a.rev ? c.re : a.re;
                 if (anchor >= 0xFFFFFFFEull) continue;

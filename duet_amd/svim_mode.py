@@ -63,6 +63,9 @@ def phase_from_bams(home, svlen_thres=50, suppread_thres=2, thread=4, include_al
     return dict(out, chroms=chroms, n_marks=len(got['pos']))
 
 
+SV_TYPE_NAMES = ('DEL', 'INS', 'INV', 'DUP')          # the extraction's type codes (oracle/svim_oracle.py)
+
+
 def spelled_contigs(home, chroms):
     """CHROM text per contig: the spelling of its BAM (chr<c>.bam else <c>.bam, as sv_phasing_fn.py:19-24 looks them up)."""
     names = []
@@ -80,10 +83,11 @@ def rows_text(home, res):
     order = sorted(keep, key=lambda i: (names[int(res['cand_contig'][i])], int(res['cand_pos'][i])))
     out = []
     for n, i in enumerate(order):
-        t = 'INS' if int(res['cand_type'][i]) == 1 else 'DEL'
+        t = SV_TYPE_NAMES[int(res['cand_type'][i]) & 3]
         ln = int(res['cand_span'][i])
+        # (the sign rule of sv_phasing_fn.py:225: positive for INS and DUP, negative for everything else)
         out.append('%s\t%d\tDuet.%d\tN\t<%s>\t.\tPASS\tSVLEN=%d;SVTYPE=<%s>\tHP:PS\t%s:%d\n' % (
-            names[int(res['cand_contig'][i])], int(res['cand_pos'][i]), n + 1, t, ln if t == 'INS' else -ln, t,
+            names[int(res['cand_contig'][i])], int(res['cand_pos'][i]), n + 1, t, ln if t in ('INS', 'DUP') else -ln, t,
             hp[int(res['pred'][i])], int(res['ps'][i])))
     return ''.join(out)
 

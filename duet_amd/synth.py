@@ -583,6 +583,43 @@ def svim_sam_lines(c, seed, min_sv=40, pos_jitter=15, len_jitter_pct=4, split_ev
             fl = 16 if rev else 0
             out.append('%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*\tNM:i:1%s' % (name, fl, c.spelled, p0 - left_len + 1, left, tag))
             out.append('%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*\tNM:i:2%s' % (name, fl | 2048, c.spelled, right_pos + 1, right, tag))
+        # round 4: tandem duplications and inversions only show in split reads -- candidates of those types (and every 11th
+        # INS / DEL position, as a second event there) get `dup_reads` split reads each: a duplication's read runs to the end
+        # of the duplicated stretch and starts over at its beginning; an inversion's read turns round at the breakpoint
+        for j in range(C):
+            t = c.cand_svtype[j].split(':')[0]
+            ln = abs(int(c.cand_svlen[j])) if int(c.cand_svlen[j]) > -(1 << 61) else 0
+            p0 = int(c.cand_pos[j])
+            kind = t if t in ('DUP', 'INV') else (('DUP', 'INV')[j % 2] if j % 11 == 5 else None)
+            if kind is None or ln < min_sv or ln > 90000 or p0 < 2000 or p0 + ln + 1000 >= c.length:
+                continue
+            for r in range(3 + j % 3):
+                name = c.name_of(0x50000000 + 8 * j + r)
+                jp, jl = (j * 7 + r * 3) % 21 - 10, (j * 5 + r) % 9 - 4
+                s0, e0 = p0 + jp, p0 + jp + ln + jl             # 0-based [s0, e0): the duplicated / inverted stretch
+                la, lb = 450 + (j + r) % 50, 380 + (j * 3 + r) % 60
+                rev = (j + r) % 2 == 1
+                tag = '\tHP:i:%d\tPC:i:%d\tPS:i:%d' % (1 + (j + r) % 2, 40 + (j * 13 + r) % 900, (p0 // 500000) * 500000 + 17) if (j + r) % 4 else ''
+                if kind == 'DUP':
+                    # read order: ... up to e0, then again from s0 ...   (reverse strand: the same two alignments, clips swapped)
+                    a_pos, b_pos = e0 - la, s0
+                    if not rev:
+                        a_cig, b_cig = '%dM%dS' % (la, lb), '%dH%dM' % (la, lb)
+                    else:
+                        a_cig, b_cig = '%dS%dM' % (lb, la), '%dM%dH' % (lb, la)
+                    fa = 16 if rev else 0
+                    out.append('%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*\tNM:i:3%s' % (name, fa, c.spelled, a_pos + 1, a_cig, tag))
+                    out.append('%s\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t*\t*\tNM:i:4%s' % (name, fa | 2048, c.spelled, b_pos + 1, b_cig, tag))
+                else:
+                    # forward up to s0's ... the read continues on the other strand from e0 backwards: the two right ends meet
+                    a_pos, b_pos = s0 - la, e0 - lb
+                    if not rev:
+                        out.append('%s\t0\t%s\t%d\t60\t%dM%dS\t*\t0\t0\t*\t*\tNM:i:5%s' % (name, c.spelled, a_pos + 1, la, lb, tag))
+                        out.append('%s\t2064\t%s\t%d\t60\t%dM%dH\t*\t0\t0\t*\t*\tNM:i:6%s' % (name, c.spelled, b_pos + 1, lb, la, tag))
+                    else:
+                        # the two left ends meet: first segment reverse at [e0, e0 + la), second forward at [s0, s0 + lb)
+                        out.append('%s\t16\t%s\t%d\t60\t%dS%dM\t*\t0\t0\t*\t*\tNM:i:5%s' % (name, c.spelled, e0 + 1, lb, la, tag))
+                        out.append('%s\t2048\t%s\t%d\t60\t%dH%dM\t*\t0\t0\t*\t*\tNM:i:6%s' % (name, c.spelled, s0 + 1, la, lb, tag))
     return out
 
 

@@ -21,8 +21,14 @@ Rule, per `samtools view` text line of a contig's haplotagged BAM:
     segments a, b on the same strand: dread = b.qs - a.qe; dref = b.start - a.end (forward) or a.start - b.end
     (reverse); both must be >= -5 (overlap tolerance); dev = dread - dref; the event sits at the reference end of the
     left segment (a.end forward, b.end reverse), pos = that + 1: dev >= min_sv_size -> INS of span dev;
-    -100000 <= dev <= -min_sv_size -> DEL of span -dev.  These marks follow the contig's CIGAR marks, reads in order
-    of first appearance.
+    -100000 <= dev <= -min_sv_size -> DEL of span -dev.
+    Round 4 (SVIM_inter.py's tandem-duplication and inversion cases, simplified; type codes DEL 0 / INS 1 / INV 2 / DUP 3):
+    same strand, dread >= -5 and dref < -5 -- the read goes BACK on the reference: a tandem duplication of the stretch both
+    segments cover, [b.start, a.end) forward / [a.start, b.end) reverse: DUP, pos = its start + 1, span = its length, when
+    min_sv_size <= span <= 100000;  opposite strands, dread >= -5: the segments meet at their right ends (a forward, b
+    reverse: p1 = a.end, p2 = b.end) or at their left ends (a reverse, b forward: p1 = a.start, p2 = b.start): INV,
+    pos = min(p1, p2) + 1, span = |p2 - p1|, when min_sv_size <= span <= 100000.
+    These marks follow the contig's CIGAR marks, reads in order of first appearance.
 The tag of a mark's read is looked up in the contig's tag table exactly like step E/F does (ef_oracle.tags_from_sam_text).
 """
 
@@ -89,11 +95,21 @@ def extract_from_sam_text(text, min_sv_size=40, min_mapq=20, depth_bin=1000):
     for name, sg in segs.items():                       # dict order = first appearance
         sg.sort()
         for a, b in zip(sg, sg[1:]):
-            if a[5] != b[5]:
-                continue
             dread = b[0] - a[1]
+            if a[5] != b[5]:
+                if dread < -SEG_TOL:
+                    continue
+                p1, p2 = (a[3], b[3]) if a[5] else (a[4], b[4])
+                if min_sv_size <= abs(p2 - p1) <= SPLIT_MAX_DEL:
+                    marks.append((2, min(p1, p2) + 1, abs(p2 - p1), name))
+                continue
             dref = (a[3] - b[4]) if a[5] else (b[3] - a[4])
-            if dread < -SEG_TOL or dref < -SEG_TOL:
+            if dread < -SEG_TOL:
+                continue
+            if dref < -SEG_TOL:
+                s0, e0 = (a[3], b[4]) if a[5] else (b[3], a[4])
+                if min_sv_size <= e0 - s0 <= SPLIT_MAX_DEL:
+                    marks.append((3, s0 + 1, e0 - s0, name))
                 continue
             dev = dread - dref
             anchor = b[4] if a[5] else a[4]
