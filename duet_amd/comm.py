@@ -53,13 +53,13 @@ def _recv_blob(sock):
 class TcpStar(object):
     def __init__(self, rank, world, addr=None, port=None, timeout=300.0):
         self.rank, self.world = int(rank), int(world)
-        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
-        port = int(port if port is not None else os.environ['MASTER_PORT'])
         self.timeout = float(timeout)
         self.peers = {}
         self.sock = None
         if self.world == 1:
             return
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(port if port is not None else os.environ['MASTER_PORT'])
         deadline = time.time() + self.timeout
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)

@@ -518,8 +518,9 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
                                                       uint32_t *part_start_out, uint32_t *n_parts_out)
 {
     __shared__ uint32_t s_pos[kScanTile + kBoxHalo], s_span[kScanTile + kBoxHalo];
-    __shared__ uint32_t s_ps[kScanTile + 2];               // starts of the tile's partitions (+ the end of the last one)
-    __shared__ uint8_t s_done[kScanTile];                  // per partition of the tile: finished here
+    // starts of the tile's partitions (+ the end of the last one) relative to the tile's first position (< 2048 + 128), bit 15: the
+    // partition is finished here.  (16 bits and no separate flag array: 26 KB of LDS per workgroup instead of 32, six per CU)
+    __shared__ uint16_t s_ps[kScanTile + 2];
     __shared__ uint16_t s_pix[kScanTile + kBoxHalo];       // per position: its partition (index within the tile's partitions)
     __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
     __shared__ PartSum s_w[kBoxThreads / 64 + 1];
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     } else {
         p_lo = tile_first[tile];
         np = tile_first[tile + 1] - p_lo;
-        for (uint32_t j = tid; j <= np; j += kBoxThreads) s_ps[j] = p.part_start[p_lo + j];
+        for (uint32_t j = tid; j <= np; j += kBoxThreads) s_ps[j] = (uint16_t)(p.part_start[p_lo + j] - t0);
     }
     // the marks' (pos, span), gathered through the sort permutation; each thread keeps its eight positions' mark indices
     // (and read indices) for the stores at the end.  Two rounds of loads, each round's loads side by side (the branches on the
@@ -649,11 +650,11 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             }
             const uint32_t d = i - H, q = d < pm ? 0u : d / pm;
             if (d == q * pm) {
-                s_ps[P + q - p_lo] = i;
+                s_ps[P + q - p_lo] = (uint16_t)(i - t0);
                 part_start_out[P + q] = i;
             }
         }
-        if (tid == 0) s_ps[np] = s_next;
+        if (tid == 0) s_ps[np] = (uint16_t)(s_next - t0);
     }
     __syncthreads();
     // one thread per partition
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
         const bool live = j < np;
         int cls = -1;
         if (live) {
-            const uint32_t s = s_ps[j], e = s_ps[j + 1], n = e - s;
+            const uint32_t s = t0 + (s_ps[j] & 0x7FFFu), e = t0 + (s_ps[j + 1] & 0x7FFFu), n = e - s;
             uint32_t plo = ~0u, phi = 0, elo = ~0u, ehi = 0, clo = ~0u, chi = 0, slo = ~0u, shi = 0;
             uint64_t sum_p = 0, sum_s = 0;
             bool bad = false;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             const float u = (float)r * p.inv_norm + (float)(shi - slo) * __builtin_amdgcn_rcpf((float)max(shi, 1u));
             // (partitions of more than 64 marks belong to the launch that started beside this one: cl_tight_big)
             const bool one = n < 2 || (n <= 64u && p.fast && p.box && !bad && u <= p.t_lo[0]);
-            s_done[j] = one ? 1 : 0;
+            if (one) s_ps[j] = (uint16_t)(s_ps[j] | 0x8000u);
             if (one) {
                 // (floor means: see emit_prep)
                 // (w: contig | type where the sort carried the records -- the tile's rows have just been read, this word is in
@@ -716,12 +717,12 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     // the finished partitions' marks keep their sorted order; the marks of the others are laid out in sorted order for the
     // agglomeration kernels, which then read their rows side by side instead of gathering them again.  (Positions before the
     // tile's first start belong to the previous tile's last partition: its block handles them as its halo.)
-    const uint32_t first = np ? s_ps[0] : 0xFFFFFFFFu, end = np ? s_ps[np] : 0u;
+    const uint32_t first = np ? t0 + (s_ps[0] & 0x7FFFu) : 0xFFFFFFFFu, end = np ? t0 + (s_ps[np] & 0x7FFFu) : 0u;
 #pragma unroll
     for (int j = 0; j <= kScanItems; ++j) {
         const uint32_t i = j < kScanItems ? t0 + j * kBoxThreads + tid : t0 + kScanTile + tid;
         if ((j == kScanItems && tid >= kBoxHalo) || i < first || i >= end) continue;
-        if (s_done[s_pix[i - t0]]) {
+        if (s_ps[s_pix[i - t0]] >> 15) {
             p.order[i] = mk[j];
             if (p.sv_mark_out) p.sv_mark_out[i] = rd[j];
         } else if (!REC) {
@@ -2442,7 +2443,11 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.idx_packed = key_bits + bits_for(M - 1) <= 64 && !(ctx->dbg & DUET_DBG_CLUSTER_PAIRS);
     // The record travels with the key (duet_recsort.hip.h) when contig, type and mark index fit one word of it
     const uint32_t idx_bits = bits_for(M - 1);
+    // ... from 1.5 M marks on: below, every pass is launch-latency bound and 8-byte keys are the cheaper thing to move (measured
+    // on the fused pipeline: 1.0 M marks, one contig 0.277 ms with the key sort against 0.287; 2 M marks over 24 contigs 0.369
+    // against 0.316, 4 M 0.483 / 0.455, 8 M 0.946 / 0.869, 2e7 2.35 / 2.22); DUET_DBG_CLUSTER_RECSORT takes it at any size
     const bool rec_mode = contig_bits + p.type_bits + idx_bits <= 32u &&
+                          (M >= (3u << 19) || (ctx->dbg & (DUET_DBG_CLUSTER_RECSORT | DUET_DBG_CLUSTER_LARGE))) &&
                           !(ctx->dbg & (DUET_DBG_CLUSTER_PAIRS | DUET_DBG_CLUSTER_LSD | DUET_DBG_CLUSTER_KEYSORT));
     p.rec_mode = rec_mode ? 1u : 0u;
     p.idx_bits = idx_bits;

@@ -31,11 +31,13 @@ def check(ctx, marks, **kw):
     # one-workgroup-per-group path / plain LSD passes instead
     # DUET_DBG_CLUSTER_KEYSORT = 0x10000: the key-only sort of rounds 1-3 (+ the gather through the permutation) where the
     # default now carries the 16-byte record with the key; DUET_DBG_CLUSTER_NOSYM = 0x20000: the pair tests of one-partition units column
-    # by column (every ordered pair) instead of every unordered pair once
+    # by column (every ordered pair) instead of every unordered pair once; DUET_DBG_CLUSTER_RECSORT = 0x40000: the record sort also
+    # below 1.5 M marks (the default there is the key-only sort; DUET_DBG_CLUSTER_LARGE implies it)
     for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600), (True, 0x800),
                        (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800), (True, 0x4000), (False, 0x8000),
                        (True, 0x10000), (False, 0x10200), (True, 0x14000), (False, 0x4200), (True, 0x10800),
-                       (True, 0x20000), (False, 0x20200), (True, 0x21200)):
+                       (True, 0x20000), (False, 0x20200), (True, 0x21200),
+                       (True, 0x40000), (False, 0x40000), (True, 0x40100), (True, 0x40800), (True, 0x44000), (True, 0x41000), (True, 0x42000), (True, 0x60000)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)

@@ -48,7 +48,10 @@ def fused_case(contigs, seed, waits):
     want_cl, want_pred, want_ps = oracle_fused(marks, soa.read_tag, depth, depth_off, 1000, 50, 2, len(contigs))
     ctx = _lib.Context(0)
     ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
-    for wait in waits:                                   # with / without the host round trip; reruns reuse every workspace
+    # with / without the host round trip; reruns reuse every workspace.  Small inputs sort 8-byte keys by default: every second
+    # run takes the record sort as well (DUET_DBG_CLUSTER_RECSORT = 0x40000; the default from 1.5 M marks on)
+    for it, wait in enumerate(waits):
+        ctx.set_debug(0x40000 if it % 2 else 0)
         ds.run_fused(ctx, wait=wait)
         got = ds.fetch()
         assert ds.n_found == len(want_cl['cand_pos'])

@@ -118,3 +118,18 @@ def test_bench_sharded_path_as_one_rank_over_rccl():
     assert d['topology']['backend'] == 'nccl' and d['topology']['world_size'] == 1 and d['topology']['rccl_version']
     assert d['gather']['collectives_per_problem'] == 1
     assert d['extra']['fused_clustered_and_phased_sharded']['parity_rank0_vs_composed_oracles'] is True
+
+
+def test_in_library_collective_one_rank():
+    """duet_comm_* directly (round 4: the collective of the sharded product path lives in libduet_ef.so): RCCL loaded at run
+    time, a communicator of ONE rank created from its own unique id on this box's GPU, the all-gather staged through device
+    buffers -- what every rank of a real multi-GPU run does with world > 1 (two ranks cannot share one GPU under RCCL)."""
+    r = fresh_interpreter(
+        'import os\nos.environ["DUET_NO_TORCH"] = "1"\nimport numpy as np\nfrom duet_amd import _lib, comm\n'
+        'ctx = _lib.Context(0)\nstar = comm.TcpStar(0, 1)\ng = comm.RcclGather(ctx, star)\n'
+        'blk = (np.arange(100003) % 251).astype(np.uint8)\nout = g.allgather(blk)\n'
+        'assert out.shape == (1, 100003) and np.array_equal(out[0], blk)\n'
+        'out = g.allgather(blk[:17])\nassert np.array_equal(out[0], blk[:17])\ng.close()\nctx.close()\nprint("COMM OK")\n',
+        {'NCCL_DEBUG': 'VERSION'})
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b'COMM OK' in r.stdout and b'RCCL version' in r.stdout + r.stderr

@@ -11,7 +11,8 @@ ctx = _lib.Context(0)
 for a in sys.argv[1:]:
     if a.startswith('dbg='):
         ctx.set_debug(int(a[4:], 0))      # DUET_DBG_* bits of include/duet_ef.h, e.g. dbg=0x200
-contigs = synth.bench_genome(20000000, 3) if big else [synth.bench_contig('1', 200000, 100000, 1)]
+n_marks = [int(float(a[6:])) for a in sys.argv[1:] if a.startswith('marks=')]      # marks=N: the 24-contig genome at another size
+contigs = synth.bench_genome(n_marks[0], 3) if n_marks else (synth.bench_genome(20000000, 3) if big else [synth.bench_contig('1', 200000, 100000, 1)])
 soa = engine.soa_from_synth(contigs)
 marks = synth.raw_marks(contigs, 1, reads_of=soa, scan_order='scan' in sys.argv[1:])
 depth, depth_off = synth.depth_bins(contigs, 1000, 1)
