@@ -3,7 +3,7 @@
 HBM, a fixed number of steps -- the command rocprofv3 wraps for the per-size kernel statistics and the FETCH_SIZE / WRITE_SIZE
 counter passes under profiles/.
 
-    python3 tools/prof_ef.py <marks> [steps=20] [deg=D]     marks <= 1.1e6: BASELINE configs[1] (one contig); else the 24-contig genome
+    python3 tools/prof_ef.py <marks> [steps=20] [deg=D] [cold]     marks <= 1.1e6: BASELINE configs[1] (one contig); else the 24-contig genome
                                                             deg=D: every candidate with exactly D marks (the walk's lanes all
                                                             loop D times: what a perfectly load-balanced walk would cost)
 """
@@ -16,6 +16,8 @@ from duet_amd.devmem import DeviceProblem
 marks = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 and '=' not in sys.argv[2] else 20
 deg = [int(a[4:]) for a in sys.argv[1:] if a.startswith('deg=')]
+cold = 'cold' in sys.argv[1:]      # cold: 1 GiB streamed through the chip between two steps -- nothing of the problem is left in
+                                   # L2 / the 256 MiB Infinity Cache, as when stage A0 has run in front (the fused pipeline)
 if marks <= 1100000:
     contigs = [synth.bench_contig('1', 200000, 100000, 1, spelled='chr1')]
 else:
@@ -29,8 +31,11 @@ with torch.cuda.stream(torch.cuda.Stream()):
     for _ in range(3):
         dp.run(ctx, st)
     torch.cuda.synchronize()
+    flush = torch.empty(1 << 28, dtype=torch.int32, device='cuda') if cold else None
     t0 = time.perf_counter()
     for _ in range(steps):
+        if cold:
+            flush.add_(1)
         dp.run(ctx, st)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
