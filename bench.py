@@ -12,11 +12,16 @@ N = 1   BASELINE.json configs[1]: one contig, ~1.0 M SV support-read marks, 200 
         (E/F) rate; `value_clustered_and_phased` is the metric read literally: the same marks, raw and shuffled, clustered
         (stage A0) AND phased in one device pipeline, with its own roofline block.  `roofline` prices the dominant kernel
         of the step (ef_classify) at config 2, where it is launch-latency bound; `roofline_bandwidth_bound` is the same
-        kernel on 2e8 marks (3.2 GB), the only size that is unambiguously HBM traffic.
+        kernel on 2e8 marks (3.2 GB), the only size that is unambiguously HBM traffic.  `scaling_point_1gpu` is configs[2]
+        (what --gpus N shards) on this one GPU: the point an N > 1 line's `value` continues -- this line's own `value` is a
+        different workload.  `summed_kernels_frac_B_EF`: B_EF over the SUM of the three kernels' times, of 8 TB/s, at 1e6 /
+        2e7 / 2e8 marks (BASELINE.md section 3's definition).  `roofline_clustered_and_phased.traffic`: FETCH_SIZE x 2 +
+        WRITE_SIZE of every kernel of the fused pipeline per run, from the committed collection profiles/*fused_traffic*.json.
 N > 1   BASELINE.json configs[2]: the synthetic whole genome (24 contigs, 2e7 marks) as ONE problem, contigs assigned to
         ranks longest-processing-time-first, each rank runs the three kernels on its shard, exactly ONE
         all_gather_into_tensor (RCCL over xGMI) per problem reassembles the records; "scaling": "strong".  Rank 0 also
-        times the same problem on its GPU alone (`same_problem_on_1_gpu`), so the line carries its own 1-GPU reference.
+        times the same problem on its GPU alone (`same_problem_on_1_gpu`), so the line carries its own 1-GPU reference
+        (`value_vs_1gpu_same_problem` = value / that).
 Rank 0 prints ONE JSON line.
 
 Algorithmic bytes: ef_classify 12 B/mark + 22 B/candidate + 8 B/read per launch; the whole
