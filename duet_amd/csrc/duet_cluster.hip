@@ -2460,13 +2460,10 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         // stage takes 285 + 33 us; 21 bits 235 us; 22 bits, two 11-bit passes, 212 us but 33 us more in the second scatter and
         // its offsets: 21 it is.  1.0 M marks: 16 bits in two 8-bit passes, groups of 32)
         uint32_t T = std::max(bits_for(M >> 4), 8u);
-        if (const char *e = getenv("DUET_RS_TBITS")) T = (uint32_t)atoi(e);                                                       // (experiments)
         T = std::min(T, key_bits);
         if (key_bits - T > 31u) T = key_bits - 31u;            // (the local stage holds the low bits in 32-bit words)
         rs_lo = key_bits - T;
-        uint32_t maxw = kRsMaxW;
-        if (const char *e = getenv("DUET_RS_MAXW")) maxw = std::min((uint32_t)kRsMaxW, std::max(4u, (uint32_t)atoi(e)));      // (experiments)
-        rs_np = (T + maxw - 1u) / maxw;
+        rs_np = (T + kRsMaxW - 1u) / kRsMaxW;
         for (uint32_t i = 0; i < rs_np; ++i) rs_w[i] = T / rs_np + (i < T % rs_np ? 1u : 0u);
     }
     const uint32_t nb_rs = (M + kRsTile - 1) / kRsTile, rs_chunks = (nb_rs + kRsChunk - 1) / kRsChunk;
@@ -2538,7 +2535,6 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         uint32_t *dtot = ctx->rx_dtot;                             // [kRsDtotCopies][2048]
         uint32_t *partial = hist + ((size_t)nb_rs << kRsMaxW);
         uint16_t *dig = (uint16_t *)valsB;                        // the next pass's digit of every record (rs_scatter -> rs_hist_dig)
-        const uint32_t swz = getenv("DUET_RS_NOSWZ") ? 0u : 1u;                                                                 // (experiments)
         const uint4 *rin = nullptr;
         int at = 0;                                               // the buffer the next launch writes
         uint32_t shift = rs_lo;
@@ -2557,11 +2553,11 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
                 hipLaunchKernelGGL(rs_col_apply, dim3(rs_chunks), dim3(256), 0, st, hist, nb_rs, w, (const uint32_t *)partial);
             }
             if (ps == 0) {
-                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
-                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
+                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
             } else {
-                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
-                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, swz, dig_out, nshift, nmask);
+                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
             }
             rin = buf[at];
             at ^= 1;

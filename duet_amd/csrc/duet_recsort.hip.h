@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void rs_col_apply(uint32_t *hist, uint32_t nb,
 // two bytes per mark instead of sixteen.
 template <int WB, bool RAW>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const uint4 *in, uint32_t n, uint32_t shift, uint32_t wbits, uint32_t nb,
-                                                         const uint32_t *hist, uint4 *out, uint32_t *dtot, uint32_t swz, uint16_t *dig_out,
+                                                         const uint32_t *hist, uint4 *out, uint32_t *dtot, uint16_t *dig_out,
                                                          uint32_t next_shift, uint32_t next_mask)
 {
     constexpr int BINS = 1 << WB, WORDS = BINS / 2, kWaves = kRsThreads / 64, kPerWave = kRsTile / kWaves, DPT = BINS / kRsThreads;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const 
     uint16_t *s_start = reinterpret_cast<uint16_t *>(s_raw + (size_t)kWaves * WORDS * 4);  // where each digit starts inside the tile
     uint4 *s_rec = reinterpret_cast<uint4 *>(s_raw);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, bins = 1u << wbits, dmask = bins - 1u;
-    const uint32_t tile = swz ? rs_tile_of(blockIdx.x, nb) : blockIdx.x;
+    const uint32_t tile = rs_tile_of(blockIdx.x, nb);
     for (uint32_t d = tid; d < (uint32_t)BINS; d += kRsThreads) s_gadj[d] = d < bins ? hist[(size_t)tile * bins + d] : 0u;
     for (uint32_t w = tid; w < (uint32_t)(kWaves * WORDS); w += kRsThreads) (&s_wloc[0][0])[w] = 0;
     const uint32_t base = tile * kRsTile, wbase = base + wave * kPerWave;
