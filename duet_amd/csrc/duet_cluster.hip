@@ -6,6 +6,9 @@
 // statement of the published SVIM 1.4.2 scheme, normative text in oracle/cluster_oracle.c / DESIGN.md section 9.
 //
 // Pipeline (DESIGN.md section 9 has the rule, the argument and the measurements):
+//   record sort    (round 4, from 1.5 M marks on; duet_recsort.hip.h) the 16-byte mark record travels with the key -- LSD passes
+//                  over the key's top bits, the low bits ordered group by group --, so that everything behind the sort reads its
+//                  rows where they lie: no permutation, no gather.  Else:
 //   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, the mark index in the spare
 //                  bits above them when it fits (else a separate value array); (pos, span[, read index]) side by side
 //   radix sort     stable LSD passes, 8-bit digits: rx_hist -> tile offsets -> rx_scatter per pass (ballot-ranked, no atomics
@@ -15,10 +18,12 @@
 //   partitions     one scan over a composite element straight off the sorted keys: natural partition starts (contig/type
 //                  change or centre gap > part_gap), a partition there and every part_max marks after -> the partition
 //                  start list and the first partition of every 2048-position tile
-//   cl_box         one workgroup per tile: gathers the tile's marks through the sort permutation, finishes the partitions whose
+//   cl_box         one workgroup per tile: takes the tile's rows (record sort) or gathers them through the sort permutation; on large
+//                  inputs it also numbers the partitions that start in its tile (no part_apply launch); finishes the partitions whose
 //                  bounding box proves ONE cluster (most, on SV-like data), lays the others' rows out in sorted order and
 //                  lists them by size class (<= 8 / 16 / 32 / 64 marks; > 64: cl_tight_big finds them itself, on a side stream beside cl_box)
-//   agglomeration  GROUP lanes per partition, one lane per mark.
+//   agglomeration  GROUP lanes per partition, one lane per mark; units that hold one or two partitions per wave evaluate every
+//                  UNORDERED pair once (the compare masks rotated on the scalar unit hand the result to the pair's other row).
 //                  small inputs: cl_fast_all -- the threshold graph and, in the same wavefront, the exact linkage on the full
 //                  triangle of sums for what that does not settle (fast_unit, link_unit);
 //                  large inputs: the contracted linkage in two tiers (tight_unit: threshold graph, tight groups, k x k sums,
@@ -27,7 +32,7 @@
 //                  every path writes each mark to its place in the partition's output (order[], and in the fused pipeline its
 //                  read index) and leaves, per cluster, a record (rank, end, floor means) at the partition's start + the
 //                  cluster's index (emit_prep)
-//   scan + cl_emit clusters per partition -> candidate bases; one thread per partition turns its clusters' records into cand_*[]
+//   scan + cl_emit clusters per partition -> candidate bases; one LANE per cluster turns the clusters' records into cand_*[]
 //
 // Bit-exactness vs the oracle: the rule works on integers (distances in fixed point relative to the threshold, cluster
 // distances exact means), so what is emitted does not depend on the order in which provably-first merges are made; the

@@ -7,15 +7,16 @@
 // IS the sort element:
 //     x = pos, y = span, z = read index (fused pipeline; else 0), w = (contig << type_bits | type) << idx_bits | mark index
 // -- 16 bytes, and the key is a function of it (contig | type in w's high bits, centre = x + y / 2), so no key array exists
-// at all.  Taken when contig, type and mark index fit w's 32 bits (2e7 marks over a genome: 5 + 1 + 25); everything else
-// keeps the key-only path.
+// at all.  Taken from 1.5 M marks on (below, every pass is launch-latency bound and 8-byte keys are the cheaper thing to move)
+// when contig, type and mark index fit w's 32 bits (2e7 marks over a genome: 5 + 1 + 25); everything else keeps the key-only
+// path.
 //
 //   rs_hist<RAW>      per 4096-mark tile, the digit counts of one pass; table laid out TILE-major (a tile's row is one
 //                     coalesced store here and one coalesced load in rs_scatter -- with 1024-way digits a digit-major table
 //                     costs a 4-byte access per digit and tile on both sides, as many sectors as the records themselves)
 //   rs_offsets_small  (up to 1024 tiles) one launch: digit totals from rs_hist's atomics, a workgroup per 64 digits runs down
 //                     its columns in 16 segments
-//   rs_col_*          (beyond) column sums per chunk of tiles -> one spine block -> exclusive offsets written back
+//   rs_col_*          (beyond) column sums per chunk of 16 tiles -> rs_offsets_small over the chunks -> offsets written back per chunk
 //   rs_scatter<WB>    stable scatter of one digit of up to WB bits: ballot-ranked per wave, the tile laid out digit-sorted in
 //                     LDS and written from there (runs leave as whole lines); it also leaves the next pass's digit of every
 //                     record beside it (rs_hist_dig reads 2 bytes per mark where rs_hist would read 16).  The first pass reads the caller's arrays and
@@ -25,9 +26,9 @@
 //   the low bits      rx_local / rx_big (duet_prims.hip.h) instantiated on records: groups of marks that agree in the globally
 //                     sorted top bits are ordered by a rank count in LDS, the record stored to its place
 //
-// Passes: LSD over the key's top bits [lo, key_bits), lo chosen so that a group holds a few dozen marks (16-17 bits of a
-// 1 M-mark input's key in two passes of 9 and 8 bits, 22 bits of a 2e7-mark genome's in two 11-bit passes), each pass stable, so equal
-// keys keep their input order (rule 1 of oracle/cluster_oracle.c).
+// Passes: LSD over the key's top bits [lo, key_bits), lo chosen so that a group holds a few dozen marks (21 bits of a 2e7-mark
+// genome's 34-bit key in an 11-bit and a 10-bit pass; 16 bits in two 8-bit passes where a 1 M-mark input is sent here), each
+// pass stable, so equal keys keep their input order (rule 1 of oracle/cluster_oracle.c).
 #ifndef DUET_RECSORT_HIP_H
 #define DUET_RECSORT_HIP_H
 
