@@ -526,7 +526,9 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     // starts of the tile's partitions (+ the end of the last one) relative to the tile's first position (< 2048 + 128), bit 15: the
     // partition is finished here.  (16 bits and no separate flag array: 26 KB of LDS per workgroup instead of 32, six per CU)
     __shared__ uint16_t s_ps[kScanTile + 2];
-    __shared__ uint16_t s_pix[kScanTile + kBoxHalo];       // per position: its partition (index within the tile's partitions)
+    // per position: its partition is finished here (a bit; the partition's thread sets the bits of its run of positions word by
+    // word).  With the 16-bit starts: 22 KB of LDS per workgroup, seven per CU (round 3: 32 KB, five)
+    __shared__ uint32_t s_dbit[(kScanTile + kBoxHalo + 31) / 32];
     __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
     __shared__ PartSum s_w[kBoxThreads / 64 + 1];
     __shared__ uint32_t s_first, s_count, s_next;
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     const uint32_t t0 = tile * kScanTile, shard = tile / p.tps;
     uint32_t p_lo = 0, np = 0;
     if (tid < kClasses) s_cnt[tid] = 0;
+    if (tid < (kScanTile + kBoxHalo + 31) / 32) s_dbit[tid] = 0;
     uint32_t hb = 0;
     PartSum carry{kNoHead, 0, 0};
     if (APPLY) {
@@ -673,7 +676,6 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             uint64_t sum_p = 0, sum_s = 0;
             bool bad = false;
             for (uint32_t i = s - t0; i < e - t0; ++i) {
-                s_pix[i] = (uint16_t)j;
                 const uint32_t ps = s_pos[i], sp = s_span[i], en = ps + sp, ce = ps + (sp >> 1);
                 bad = bad || en < ps;                        // end does not fit 32 bits: leave it to the exact path
                 plo = min(plo, ps); phi = max(phi, ps);
@@ -689,6 +691,13 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
             const bool one = n < 2 || (n <= 64u && p.fast && p.box && !bad && u <= p.t_lo[0]);
             if (one) s_ps[j] = (uint16_t)(s_ps[j] | 0x8000u);
             if (one) {
+                // the positions s - t0 .. e - t0 - 1 are done: at most five words of the bit array (a partition has <= 128 marks)
+                for (uint32_t a = s - t0, b = e - t0; a < b;) {
+                    const uint32_t w = a >> 5, hi = min(b, (w + 1u) << 5);
+                    const uint32_t m = (hi - a == 32u ? 0xFFFFFFFFu : ((1u << (hi - a)) - 1u) << (a & 31u));
+                    atomicOr(&s_dbit[w], m);
+                    a = hi;
+                }
                 // (floor means: see emit_prep)
                 // (w: contig | type where the sort carried the records -- the tile's rows have just been read, this word is in
                 // cache; cl_emit then needs nothing of a partition but its cluster records)
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     for (int j = 0; j <= kScanItems; ++j) {
         const uint32_t i = j < kScanItems ? t0 + j * kBoxThreads + tid : t0 + kScanTile + tid;
         if ((j == kScanItems && tid >= kBoxHalo) || i < first || i >= end) continue;
-        if (s_ps[s_pix[i - t0]] >> 15) {
+        if ((s_dbit[(i - t0) >> 5] >> ((i - t0) & 31u)) & 1u) {
             p.order[i] = mk[j];
             if (p.sv_mark_out) p.sv_mark_out[i] = rd[j];
         } else if (!REC) {
