@@ -11,6 +11,8 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <string.h>
+#include <functional>
+#include <mutex>
 #include <string>
 
 #include "duet_ef.h"
@@ -40,18 +42,27 @@ struct Rccl {
     std::string why;
 };
 
+void rccl_load(Rccl &r);
+
 Rccl &rccl()
 {
     static Rccl r;
-    if (r.handle || !r.why.empty()) return r;
+    static std::once_flag once;                            // (contexts of different host threads may get here together)
+    std::call_once(once, rccl_load, std::ref(r));
+    return r;
+}
+
+void rccl_load(Rccl &r)
+{
     const char *names[3] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }
     if (!r.handle) {
-        r.why = std::string("RCCL is not available (dlopen librccl.so.1: ") + (dlerror() ? dlerror() : "?") + ")";
-        return r;
+        const char *why = dlerror();
+        r.why = std::string("RCCL is not available (dlopen librccl.so.1: ") + (why ? why : "?") + ")";
+        return;
     }
     r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
     r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
@@ -62,7 +73,6 @@ Rccl &rccl()
         r.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
         r.handle = nullptr;
     }
-    return r;
 }
 
 std::string nccl_text(Rccl &r, const char *what, int code)
