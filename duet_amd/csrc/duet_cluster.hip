@@ -98,6 +98,9 @@ struct ClParams {
     uint32_t sv_depth_bin;
     uint32_t *sv_mark_out, *sv_svread, *sv_refread;
     uint8_t *sv_gt;
+    uint32_t *ef_ctg_off, *ef_zero;                   // ... and step E/F's plan: first candidate of every contig [n_contigs + 1], n_contigs + 8 words to zero
+    uint32_t n_contigs;
+    const uint32_t *n_cands;                          // (device scalar: the candidates' number, there before cl_emit starts)
     uint4 *srec;                                      // [M] per sorted position of a partition the box test left open: (pos, span, read index, mark index)
     uint4 *e_rec;                                     // [M] cluster c of the partition that starts at s, at s + c: (rank | end << 8, floor mean pos, floor mean span, -)
     uint32_t *pc;                                     // [P] clusters per partition
@@ -2309,6 +2312,14 @@ __global__ __launch_bounds__(64) void cl_link_one(const ClParams p, const uint32
 __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) p.cand_off[0] = 0;
+    // Step E/F's plan (fused pipeline): the first candidate of every contig is where the candidates' contig changes -- the
+    // candidate there writes the offsets of the contigs it opens (its own and the empty ones before it), the last candidate
+    // those behind it; the per-contig seed counts and the status words are zeroed here.  (A launch of its own for K + 1
+    // binary searches cost 6 us at 1.0 M marks.)
+    const bool plan = p.ef_ctg_off != nullptr;
+    const uint32_t n_cands = plan ? *p.n_cands : 0u;
+    if (plan && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < p.n_contigs + 8u; i += blockDim.x) p.ef_zero[i] = 0u;
     const uint32_t n_parts = *p.n_parts, lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t b0 = wave * 64u; b0 < n_parts; b0 += n_waves * 64u) {
@@ -2317,6 +2328,12 @@ __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
         const uint32_t s = has ? p.part_start[part] : 0u, nc = has ? p.pc[part] : 0u, c0 = has ? p.cbase[part] : 0u;
         uint32_t hi = 0;                                        // contig | type: in the cluster records (record sort), else from the sorted key
         if (has && !p.rec_mode) hi = (uint32_t)((p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits);
+        // (the plan: the contig of the partition in front of the wave's first one, through lane 0)
+        uint32_t k_before = 0xFFFFFFFFu;
+        if (plan && lane == 0 && b0 > 0) {
+            const uint32_t sb = p.part_start[b0 - 1u];
+            k_before = (p.rec_mode ? p.e_rec[sb].w : (uint32_t)((p.skeys[sb] & key_mask(p.key_bits)) >> p.centre_bits)) >> p.type_bits;
+        }
         const uint32_t base = (uint32_t)__shfl((int)c0, 0, 64);
         const uint32_t n_has = min(64u, n_parts - b0);
         const uint32_t tot = (uint32_t)__shfl((int)(c0 + nc), (int)n_has - 1, 64) - base;
@@ -2332,10 +2349,22 @@ __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
             }
             const uint32_t ps = (uint32_t)__shfl((int)s, (int)lo, 64), pr = (uint32_t)__shfl((int)rel, (int)lo, 64);
             const uint32_t ph = (uint32_t)__shfl((int)hi, (int)lo, 64);
-            if (c >= tot) continue;
-            const uint4 rec = p.e_rec[ps + (c - pr)];
+            const bool on = c < tot;
+            uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+            if (on) rec = p.e_rec[ps + (c - pr)];
             const uint32_t ct = p.rec_mode ? rec.w : ph;
             const uint32_t k = ct >> p.type_bits, type = ct & ((1u << p.type_bits) - 1u);
+            if (plan) {
+                uint32_t kp = (uint32_t)__shfl_up((int)k, 1, 64);
+                if (lane == 0) kp = k_before;
+                k_before = (uint32_t)__shfl((int)k, 63, 64);    // (the next 64 clusters, if there are any: this lot was full)
+                const uint32_t cand = base + c;
+                if (on && k != kp)
+                    for (uint32_t kk = kp + 1u; kk <= k; ++kk) p.ef_ctg_off[kk] = cand;
+                if (on && cand + 1u == n_cands)
+                    for (uint32_t kk = k + 1u; kk <= p.n_contigs; ++kk) p.ef_ctg_off[kk] = n_cands;
+            }
+            if (!on) continue;
             const uint32_t info = rec.x, cand = base + c;
             p.cand_off[cand + 1] = ps + (info >> 8);
             p.cand_contig[cand] = (uint16_t)k;
@@ -2388,6 +2417,8 @@ struct SvExtra {
     uint32_t depth_bin;
     uint32_t *mark_out, *svread, *refread;
     uint8_t *gt;
+    uint32_t *ef_ctg_off, *ef_zero;       // step E/F's plan, written by cl_emit (null: E/F plans for itself)
+    uint32_t n_contigs;
 };
 int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluster_result *res, void *stream_, const SvExtra *sv);
 }  // namespace
@@ -2506,6 +2537,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     if (sv) {
         p.sv_mark_in = sv->mark_in; p.sv_depth = sv->depth; p.sv_depth_off = sv->depth_off; p.sv_depth_bin = sv->depth_bin;
         p.sv_mark_out = sv->mark_out; p.sv_svread = sv->svread; p.sv_refread = sv->refread; p.sv_gt = sv->gt;
+        p.ef_ctg_off = sv->ef_ctg_off; p.ef_zero = sv->ef_zero; p.n_contigs = sv->n_contigs;
     }
     p.order = res->order; p.cand_off = res->cand_off; p.cand_pos = res->cand_pos; p.cand_span = res->cand_span;
     p.cand_contig = res->cand_contig; p.cand_type = res->cand_type;
@@ -2715,6 +2747,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
     p.cbase = cbase;
+    p.n_cands = res->n_cands;
     hipLaunchKernelGGL(cl_emit, dim3(std::min((M + 16383u) / 16384u * 8u, 4096u)), b256, 0, st, p);        // (a wave per 64 partitions, striding)
     HIP_TRY(ctx, hipGetLastError());
     if (getenv("DUET_CL_DEBUG")) {
@@ -2827,6 +2860,9 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
     sv.mark_in = pr->mark_read; sv.depth = pr->depth; sv.depth_off = d_depth_off; sv.depth_bin = pr->depth_bin;
     sv.mark_out = (uint32_t *)ctx->sv_ws[4].ptr; sv.svread = (uint32_t *)ctx->sv_ws[1].ptr;
     sv.refread = (uint32_t *)ctx->sv_ws[2].ptr; sv.gt = (uint8_t *)ctx->sv_ws[3].ptr;
+    sv.ef_ctg_off = nullptr; sv.ef_zero = nullptr; sv.n_contigs = K;
+    // (fully asynchronous runs: cl_emit writes step E/F's plan into E/F's workspace, sized for the bound of M candidates)
+    if (!n_cands_host && (rc = duet_ef_plan_on_device_prepare(ctx, K, M, st, &sv.ef_ctg_off, &sv.ef_zero))) return rc;
     if ((rc = cluster_run(ctx, &pr->marks, res, st, &sv))) return rc;
     if (!n_cands_host) {
         // fully asynchronous: E/F is planned on the device from the candidates' contig column; buffers and grids are
@@ -2839,7 +2875,7 @@ int duet_svim_phase_device(duet_ctx *ctx, const duet_svim_problem *pr, const due
         ef.cand_gt_ok = sv.gt; ef.cand_off = res->cand_off; ef.mark_read = sv.mark_out;
         ef.svlen_thres = pr->svlen_thres; ef.suppread_thres = pr->suppread_thres;
         return duet_ef_run_planned_on_device(ctx, &ef, M, (const uint32_t *)res->n_cands, nullptr, (const uint16_t *)res->cand_contig,
-                                             out_pred, out_ps, st);
+                                             out_pred, out_ps, st, true);
     }
     hipLaunchKernelGGL(sv_contig_offsets, dim3((K + 1 + 255) / 256), dim3(256), 0, st, (const uint16_t *)res->cand_contig,
                        (const uint32_t *)res->n_cands, K, d_ctg_off);

@@ -1085,7 +1085,8 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         const uint32_t ps_in = live ? p.out_ps[c] : 0;
         if (tid == 0) {
             const uint32_t last = min(c0 + 255u, n_cands - 1);
-            const uint32_t k0 = p.blk_ctg[tile];
+            // (a device-planned run with the candidates' contig column reads the tile's contig there: no table of the tiles' contigs)
+            const uint32_t k0 = (DYN && p.cand_contig) ? (uint32_t)p.cand_contig[c0] : p.blk_ctg[tile];
             uint32_t k1 = k0;
             while (last >= p.ctg_off[k1 + 1]) ++k1;
             uint32_t any = 0;
@@ -1435,12 +1436,14 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
 // Device-planned run (used by duet_svim_phase_device): the candidate count and the contig offsets exist only on the
 // device (d_n_cands, d_ctg_off[K+1]); every buffer and grid is sized for c_max candidates and the kernels read the real
 // count.  Nothing here waits for the device.
-int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
-                                  const uint32_t *d_ctg_off, const uint16_t *d_cand_contig, uint8_t *out_pred, uint32_t *out_ps,
-                                  hipStream_t stream)
+//
+// The workspace first: a producer that knows the candidates' contigs as it writes them (stage A0's cl_emit) fills in the
+// plan itself -- the contig offsets [K+1], and K + 8 zeroed words (seeds per contig, status) behind them -- and no plan
+// kernel runs (it cost the fused pipeline 6 us at 1.0 M marks, 9 us at 2e7, for K + 1 numbers).
+int duet_ef_plan_on_device_prepare(duet_ctx *ctx, uint32_t K, uint32_t c_max, hipStream_t stream, uint32_t **ctg_off_out,
+                                   uint32_t **zero_out)
 {
-    const uint32_t K = pr->n_contigs, C = c_max;
-    if (K == 0 || C == 0) return DUET_OK;
+    const uint32_t C = c_max;
     const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
     const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
     const size_t want[6] = {small_words * 4, C, (size_t)B * kCandPerBlock * 8, ((size_t)C + K + 1) * 4, ((size_t)C + K + 1) * 4,
@@ -1461,7 +1464,24 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     ctx->d_blk_ctg = w;            w += B;
     w += ((uintptr_t)w & 31) ? (32 - ((uintptr_t)w & 31)) / 4 : 0;
     ctx->d_blk_cnt = w;
-    {
+    ctx->plan_off.clear();                                     // the cached host-side plan no longer describes the workspace
+    ctx->plan_C = 0;
+    ctx->plan_stream = stream;
+    if (ctg_off_out) *ctg_off_out = ctx->d_ctg_off;
+    if (zero_out) *zero_out = ctx->d_n_one;
+    return DUET_OK;
+}
+
+int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
+                                  const uint32_t *d_ctg_off, const uint16_t *d_cand_contig, uint8_t *out_pred, uint32_t *out_ps,
+                                  hipStream_t stream, bool planned)
+{
+    const uint32_t K = pr->n_contigs, C = c_max;
+    if (K == 0 || C == 0) return DUET_OK;
+    const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
+    int rc;
+    if ((rc = duet_ef_plan_on_device_prepare(ctx, K, c_max, stream, nullptr, nullptr))) return rc;
+    if (!planned) {
         const uint32_t nthr = B > K + 8 ? B : K + 8;
         if (d_cand_contig)      // no contig offsets yet: they come out of the same launch
             hipLaunchKernelGGL(plan_device_contigs, dim3((nthr + 255) / 256), dim3(256), 0, stream, d_cand_contig, d_n_cands, K, B,
@@ -1470,9 +1490,6 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
             hipLaunchKernelGGL(plan_device, dim3((nthr + 255) / 256), dim3(256), 0, stream, d_ctg_off, K, B, ctx->d_ctg_off,
                                ctx->d_n_one, ctx->d_blk_ctg);
     }
-    ctx->plan_off.clear();                                     // the cached host-side plan no longer describes the workspace
-    ctx->plan_C = 0;
-    ctx->plan_stream = stream;
 
     Params p;
     memset(&p, 0, sizeof(p));

@@ -74,10 +74,14 @@ inline int duet_fail(duet_ctx *ctx, int code, const std::string &msg)
                              std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
 
-// device-planned E/F run (duet_ef.hip), for the fused pipeline in duet_cluster.hip
+// device-planned E/F run (duet_ef.hip), for the fused pipeline in duet_cluster.hip.  _prepare sizes the workspace for the bound
+// and names the plan's place in it: ctg_off[K + 1], and K + 8 words to zero (seeds per contig, status words) -- a producer that
+// writes both itself passes planned = true and no plan kernel is launched
+int duet_ef_plan_on_device_prepare(duet_ctx *ctx, uint32_t K, uint32_t c_max, hipStream_t stream, uint32_t **ctg_off_out,
+                                   uint32_t **zero_out);
 int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
                                   const uint32_t *d_ctg_off /* or null ... */, const uint16_t *d_cand_contig /* ... then the candidates' contig column */,
-                                  uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream);
+                                  uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream, bool planned);
 
 // host arrays of an E/F problem -> the context's staging buffers (duet_ef.hip)
 int duet_ef_upload(duet_ctx *ctx, const duet_ef_problem *pr, duet_ef_problem *d, hipStream_t s);
