@@ -102,7 +102,10 @@ struct ClParams {
     uint32_t n_contigs;
     const uint32_t *n_cands;                          // (device scalar: the candidates' number, there before cl_emit starts)
     uint4 *srec;                                      // [M] per sorted position of a partition the box test left open: (pos, span, read index, mark index)
-    uint4 *e_rec;                                     // [M] cluster c of the partition that starts at s, at s + c: (rank | end << 8, floor mean pos, floor mean span, -)
+    uint4 *e_rec;                                     // [M] cluster c >= 1 of the partition that starts at s, at s + c: (rank | end << 8, floor mean pos, floor mean span,
+                                                      // contig | type in rec_mode)
+    uint4 *e_first;                                   // [P] cluster 0 of every partition, by partition number: most partitions have one cluster, and
+                                                      // cl_emit reads these records side by side instead of one 16-byte record per line
     uint32_t *pc;                                     // [P] clusters per partition
     const uint32_t *cbase;                            // [P] first candidate of each partition
     // outputs
@@ -704,8 +707,8 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
                 // (floor means: see emit_prep)
                 // (w: contig | type where the sort carried the records -- the tile's rows have just been read, this word is in
                 // cache; cl_emit then needs nothing of a partition but its cluster records)
-                p.e_rec[s] = make_uint4(0u | (n << 8), (uint32_t)((double)sum_p / (double)n), (uint32_t)((double)sum_s / (double)n),
-                                        REC ? p.srec[s].w >> p.idx_bits : 0u);
+                p.e_first[p_lo + j] = make_uint4(0u | (n << 8), (uint32_t)((double)sum_p / (double)n), (uint32_t)((double)sum_s / (double)n),
+                                                 REC ? p.srec[s].w >> p.idx_bits : 0u);
                 p.pc[p_lo + j] = 1;
             } else {
                 cls = size_class(n);
@@ -895,8 +898,9 @@ __device__ __forceinline__ void emit_prep(const ClParams &p, bool go, uint32_t p
                 // Floor means: a sum stays below 2^40 and size <= 128, so the correctly rounded binary64 quotient
                 // lies strictly between the same two integers as the true one (or is that integer): no 64-bit division
                 const uint32_t ci = heads.count_below(rt[r]);
-                p.e_rec[s + ci] = make_uint4(rank | ((before[r] + size) << 8), (uint32_t)((double)s_sum[k][0] / (double)size),
-                                             (uint32_t)((double)s_sum[k][1] / (double)size), p.rec_mode ? p.srec[s].w >> p.idx_bits : 0u);
+                uint4 *at_ = ci ? p.e_rec + (s + ci) : p.e_first + part;
+                *at_ = make_uint4(rank | ((before[r] + size) << 8), (uint32_t)((double)s_sum[k][0] / (double)size),
+                                  (uint32_t)((double)s_sum[k][1] / (double)size), p.rec_mode ? p.srec[s].w >> p.idx_bits : 0u);
             }
         }
     }
@@ -2331,8 +2335,8 @@ __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
         // (the plan: the contig of the partition in front of the wave's first one, through lane 0)
         uint32_t k_before = 0xFFFFFFFFu;
         if (plan && lane == 0 && b0 > 0) {
-            const uint32_t sb = p.part_start[b0 - 1u];
-            k_before = (p.rec_mode ? p.e_rec[sb].w : (uint32_t)((p.skeys[sb] & key_mask(p.key_bits)) >> p.centre_bits)) >> p.type_bits;
+            k_before = (p.rec_mode ? p.e_first[b0 - 1u].w
+                                   : (uint32_t)((p.skeys[p.part_start[b0 - 1u]] & key_mask(p.key_bits)) >> p.centre_bits)) >> p.type_bits;
         }
         const uint32_t base = (uint32_t)__shfl((int)c0, 0, 64);
         const uint32_t n_has = min(64u, n_parts - b0);
@@ -2351,7 +2355,7 @@ __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
             const uint32_t ph = (uint32_t)__shfl((int)hi, (int)lo, 64);
             const bool on = c < tot;
             uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-            if (on) rec = p.e_rec[ps + (c - pr)];
+            if (on) rec = c == pr ? p.e_first[b0 + lo] : p.e_rec[ps + (c - pr)];
             const uint32_t ct = p.rec_mode ? rec.w : ph;
             const uint32_t k = ct >> p.type_bits, type = ct & ((1u << p.type_bits) - 1u);
             if (plan) {
@@ -2514,12 +2518,12 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t nb_rs = (M + kRsTile - 1) / kRsTile, rs_chunks = (nb_rs + kRsChunk - 1) / kRsChunk;
     {
         const size_t hist_legacy = (size_t)256 * nb_rx * 4, hist_rec = ((size_t)nb_rs + rs_chunks + 1) * (4u << kRsMaxW);
-        const size_t sizes[15] = {rec_mode ? 16 : (size_t)M * 8, rec_mode ? 16 : (size_t)M * 8, (size_t)M * 4, rec_mode ? (size_t)M * 2 + 16 : (size_t)M * 4,
+        const size_t sizes[16] = {rec_mode ? 16 : (size_t)M * 8, rec_mode ? 16 : (size_t)M * 8, (size_t)M * 4, rec_mode ? (size_t)M * 2 + 16 : (size_t)M * 4,
                                   rec_mode ? hist_rec : hist_legacy,
                                   ((size_t)nb_sc + 1) * sizeof(PartSum) + 16 + (size_t)nb_sc * kScanThreads, ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
                                   ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + 2 * kClasses * kShards), (size_t)M * 4 * kClasses,
-                                  ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * ((sv || rec_mode) ? 16 : 8), (size_t)M * 16};
-        for (int i = 0; i < 15; ++i)
+                                  ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * ((sv || rec_mode) ? 16 : 8), (size_t)M * 16, (size_t)M * 16};
+        for (int i = 0; i < 16; ++i)
             if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
     }
     scal = (uint32_t *)ctx->cl_ws[11].ptr;
@@ -2570,6 +2574,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     PartSum *tiles = (PartSum *)tmpA;                             // the partition scan's tile summaries: 3 words per 2048 marks
     uint8_t *hbits = (uint8_t *)tmpA + ((((size_t)nb_sc + 1) * sizeof(PartSum) + 15) & ~(size_t)15);      // ... and the head flags, a bit per mark
     p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
+    p.e_first = (uint4 *)ctx->cl_ws[15].ptr;
     if (rec_mode) {
         // the record sort (duet_recsort.hip.h): the first pass reads the caller's arrays, every pass moves 16-byte records
         RsSrc src;

@@ -38,7 +38,7 @@ struct duet_ctx {
     // host-run staging
     DevBuf h_in[9], h_out[2];
     // clustering (A0) workspace and host-run staging
-    DevBuf cl_ws[15], cl_in[4], cl_out[6];
+    DevBuf cl_ws[16], cl_in[4], cl_out[6];
     DevBuf rows_ws[8];                     // device-side row emission
     DevBuf rows_in[5];                     // host-array entry: uploaded text pool, offsets, ranks, sign flags; the rows
     DevBuf eval_ws;                        // evaluator (duet_eval.hip): one arena

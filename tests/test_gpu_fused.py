@@ -41,11 +41,29 @@ def test_fused_pipeline_config3_size():
     fused_case(synth.bench_genome(20000000, 3), 3, (False, True))
 
 
-def fused_case(contigs, seed, waits):
+def test_fused_pipeline_with_contigs_that_have_no_marks():
+    """Contigs without a mark in front of, between and behind the others (and without depth bins): step E/F's contig
+    offsets are written by cl_emit where the candidates' contig changes -- the empty ones get theirs from the candidate
+    that opens the next non-empty contig, the trailing ones from the last candidate."""
+    fused_case(H.case_contigs('genome_small', 7), 7, (False, True, False, True), contig_ids=lambda K: [2 + i + 2 * (i // 3) for i in range(K)], extra=3)
+
+
+def fused_case(contigs, seed, waits, contig_ids=None, extra=0):
     soa = engine.soa_from_synth(contigs)
     marks = synth.raw_marks(contigs, seed, reads_of=soa)
     depth, depth_off = synth.depth_bins(contigs, 1000, seed)
-    want_cl, want_pred, want_ps = oracle_fused(marks, soa.read_tag, depth, depth_off, 1000, 50, 2, len(contigs))
+    n_contigs = len(contigs)
+    if contig_ids is not None:
+        # the same marks on other contig numbers: ids[i] for contig i, `extra` empty contigs behind the last
+        ids = np.asarray(contig_ids(n_contigs), dtype=np.int64)
+        n_new = int(ids.max()) + 1 + extra
+        marks = dict(marks)
+        marks['contig'] = ids[marks['contig'].astype(np.int64)].astype(marks['contig'].dtype)
+        nb = np.zeros(n_new, dtype=np.int64)
+        nb[ids] = np.diff(depth_off.astype(np.int64))
+        depth_off = np.concatenate([[0], np.cumsum(nb)]).astype(np.uint32)       # (ids ascend: the bins keep their order)
+        n_contigs = n_new
+    want_cl, want_pred, want_ps = oracle_fused(marks, soa.read_tag, depth, depth_off, 1000, 50, 2, n_contigs)
     ctx = _lib.Context(0)
     ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
     # with / without the host round trip; reruns reuse every workspace.  Small inputs sort 8-byte keys by default: every second
