@@ -25,6 +25,9 @@ else:
 soa = engine.soa_from_synth(contigs)
 del contigs
 ctx = _lib.Context(0)
+for a in sys.argv[1:]:
+    if a.startswith('dbg='):
+        ctx.set_debug(int(a[4:], 0))      # DUET_DBG_EF_* bits of include/duet_ef.h, e.g. dbg=0x80
 dp = DeviceProblem(soa, 50, 2)
 with torch.cuda.stream(torch.cuda.Stream()):
     st = torch.cuda.current_stream().cuda_stream

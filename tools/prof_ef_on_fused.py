@@ -51,6 +51,9 @@ if resort:
 soa = engine.EfSoA(cand_ctg_off=np.searchsorted(k, np.arange(K + 1)), read_tag=soa0.read_tag, cand_pos=cand_pos, cand_svlen=cand_span,
                    cand_svread=support, cand_refread=refread, cand_gt_ok=np.ones(N, dtype=np.uint8), cand_off=off, mark_read=mark_read)
 del ds
+for a in sys.argv[1:]:
+    if a.startswith('dbg='):
+        ctx.set_debug(int(a[4:], 0))      # DUET_DBG_EF_* bits of include/duet_ef.h, e.g. dbg=0x80
 dp = DeviceProblem(soa, 50, 2)
 with torch.cuda.stream(torch.cuda.Stream()):
     st = torch.cuda.current_stream().cuda_stream
