@@ -14,7 +14,7 @@ tl() {  # name, env assignments..., then args of prof_fused
   name=$1; shift
   rm -rf /tmp/prof_$name
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$name -- python3 $R/tools/prof_fused.py "$@" > $O/${T}_$name.log 2>&1
-  python3 $R/tools/timeline.py /tmp/prof_$name 'rs_hist<true>' > $O/${T}_${name}_timeline.txt 2>&1
+  python3 $R/tools/timeline.py /tmp/prof_$name 'rs_hist<true' > $O/${T}_${name}_timeline.txt 2>&1
   grep "fused ms" $O/${T}_$name.log
   cat $O/${T}_${name}_timeline.txt
 }

@@ -58,8 +58,8 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/${T}_tl_fused_b
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/${T}_tl_fused_scan -- python3 $R/tools/prof_fused.py big scan > $O/${T}_tl_fused_scan.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/${T}_tl_fused_key -- python3 $R/tools/prof_fused.py big dbg=0x10000 > $O/${T}_tl_fused_key.log 2>&1
 python3 $R/tools/timeline.py /tmp/${T}_tl_fused cl_keys > $P/fused_config2_timeline.txt 2>&1      # (below 1.5 M marks: the key-only sort)
-python3 $R/tools/timeline.py /tmp/${T}_tl_fused_big 'rs_hist<true>' > $P/fused_2e7_timeline.txt 2>&1
-python3 $R/tools/timeline.py /tmp/${T}_tl_fused_scan 'rs_hist<true>' > $P/fused_2e7_scan_order_timeline.txt 2>&1
+python3 $R/tools/timeline.py /tmp/${T}_tl_fused_big 'rs_hist<true' > $P/fused_2e7_timeline.txt 2>&1
+python3 $R/tools/timeline.py /tmp/${T}_tl_fused_scan 'rs_hist<true' > $P/fused_2e7_scan_order_timeline.txt 2>&1
 python3 $R/tools/timeline.py /tmp/${T}_tl_fused_key cl_keys > $P/fused_2e7_key_only_sort_timeline.txt 2>&1
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"; do
