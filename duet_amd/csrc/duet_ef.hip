@@ -1009,6 +1009,13 @@ __device__ __forceinline__ void finalize_candidate(const Params &p, uint32_t c, 
                                                    const uint32_t *s_one, uint32_t n_lds, uint32_t any_empty)
 {
     if (code < 4 && !any_empty) return;                        // already final
+    // (what the candidate will need of its own columns leaves now, beside the group summary and the seeds -- not one
+    // round trip behind them)
+    const bool two = (code & (kClass2 | kClass2Slow)) != 0 && !(code & kDivZero);
+    const bool work = code >= 4 && !(code & kDivZero);
+    uint32_t c_pos = 0, c_o0 = 0, c_o1 = 0, c_svread = 0, c_refread = 0;
+    if (work) c_pos = p.cand_pos[c];
+    if (two) { c_o0 = p.cand_off[c]; c_o1 = p.cand_off[c + 1]; c_svread = p.cand_svread[c]; c_refread = p.cand_refread[c]; }
     const uint32_t *one;
     uint32_t n_one;
     if (lds_mode) {
@@ -1056,15 +1063,15 @@ __device__ __forceinline__ void finalize_candidate(const Params &p, uint32_t c, 
         } else {
             class2_from_marks(p, c, one, n_one, v, ps);
         }
-        if (v.hap1 == 0 && v.hap2 == 0) ps = nearest_ps(one, n_one, p.cand_pos[c]);       // :106
-        const uint32_t deg = p.cand_off[c + 1] - p.cand_off[c];
-        p.out_pred[c] = (uint8_t)decide(2, v, deg, p.cand_svread[c], p.cand_refread[c]);
+        if (v.hap1 == 0 && v.hap2 == 0) ps = nearest_ps(one, n_one, c_pos);              // :106
+        const uint32_t deg = c_o1 - c_o0;
+        p.out_pred[c] = (uint8_t)decide(2, v, deg, c_svread, c_refread);
         p.out_ps[c] = ps;
         return;
     }
     // kNeedNearest
     p.out_pred[c] = code & 3;
-    p.out_ps[c] = nearest_ps(one, n_one, p.cand_pos[c]);
+    p.out_ps[c] = nearest_ps(one, n_one, c_pos);
 }
 
 template <bool DYN = false>
@@ -1083,6 +1090,38 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         const bool live = c < n_cands;
         const uint8_t code = live ? p.out_pred[c] : 0;
         const uint32_t ps_in = live ? p.out_ps[c] : 0;
+        if (!DYN && p.n_small) {
+            // The contig offsets ride in the kernel arguments (K <= kSmallK): the tile's contigs are a binary search on the
+            // scalar unit, no memory; the seed count and the first 1024 seeds of the tile's contig leave TOGETHER with the
+            // candidates' codes -- one round trip where thread 0 used to walk four dependent ones (tile's contig -> contig
+            // offsets -> seed count -> seeds) in front of everybody: 7.0 -> 5.x us at config 2.
+            const uint32_t last = min(c0 + 255u, n_cands - 1);
+            uint32_t lo = 0, hi = p.n_small;                   // the last k with ctg_small[k] <= c0
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (p.ctg_small[mid] <= c0) lo = mid; else hi = mid;
+            }
+            const uint32_t k0 = lo;
+            uint32_t k1 = k0;
+            while (last >= p.ctg_small[k1 + 1]) ++k1;
+            const uint32_t base = p.ctg_small[k0] + k0 + 1;
+            uint32_t ahead[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ahead[i] = p.onebuf[min(base + tid + 256u * i, p.one_cap - 1u)];
+            uint32_t any = 0;
+            for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0) ? 1u : 0u;
+            const uint32_t n0 = p.n_one[k0];
+            const bool lds_mode = k0 == k1 && n0 > 0 && n0 <= kOneLds;
+            if (lds_mode) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (tid + 256u * i < n0) s_one[tid + 256u * i] = ahead[i];
+                for (uint32_t i = tid + 1024u; i < n0; i += 256u) s_one[i] = p.onebuf[base + i];
+            }
+            __syncthreads();
+            if (live) finalize_candidate(p, c, code, ps_in, k0, lds_mode, s_one, n0, any);
+            break;
+        }
         if (tid == 0) {
             const uint32_t last = min(c0 + 255u, n_cands - 1);
             // (a device-planned run with the candidates' contig column reads the tile's contig there: no table of the tiles' contigs)
