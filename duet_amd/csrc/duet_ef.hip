@@ -1074,7 +1074,8 @@ __device__ __forceinline__ void finalize_candidate(const Params &p, uint32_t c, 
     p.out_ps[c] = nearest_ps(one, n_one, c_pos);
 }
 
-template <bool DYN = false>
+// TPB: tiles of 256 candidates per workgroup (host-planned runs with the contig offsets in the kernel arguments only)
+template <bool DYN = false, int TPB = 1>
 __global__ __launch_bounds__(256) void ef_finalize(const Params p)
 {
     __shared__ uint32_t s_one[kOneLds];
@@ -1083,6 +1084,51 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
     STAMP(2, 0);
     if (blockIdx.x == 0 && tid == 0) p.status[1] = 0;          // the summary pool's counter, for the next run's ef_classify
     const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
+    if (!DYN && p.n_small) {
+        // The contig offsets ride in the kernel arguments (K <= kSmallK): the tile's contigs are a binary search on the
+        // scalar unit, no memory; the seed count and the first 1024 seeds of the tile's contig leave TOGETHER with the
+        // candidates' codes -- one round trip where thread 0 used to walk four dependent ones (tile's contig -> contig
+        // offsets -> seed count -> seeds) in front of everybody.
+        const uint32_t c0 = blockIdx.x * (256u * TPB);
+        uint8_t code[TPB];
+        uint32_t ps_in[TPB];
+#pragma unroll
+        for (int r = 0; r < TPB; ++r) {
+            const uint32_t c = c0 + 256u * r + tid;
+            code[r] = c < n_cands ? p.out_pred[c] : 0;
+            ps_in[r] = c < n_cands ? p.out_ps[c] : 0;
+        }
+        const uint32_t last = min(c0 + 256u * TPB - 1u, n_cands - 1);
+        uint32_t lo = 0, hi = p.n_small;                       // the last k with ctg_small[k] <= c0
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.ctg_small[mid] <= c0) lo = mid; else hi = mid;
+        }
+        const uint32_t k0 = lo;
+        uint32_t k1 = k0;
+        while (last >= p.ctg_small[k1 + 1]) ++k1;
+        const uint32_t base = p.ctg_small[k0] + k0 + 1;
+        uint32_t ahead[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ahead[i] = p.onebuf[min(base + tid + 256u * i, p.one_cap - 1u)];
+        uint32_t any = 0;
+        for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0) ? 1u : 0u;
+        const uint32_t n0 = p.n_one[k0];
+        const bool lds_mode = k0 == k1 && n0 > 0 && n0 <= kOneLds;
+        if (lds_mode) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tid + 256u * i < n0) s_one[tid + 256u * i] = ahead[i];
+            for (uint32_t i = tid + 1024u; i < n0; i += 256u) s_one[i] = p.onebuf[base + i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < TPB; ++r) {
+            const uint32_t c = c0 + 256u * r + tid;
+            if (c < n_cands) finalize_candidate(p, c, code[r], ps_in[r], k0, lds_mode, s_one, n0, any);
+        }
+        return;
+    }
     // (device-planned runs stride over the real tiles like ef_classify)
     for (uint32_t tile = blockIdx.x; !DYN || tile * 256u < n_cands; tile += gridDim.x) {
         const uint32_t c0 = tile * 256u;
@@ -1090,38 +1136,6 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         const bool live = c < n_cands;
         const uint8_t code = live ? p.out_pred[c] : 0;
         const uint32_t ps_in = live ? p.out_ps[c] : 0;
-        if (!DYN && p.n_small) {
-            // The contig offsets ride in the kernel arguments (K <= kSmallK): the tile's contigs are a binary search on the
-            // scalar unit, no memory; the seed count and the first 1024 seeds of the tile's contig leave TOGETHER with the
-            // candidates' codes -- one round trip where thread 0 used to walk four dependent ones (tile's contig -> contig
-            // offsets -> seed count -> seeds) in front of everybody: 7.0 -> 5.x us at config 2.
-            const uint32_t last = min(c0 + 255u, n_cands - 1);
-            uint32_t lo = 0, hi = p.n_small;                   // the last k with ctg_small[k] <= c0
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (p.ctg_small[mid] <= c0) lo = mid; else hi = mid;
-            }
-            const uint32_t k0 = lo;
-            uint32_t k1 = k0;
-            while (last >= p.ctg_small[k1 + 1]) ++k1;
-            const uint32_t base = p.ctg_small[k0] + k0 + 1;
-            uint32_t ahead[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ahead[i] = p.onebuf[min(base + tid + 256u * i, p.one_cap - 1u)];
-            uint32_t any = 0;
-            for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0) ? 1u : 0u;
-            const uint32_t n0 = p.n_one[k0];
-            const bool lds_mode = k0 == k1 && n0 > 0 && n0 <= kOneLds;
-            if (lds_mode) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (tid + 256u * i < n0) s_one[tid + 256u * i] = ahead[i];
-                for (uint32_t i = tid + 1024u; i < n0; i += 256u) s_one[i] = p.onebuf[base + i];
-            }
-            __syncthreads();
-            if (live) finalize_candidate(p, c, code, ps_in, k0, lds_mode, s_one, n0, any);
-            break;
-        }
         if (tid == 0) {
             const uint32_t last = min(c0 + 255u, n_cands - 1);
             // (a device-planned run with the candidates' contig column reads the tile's contig there: no table of the tiles' contigs)
@@ -1464,7 +1478,18 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     else
         hipExtLaunchKernelGGL(ef_classify<false>, dim3(blocks), dim3(kCandPerBlock), 0, stream, ev[0], ev[1], 0, p);
     hipExtLaunchKernelGGL(ef_seed_sort, dim3(pr->n_contigs), dim3(kSortThreads), 0, stream, ev[2], ev[3], 0, p);
-    hipExtLaunchKernelGGL(ef_finalize<false>, dim3((pr->n_cands + 255) / 256), dim3(256), 0, stream, ev[4], ev[5], 0, p);
+    {
+        // Tiles per workgroup: the per-workgroup costs (launch, the tile's contigs, the seeds into LDS) once per 512 / 1024
+        // candidates where there are enough of them to fill the chip anyway -- measured (tools/gpu/r4_fin.sh), 1 / 2 / 4 tiles:
+        // 1e5 candidates 6.3 / 8.5 / 11.2 us, 2e6 20.6 / 18.4 / 18.8 us, 2e7 127 / 91 / 75 us
+        const uint32_t C = pr->n_cands;
+        int tpb = (!p.n_small || C < 1000000u) ? 1 : (C < 8000000u ? 2 : 4);
+        if (p.n_small && (ctx->dbg & DUET_DBG_EF_FIN_TPB2)) tpb = 2;
+        if (p.n_small && (ctx->dbg & DUET_DBG_EF_FIN_TPB4)) tpb = 4;
+        if (tpb == 4) hipExtLaunchKernelGGL((ef_finalize<false, 4>), dim3((C + 1023) / 1024), dim3(256), 0, stream, ev[4], ev[5], 0, p);
+        else if (tpb == 2) hipExtLaunchKernelGGL((ef_finalize<false, 2>), dim3((C + 511) / 512), dim3(256), 0, stream, ev[4], ev[5], 0, p);
+        else hipExtLaunchKernelGGL((ef_finalize<false, 1>), dim3((C + 255) / 256), dim3(256), 0, stream, ev[4], ev[5], 0, p);
+    }
     HIP_TRY(ctx, hipGetLastError());
     ctx->pending_check = true;
     return DUET_OK;

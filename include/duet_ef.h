@@ -137,6 +137,8 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
  * partition through the exact linkage instead of the bounding-box / threshold-graph fast paths (the outputs are
  * identical; tests use it to exercise both).  0 in production. */
 #define DUET_DBG_EF_NO_SEED_HASH 0x40u   /* E/F: ef_seed_sort orders an unsorted seed list itself instead of taking its distinct values through a hash set first */
+#define DUET_DBG_EF_FIN_TPB2 0x20u       /* E/F: ef_finalize takes two tiles of 256 candidates per workgroup whatever the size (default from 1 M candidates on) */
+#define DUET_DBG_EF_FIN_TPB4 0x80u       /* ... four (default from 8 M candidates on) */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */

@@ -112,6 +112,20 @@ def test_fuzz_soa(ctx, seed):
     check_against_c_oracle(ctx, soa, 52, 4)
 
 
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_finalize_with_two_and_four_tiles_per_workgroup(ctx, seed):
+    """ef_finalize takes 2 / 4 tiles of 256 candidates per workgroup from 1 M / 8 M candidates on; the debug bits 0x20 / 0x80 force
+    that on small problems: contigs that start and end inside a workgroup's candidates, contigs without seeds, several phase sets."""
+    soa = soa_fuzz.random_soa(5000 + seed, n_contigs=6, cands_per_contig=(100, 1500), reads_per_contig=(100, 700), n_ps=(1, 12))
+    for dbg in (0x20, 0x80):
+        ctx.set_debug(dbg)
+        try:
+            for thres in ((50, 2), (0, 0)):
+                check_against_c_oracle(ctx, soa, *thres)
+        finally:
+            ctx.set_debug(0)
+
+
 @pytest.mark.parametrize('n_ps', [3, 40, 700, 1900, 2300, 6000])
 def test_unsorted_candidates_seed_set_paths(ctx, n_ps):
     """Candidates NOT in position order with n_ps phase sets per contig: the seed list arrives unsorted.  Few distinct seeds go
