@@ -2598,7 +2598,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
             const uint32_t w = rs_w[ps];
             uint32_t *htot = rs_small ? dtot : (uint32_t *)nullptr;
             if (ps == 0) hipLaunchKernelGGL(rs_hist<true>, dim3(nb_rs), dim3(kRsHistThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, hist, htot, big_count);
-            else hipLaunchKernelGGL(rs_hist_dig, dim3(nb_rs), dim3(kRsHistThreads), 0, st, (const uint16_t *)dig, M, w, hist, htot);
+            else hipLaunchKernelGGL(rs_hist_dig, dim3(nb_rs), dim3(kRsDigThreads), 0, st, (const uint16_t *)dig, M, w, hist, htot);
             uint16_t *dig_out = ps + 1 < rs_np ? dig : (uint16_t *)nullptr;
             const uint32_t nshift = shift + w, nmask = ps + 1 < rs_np ? (1u << rs_w[ps + 1]) - 1u : 0u;
             if (rs_small) {

@@ -110,26 +110,34 @@ __global__ __launch_bounds__(kRsHistThreads) void rs_hist(const RsSrc src, const
     }
 }
 
-// ... from the digits the pass before left beside the records
-__global__ __launch_bounds__(kRsHistThreads) void rs_hist_dig(const uint16_t *dig, uint32_t n, uint32_t wbits, uint32_t *hist, uint32_t *dtot)
+// ... from the digits the pass before left beside the records.  256 threads, sixteen digits each (two 16-byte loads): with
+// 1024 threads of four digits the launch was 78 k waves of a few dozen instructions -- 20 us for 40 MB at 2e7 marks
+constexpr int kRsDigThreads = 256;
+__global__ __launch_bounds__(kRsDigThreads) void rs_hist_dig(const uint16_t *dig, uint32_t n, uint32_t wbits, uint32_t *hist, uint32_t *dtot)
 {
     __shared__ uint32_t s_h[1 << kRsMaxW];
     const uint32_t tid = threadIdx.x, bins = 1u << wbits, tile = blockIdx.x;
-    for (uint32_t d = tid; d < bins; d += kRsHistThreads) s_h[d] = 0;
+    for (uint32_t d = tid; d < bins; d += kRsDigThreads) s_h[d] = 0;
     __syncthreads();
-    static_assert(kRsTile == kRsHistThreads * 4, "four digits (one 8-byte load) per thread");
-    const uint32_t i = tile * kRsTile + tid * 4u;
-    if (i + 3u < n) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(dig + i);
-        atomicAdd(&s_h[v.x & 0xFFFFu], 1u);
-        atomicAdd(&s_h[v.x >> 16], 1u);
-        atomicAdd(&s_h[v.y & 0xFFFFu], 1u);
-        atomicAdd(&s_h[v.y >> 16], 1u);
-    } else {
-        for (uint32_t j = i; j < n; ++j) atomicAdd(&s_h[dig[j]], 1u);
+    static_assert(kRsTile == kRsDigThreads * 16, "sixteen digits (two 16-byte loads) per thread");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // (thread tid takes digits [8 tid, 8 tid + 8) of the tile's first and of its second half: a wave's load is one run of memory)
+        const uint32_t i = tile * kRsTile + h * (kRsTile / 2) + tid * 8u;
+        if (i + 7u < n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(dig + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                atomicAdd(&s_h[w[k] & 0xFFFFu], 1u);
+                atomicAdd(&s_h[w[k] >> 16], 1u);
+            }
+        } else {
+            for (uint32_t j = i; j < n && j < i + 8u; ++j) atomicAdd(&s_h[dig[j]], 1u);
+        }
     }
     __syncthreads();
-    for (uint32_t d = tid; d < bins; d += kRsHistThreads) {
+    for (uint32_t d = tid; d < bins; d += kRsDigThreads) {
         const uint32_t c = s_h[d];
         hist[(size_t)tile * bins + d] = c;
         if (dtot && c) atomicAdd(&dtot[(tile % kRsDtotCopies) * bins + d], c);
