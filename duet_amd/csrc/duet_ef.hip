@@ -1136,6 +1136,23 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         const bool live = c < n_cands;
         const uint8_t code = live ? p.out_pred[c] : 0;
         const uint32_t ps_in = live ? p.out_ps[c] : 0;
+        if (DYN && p.cand_contig) {
+            // device-planned run with the candidates' contig column: the tile's first and last contig from the column (they leave
+            // with the codes), then the contig's offset and seed count, then the seeds -- every thread the same (scalar) loads,
+            // not thread 0 walking them in front of a barrier
+            const uint32_t last = min(c0 + 255u, n_cands - 1);
+            const uint32_t k0 = p.cand_contig[c0], k1 = p.cand_contig[last];
+            uint32_t any = 0;
+            for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0) ? 1u : 0u;
+            const uint32_t n0 = p.n_one[k0], base = p.ctg_off[k0] + k0 + 1;
+            const bool lds_mode = k0 == k1 && n0 > 0 && n0 <= kOneLds;
+            if (lds_mode)
+                for (uint32_t i = tid; i < n0; i += 256u) s_one[i] = p.onebuf[base + i];
+            __syncthreads();
+            if (live) finalize_candidate(p, c, code, ps_in, k0, lds_mode, s_one, n0, any);
+            __syncthreads();                                   // s_one is reused
+            continue;
+        }
         if (tid == 0) {
             const uint32_t last = min(c0 + 255u, n_cands - 1);
             // (a device-planned run with the candidates' contig column reads the tile's contig there: no table of the tiles' contigs)
