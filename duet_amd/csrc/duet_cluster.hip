@@ -2606,14 +2606,13 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
             } else {
                 hipLaunchKernelGGL(rs_col_reduce, dim3(rs_chunks), dim3(256), 0, st, (const uint32_t *)hist, nb_rs, w, partial, dtot);
                 hipLaunchKernelGGL(rs_offsets_small, dim3(std::max(1u, (1u << w) / 64u)), dim3(1024), 0, st, partial, rs_chunks, w, (const uint32_t *)dtot);
-                hipLaunchKernelGGL(rs_col_apply, dim3(rs_chunks), dim3(256), 0, st, hist, nb_rs, w, (const uint32_t *)partial);
             }
             if (ps == 0) {
-                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
-                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
+                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask, rs_small ? (const uint32_t *)nullptr : (const uint32_t *)partial);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, true>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, (const uint4 *)nullptr, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask, rs_small ? (const uint32_t *)nullptr : (const uint32_t *)partial);
             } else {
-                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
-                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask);
+                if (w <= 10u) hipLaunchKernelGGL((rs_scatter<10, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask, rs_small ? (const uint32_t *)nullptr : (const uint32_t *)partial);
+                else hipLaunchKernelGGL((rs_scatter<kRsMaxW, false>), dim3(nb_rs), dim3(kRsThreads), 0, st, src, rin, M, shift, w, nb_rs, (const uint32_t *)hist, buf[at], dtot, dig_out, nshift, nmask, rs_small ? (const uint32_t *)nullptr : (const uint32_t *)partial);
             }
             rin = buf[at];
             at ^= 1;

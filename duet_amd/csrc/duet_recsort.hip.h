@@ -16,7 +16,8 @@
 //                     costs a 4-byte access per digit and tile on both sides, as many sectors as the records themselves)
 //   rs_offsets_small  (up to 1024 tiles) one launch: digit totals from rs_hist's atomics, a workgroup per 64 digits runs down
 //                     its columns in 16 segments
-//   rs_col_*          (beyond) column sums per chunk of 16 tiles -> rs_offsets_small over the chunks -> offsets written back per chunk
+//   rs_col_reduce     (beyond) column sums per chunk of 16 tiles -> rs_offsets_small over the chunks; rs_scatter adds the counts of the
+//                     tiles in front of its own in the chunk itself
 //   rs_scatter<WB>    stable scatter of one digit of up to WB bits: ballot-ranked per wave, the tile laid out digit-sorted in
 //                     LDS and written from there (runs leave as whole lines); it also leaves the next pass's digit of every
 //                     record beside it (rs_hist_dig reads 2 bytes per mark where rs_hist would read 16).  The first pass reads the caller's arrays and
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(1024) void rs_offsets_small(uint32_t *hist, uint32_
     }
 }
 
-// more tiles: column sums per chunk of kRsChunk tiles, one block for the chunks' running sums and the digits' bases, the
-// offsets written back per chunk
+// more tiles: column sums per chunk of kRsChunk tiles, one block for the chunks' running sums and the digits' bases; rs_scatter
+// finds a tile's offsets from its chunk's (below)
 // (the chunks' sums then go through rs_offsets_small as if they were tiles -- a few hundred of them: the digit totals by one
 // atomic per chunk and digit)
 __global__ __launch_bounds__(256) void rs_col_reduce(const uint32_t *hist, uint32_t nb, uint32_t wbits, uint32_t *partial /* [chunks][bins] */,
@@ -217,22 +218,6 @@ __global__ __launch_bounds__(256) void rs_col_reduce(const uint32_t *hist, uint3
         if (s) atomicAdd(&dtot[(c % kRsDtotCopies) * bins + d], s);
     }
 }
-__global__ __launch_bounds__(256) void rs_col_apply(uint32_t *hist, uint32_t nb, uint32_t wbits, const uint32_t *partial /* the chunks' offsets */)
-{
-    const uint32_t bins = 1u << wbits, c = blockIdx.x, t0 = c * kRsChunk, t1 = min(nb, t0 + kRsChunk);
-    for (uint32_t d = threadIdx.x; d < bins; d += 256u) {
-        uint32_t run = partial[(size_t)c * bins + d];
-        uint32_t v[kRsChunk];
-#pragma unroll
-        for (int j = 0; j < kRsChunk; ++j) v[j] = t0 + j < t1 ? hist[(size_t)(t0 + j) * bins + d] : 0u;
-#pragma unroll
-        for (int j = 0; j < kRsChunk; ++j) {
-            if (t0 + j < t1) hist[(size_t)(t0 + j) * bins + d] = run;
-            run += v[j];
-        }
-    }
-}
-
 // stable scatter of one digit (bits [shift, shift + wbits) of the key, wbits <= WB); hist holds the offsets.
 // 512 threads = 8 waves, 8 marks per thread.  Each wave ranks its 512 marks on its own: ballot match inside the wave, then ONE
 // returning LDS add per round by the digit's first lane into the wave's counter row (two 16-bit counters per word) -- the adds
@@ -245,7 +230,8 @@ __global__ __launch_bounds__(256) void rs_col_apply(uint32_t *hist, uint32_t nb,
 template <int WB, bool RAW>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const uint4 *in, uint32_t n, uint32_t shift, uint32_t wbits, uint32_t nb,
                                                          const uint32_t *hist, uint4 *out, uint32_t *dtot, uint16_t *dig_out,
-                                                         uint32_t next_shift, uint32_t next_mask)
+                                                         uint32_t next_shift, uint32_t next_mask,
+                                                         const uint32_t *chunk_off /* [chunks][bins], or null: hist holds the tiles' offsets */)
 {
     constexpr int BINS = 1 << WB, WORDS = BINS / 2, kWaves = kRsThreads / 64, kPerWave = kRsTile / kWaves, DPT = BINS / kRsThreads;
     constexpr int kStage = 2048, kRounds = kRsTile / kStage;
@@ -259,7 +245,23 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter(const RsSrc src, const 
     uint4 *s_rec = reinterpret_cast<uint4 *>(s_raw);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, bins = 1u << wbits, dmask = bins - 1u;
     const uint32_t tile = rs_tile_of(blockIdx.x, nb);
-    for (uint32_t d = tid; d < (uint32_t)BINS; d += kRsThreads) s_gadj[d] = d < bins ? hist[(size_t)tile * bins + d] : 0u;
+    if (chunk_off) {
+        // more than kRsSmallTiles tiles: hist holds the tiles' COUNTS and chunk_off the offsets of every chunk of kRsChunk tiles;
+        // the tile adds up the counts of the tiles in front of it in its chunk itself (rows its XCD's other workgroups read as well:
+        // they come out of L2) -- a launch that wrote every tile's offsets back read and wrote the 40 MB table once more
+        const uint32_t c = tile / kRsChunk, t0 = c * kRsChunk;
+        for (uint32_t d = tid; d < (uint32_t)BINS; d += kRsThreads) {
+            uint32_t v = 0;
+            if (d < bins) {
+                v = chunk_off[(size_t)c * bins + d];
+#pragma unroll
+                for (int j = 0; j < kRsChunk - 1; ++j) v += t0 + j < tile ? hist[(size_t)(t0 + j) * bins + d] : 0u;
+            }
+            s_gadj[d] = v;
+        }
+    } else {
+        for (uint32_t d = tid; d < (uint32_t)BINS; d += kRsThreads) s_gadj[d] = d < bins ? hist[(size_t)tile * bins + d] : 0u;
+    }
     for (uint32_t w = tid; w < (uint32_t)(kWaves * WORDS); w += kRsThreads) (&s_wloc[0][0])[w] = 0;
     const uint32_t base = tile * kRsTile, wbase = base + wave * kPerWave;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));

@@ -30,7 +30,7 @@ def per_kernel(path, counter):
 marks, fetch_csv, write_csv, collected, command = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5]
 ft, fc = per_kernel(fetch_csv, 'FETCH_SIZE')
 wt, wc = per_kernel(write_csv, 'WRITE_SIZE')
-pipeline = [k for k in ft if k.split('<')[0] in ('rs_hist', 'rs_hist_dig', 'rs_offsets_small', 'rs_col_reduce', 'rs_col_apply', 'rs_scatter',
+pipeline = [k for k in ft if k.split('<')[0] in ('rs_hist', 'rs_hist_dig', 'rs_offsets_small', 'rs_col_reduce', 'rs_scatter',
                                                   'rx_local', 'rx_big', 'part_reduce', 'part_spine', 'part_apply', 'cl_box', 'cl_tight_big',
                                                   'cl_link_one', 'cl_fast_all', 'cl_tight_all', 'cl_tight_one', 'cl_tier2_one', 'cl_tier2_all',
                                                   'scan_reduce', 'scan_spine', 'scan_apply', 'cl_emit', 'plan_device_contigs', 'ef_classify',
