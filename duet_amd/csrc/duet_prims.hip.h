@@ -371,7 +371,11 @@ void launch_scan(const Load in, uint32_t n, uint32_t *part, const Store out, uin
                  const uint32_t *n_dyn = nullptr /* device: the real element count, n being its bound */)
 {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
-    if (nb >= 1 && nb <= kSelfSpine && !force_spine) {
+    // (a device-side element count, usually a fraction of the bound -- stage A0's partitions are 7 % of its marks --: the tiles
+    // past it neither load nor combine anything, so the spine-less path also pays where the BOUND has more tiles than kSelfSpine;
+    // up to kSelfSpineDyn of them, so that an input whose count does reach the bound costs tens of microseconds, not more)
+    constexpr uint32_t kSelfSpineDyn = 16384;
+    if (nb >= 1 && (nb <= kSelfSpine || (n_dyn && nb <= kSelfSpineDyn)) && !force_spine) {
         hipLaunchKernelGGL((scan_reduce<OP, Load>), dim3(nb), dim3(kScanThreads), 0, st, in, n, part, zero14, n_dyn);
         hipLaunchKernelGGL((scan_apply<OP, Load, Store, true>), dim3(nb), dim3(kScanThreads), 0, st, in, n, (const uint32_t *)part, out,
                            total, n_dyn);
