@@ -27,7 +27,10 @@ for i in range(n_ef):
     rc, wp, ws = c_oracle.ef(soa, sl, sr)
     if rc:
         continue
+    # (E/F paths in turn: default; ef_finalize with two / four tiles per workgroup; the seed sort without its hash set)
+    ctx.set_debug([0, 0x20, 0x80, 0x40][i % 4])
     p, s = ctx.run_host(soa, sl, sr)
+    ctx.set_debug(0)
     if not (np.array_equal(p, wp) and np.array_equal(s, ws)):
         bad += 1
         print('E/F MISMATCH seed', 5000 + i, k)
