@@ -542,6 +542,134 @@ def weak_grouped_run(args, ctx, torch, dist_mod, rank, world, local_rank):
             'marks_per_s': marks * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3, 'parity_vs_oracle': bool(oks == world)}
 
 
+LINE_BUDGET = 8000        # bytes of the ONE printed JSON line (round 4's 22.5 kB line was not parsed by the driver; 11.9 kB was)
+
+_ROOF_KEYS = ('kernel', 'kernels', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'real_hbm_frac',
+              'algorithmic_bytes_per_launch', 'algorithmic_bytes_per_run', 'launch_ms', 'run_ms', 'launches_timed', 'workload')
+
+
+def _num(x):
+    """Floats to 6 significant digits (the line is a record, not an archive; the detail file keeps everything)."""
+    if isinstance(x, float):
+        return float('%.6g' % x)
+    if isinstance(x, dict):
+        return {k: _num(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v) for v in x]
+    return x
+
+
+def _slim_roofline(r):
+    if not isinstance(r, dict):
+        return r
+    out = {k: r[k] for k in _ROOF_KEYS if k in r}
+    if isinstance(out.get('kernels'), str):
+        out['kernels'] = out['kernels'][:60]
+    src = r.get('traffic_source')
+    if isinstance(src, dict) and src.get('file'):
+        out['traffic_file'] = src['file']
+    return out
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line rank 0 prints: the contract's keys, `roofline`, `cpu_baseline` and a handful of numbers per extra
+    point -- no per-kernel tables, no prose.  Everything else (`full`) goes to the detail file and to stderr.  Pure
+    function of `full` (tests/test_bench_line.py builds it from canned numbers)."""
+    top = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+           'dtype', 'data', 'parity_vs_oracle', 'plumbing_test_one_gpu', 'kernels_us_isolated', 'value_clustered_and_phased',
+           'ms_per_step_clustered_and_phased', 'parity_clustered_and_phased_vs_composed_oracles', 'value_vs_1gpu_same_problem',
+           'collective')
+    out = {k: full[k] for k in top if k in full}
+    cfg = full.get('config', {})
+    out['config'] = _pick(cfg, ('workload', 'marks', 'candidates', 'reads', 'contigs', 'marks_per_gpu', 'candidates_per_gpu',
+                                'reads_per_gpu', 'parallelism', 'svlen_thres', 'suppread_thres', 'generator'))
+    if isinstance(out['config'].get('workload'), str):
+        out['config']['workload'] = out['config']['workload'][:200]
+    for k in ('roofline', 'roofline_clustered_and_phased', 'roofline_bandwidth_bound'):
+        if k in full:
+            out[k] = _slim_roofline(full[k])
+    if 'cpu_baseline' in full:
+        cb = full['cpu_baseline']
+        out['cpu_baseline'] = _pick(cb, ('value', 'unit', 'cores', 'kind', 'ms_per_pass', 'host_cpu_model', 'host_cores'))
+        out['cpu_baseline']['sample'] = str(cb.get('sample', ''))[:160]
+        cal = cb.get('calibration')
+        if isinstance(cal, dict):
+            out['cpu_baseline']['reference_python_estimate_marks_per_s'] = cal.get('reference_python_ef_marks_per_s_here_estimate')
+    for k in ('cpu_baseline_ncore', 'cpu_baseline_python'):
+        if k in full:
+            out[k] = _pick(full[k], ('value', 'unit', 'cores', 'kind'))
+    if 'scaling_point_1gpu' in full:
+        out['scaling_point_1gpu'] = _pick(full['scaling_point_1gpu'], ('value', 'unit', 'ms_per_step', 'marks'))
+    if 'summed_kernels_frac_B_EF' in full:
+        out['summed_kernels_frac_B_EF'] = {k: v.get('frac_of_8TBs') for k, v in full['summed_kernels_frac_B_EF'].items()}
+    # N > 1
+    if 'sharding' in full:
+        out['sharding'] = _pick(full['sharding'], ('lpt_imbalance_max_over_mean_marks', 'record_bytes_per_rank'))
+    if 'gather' in full:
+        out['gather'] = full['gather']
+    if 'per_rank' in full:
+        pr = full['per_rank']
+        out['per_rank'] = {'marks': [r.get('marks') for r in pr], 'ef_classify_us': [round(r.get('ef_classify_ms', 0) * 1e3, 2) for r in pr],
+                           'kernels_only_us': [round(r.get('kernels_only_ms_per_step', 0) * 1e3, 2) for r in pr]}
+    if 'topology' in full:
+        tp = full['topology']
+        out['topology'] = _pick(tp, ('backend', 'world_size', 'rccl_version', 'one_gpu_plumbing_mode', 'distinct_devices'))
+        out['topology']['devices'] = ['%s@%s' % (r.get('device'), r.get('pci_bus_id')) for r in tp.get('ranks', [])]
+    if 'same_problem_on_1_gpu' in full and full['same_problem_on_1_gpu']:
+        out['same_problem_on_1_gpu'] = _pick(full['same_problem_on_1_gpu'], ('ms_per_step', 'marks_per_s', 'parity_vs_oracle'))
+    ex = full.get('extra')
+    if isinstance(ex, dict):
+        keep = ('marks', 'candidates', 'candidates_found', 'phased', 'ms_per_step', 'ms_per_run', 'marks_per_s', 'parity_vs_oracle',
+                'parity_vs_composed_oracles', 'parity_rank0_vs_composed_oracles', 'ms_per_run_with_count_returned', 'kernels_ms',
+                'kernels_us', 'us_per_job', 'streams', 't_kernels_ms', 't_abi_ms', 't_e2e_ms', 'scaling', 'error',
+                'pipeline_only_ms_per_step_max_over_ranks', 'ef_classify_us', 'lane_efficiency', 'degree_mean', 'degree_max',
+                'sha256_matches_reference', 'ms_per_step_e_f')
+        sx = {}
+        for name, pt in ex.items():
+            if not isinstance(pt, dict):
+                continue
+            e = _pick(pt, keep)
+            rf = pt.get('roofline')
+            if isinstance(rf, dict):
+                e['frac'] = rf.get('frac')
+                e['traffic'] = rf.get('traffic')
+                e['real_hbm_frac'] = rf.get('real_hbm_frac')
+            sx[name] = e
+        out['extra'] = sx
+    if detail_path:
+        out['detail_file'] = detail_path
+    out = _num(out)
+    # the hard bound: shed the optional blocks, largest first, until the line fits
+    for k in ('extra', 'per_rank', 'topology', 'kernels_us_isolated', 'summed_kernels_frac_B_EF', 'cpu_baseline_python',
+              'roofline_bandwidth_bound', 'roofline_clustered_and_phased'):
+        if len(json.dumps(out)) <= LINE_BUDGET:
+            break
+        out.pop(k, None)
+    return out
+
+
+def write_detail(full, world):
+    """The complete record (per-kernel traffic tables, notes, every extra point): gpurun_out/ when it exists (it is merged
+    back from the GPU box), else the temp dir.  NOT echoed on stderr: the driver's record is a bounded tail of stdout + stderr
+    and the printed line must stay inside it.  Returns the path or None."""
+    import tempfile
+    text = json.dumps(full)
+    for d in (os.path.join(REPO, 'gpurun_out'), tempfile.gettempdir()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, 'bench_detail_n%d.json' % world)
+            with open(path, 'w') as f:
+                f.write(text + '\n')
+            return os.path.relpath(path, REPO) if path.startswith(REPO) else path
+        except OSError:
+            continue
+    return None
+
+
 METRIC = 'SV support-read marks clustered+phased /sec; bit-exact phased_sv.vcf vs ref'
 DTYPE = 'u32/u64 integer + f64 threshold compares'
 
@@ -718,7 +846,8 @@ def main():
             if rank == 0:
                 out['extra'] = {'weak_grouped_config2_per_rank': weak, 'fused_clustered_and_phased_sharded': fused}
     if rank == 0:
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+        path = write_detail(out, world)
+        os.write(json_fd, (json.dumps(compact_line(out, path)) + '\n').encode())
     os.close(json_fd)
 
     if dist_mod is not None:
