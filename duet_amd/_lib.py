@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libduet_ef.so')
 
 DUET_OK = 0
 DUET_ERR_DIV_ZERO = -5
+DUET_ERR_TIMEOUT = -6
 MARK_ABSENT = 0xFFFFFFFF
 N_KERNELS = 3
 KERNEL_NAMES = ('ef_classify', 'ef_seed_sort', 'ef_finalize')
@@ -25,7 +26,8 @@ EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last
            'duet_ctx_set_profiling', 'duet_ctx_set_debug', 'duet_ef_run_device', 'duet_ef_check', 'duet_ef_run_host',
            'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_svim_phase_host', 'duet_rows_run_device',
            'duet_ef_rows_run_host', 'duet_eval_run_host', 'duet_comm_unique_id', 'duet_comm_create', 'duet_comm_allgather_device',
-           'duet_comm_allgather_host', 'duet_comm_destroy')
+           'duet_comm_allgather_host', 'duet_comm_destroy', 'duet_comm_set_timeout', 'duet_comm_block_bytes',
+           'duet_comm_ef_allgather')
 
 
 class EfProblem(ctypes.Structure):
@@ -145,6 +147,11 @@ def load():
     lib.duet_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.duet_comm_allgather_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
     lib.duet_comm_allgather_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.duet_comm_set_timeout.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    lib.duet_comm_block_bytes.restype = ctypes.c_uint64
+    lib.duet_comm_block_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.duet_comm_ef_allgather.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfProblem), ctypes.c_void_p, ctypes.c_uint32,
+                                           ctypes.c_uint32, ctypes.c_void_p]
     lib.duet_comm_destroy.restype = None
     lib.duet_comm_destroy.argtypes = [ctypes.c_void_p]
     _lib = lib

@@ -10,11 +10,17 @@ started.  Now a rank needs numpy and the native libraries only:
     RCCL unique id, and in the one-GPU plumbing mode (DUET_ONE_GPU=1: every rank on device 0, where RCCL cannot run two ranks)
     the record blocks themselves.
   * `RcclGather` -- the collective inside libduet_ef.so (duet_comm_*): ncclCommInitRank from rank 0's id, ncclAllGather over
-    xGMI on device buffers of the rank's context.
+    xGMI on device buffers of the rank's context.  `ef_allgather` is a rank's whole data path in ONE library call
+    (duet_comm_ef_allgather): the shard's arrays up, the three kernels writing straight into the rank's record block on the
+    device, the rows-kept-per-CHROM-text counters and the status word appended by a small kernel, ncclAllGather on the
+    kernels' stream, one copy of the gathered blocks back -- the results never visit the host before the collective.
   * `HostGather` -- the same interface over the TCP star alone.
 
-Every blocking step is bounded by `timeout` seconds (DUET_RDZV_TIMEOUT): a rank that never arrives makes the others fail,
-not hang."""
+Every blocking step is bounded by `timeout` seconds (DUET_RDZV_TIMEOUT): the TCP star's accepts, reads and writes here, and
+inside the library ncclCommInitRank (run on a helper thread, waited for with a deadline) and the wait behind the all-gather
+(the stream is polled against a deadline) -- DUET_ERR_TIMEOUT -> `CommTimeout`.  A rank that never arrives makes the others
+fail, not hang; a rank that gave up on RCCL must leave through os._exit (duet_amd/multi.py does): a helper thread may still
+sit inside RCCL."""
 
 import os
 import socket
@@ -26,6 +32,16 @@ import numpy as np
 
 class CommError(RuntimeError):
     pass
+
+
+class CommTimeout(CommError):
+    """A collective step ran into DUET_RDZV_TIMEOUT; the process should end itself with os._exit."""
+
+
+def block_bytes(n_max, n_slots):
+    """Bytes of one rank's record block: ps u32[n_max] | pred u8[n_max] | pad to 16 | status u32 + 12 | kept u64[n_slots]
+    (include/duet_ef.h: duet_comm_block_bytes)."""
+    return (5 * int(n_max) + 15) // 16 * 16 + 16 + 8 * int(n_slots)
 
 
 def _recv_exact(sock, n):
@@ -76,10 +92,25 @@ class TcpStar(object):
                         conn, _ = srv.accept()
                     except socket.timeout:
                         continue
-                    conn.settimeout(self.timeout)
+                    # the 4-byte rank id is read under what is LEFT of the deadline; an id that is not an expected peer's
+                    # (a stray local connection to the port, a duplicate) is turned away instead of derailing the rendezvous
+                    conn.settimeout(max(0.05, deadline - time.time()))
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    (r,) = struct.unpack('<I', _recv_exact(conn, 4))
+                    try:
+                        (r,) = struct.unpack('<I', _recv_exact(conn, 4))
+                    except (socket.timeout, CommError, OSError):
+                        conn.close()
+                        continue
+                    if not (1 <= r < self.world) or r in self.peers:
+                        conn.close()
+                        continue
+                    conn.settimeout(self.timeout)
                     self.peers[r] = conn
+            except BaseException:
+                for c in self.peers.values():
+                    c.close()
+                self.peers = {}
+                raise
             finally:
                 srv.close()
         else:
@@ -130,10 +161,15 @@ class TcpStar(object):
         except socket.timeout:
             raise CommError('all-gather timed out after %.0f s' % self.timeout)
         parts, at = [], 0
-        for _ in range(self.world):
-            (n,) = struct.unpack_from('<Q', packed, at)
-            parts.append(packed[at + 8:at + 8 + n])
-            at += 8 + n
+        try:
+            for _ in range(self.world):
+                (n,) = struct.unpack_from('<Q', packed, at)
+                if at + 8 + n > len(packed):
+                    raise struct.error('short')
+                parts.append(packed[at + 8:at + 8 + n])
+                at += 8 + n
+        except struct.error:
+            raise CommError('all-gather: rank 0 sent %d bytes that do not hold %d blocks' % (len(packed), self.world))
         return parts
 
     def close(self):
@@ -158,6 +194,22 @@ class HostGather(object):
             raise CommError('all-gather: blocks of different sizes')
         return np.frombuffer(b''.join(parts), dtype=np.uint8).reshape(self.star.world, block.size).copy()
 
+    def ef_allgather(self, soa, svlen_thres, suppread_thres, cand_slot, n_slots, n_max, compute):
+        """A rank's data path with the star as the collective (the one-GPU plumbing mode, the CPU tests): `compute` is the
+        rank's E/F (shard -> (block bytes ps | pred [| anything], status)); the trailer -- status word, rows kept per
+        CHROM-text slot -- is assembled here.  -> uint8 [world, block_bytes(n_max, n_slots)]"""
+        blk, status = compute(soa, svlen_thres, suppread_thres, n_max)
+        blk = np.ascontiguousarray(blk, dtype=np.uint8)
+        rb = (5 * int(n_max) + 15) // 16 * 16
+        out = np.zeros(block_bytes(n_max, n_slots), dtype=np.uint8)
+        out[:rb] = blk[:rb]
+        out[rb:rb + 4] = np.array([status], dtype=np.uint32).view(np.uint8)
+        if n_slots and soa.n_cands and status == 0:
+            pred = blk[4 * int(n_max):4 * int(n_max) + soa.n_cands]
+            kept = np.bincount(np.asarray(cand_slot, dtype=np.int64)[pred != 0], minlength=int(n_slots)).astype(np.uint64)
+            out[rb + 16:] = kept[:int(n_slots)].view(np.uint8)
+        return self.allgather(out)
+
     def close(self):
         pass
 
@@ -179,9 +231,35 @@ class RcclGather(object):
             ident = bytes(buf)
         ident = star.bcast(ident)
         arr = (ctypes.c_ubyte * 128).from_buffer_copy(ident)
+        # bounded inside the library by DUET_RDZV_TIMEOUT (ncclCommInitRank on a helper thread, waited for with a deadline)
+        os.environ['DUET_RDZV_TIMEOUT'] = repr(float(star.timeout))
         self.handle = lib.duet_comm_create(ctx.handle, arr, star.rank, star.world)
         if not self.handle:
-            raise CommError('duet_comm_create: %s' % ctx.last_error())
+            why = ctx.last_error()
+            raise (CommTimeout if 'did not finish within' in why else CommError)('duet_comm_create: %s' % why)
+
+    def _raise(self, rc):
+        from duet_amd import _lib
+        if rc == _lib.DUET_ERR_TIMEOUT:
+            raise CommTimeout(self.ctx.last_error())
+        self.ctx._raise(rc)
+
+    def ef_allgather(self, soa, svlen_thres, suppread_thres, cand_slot, n_slots, n_max, compute=None):
+        """duet_comm_ef_allgather: upload, ef_classify -> ef_seed_sort -> ef_finalize into the rank's block on the device,
+        trailer kernel, ONE ncclAllGather on the same stream, one download.  -> uint8 [world, block_bytes(n_max, n_slots)]
+        (`compute` is not used: the kernels run inside the call)."""
+        import ctypes
+        from duet_amd import _lib
+        prob, keep = _lib.problem_from_arrays(soa, svlen_thres, suppread_thres)
+        slots = np.ascontiguousarray(cand_slot, dtype=np.uint32)
+        out = np.empty((self.star.world, block_bytes(n_max, n_slots)), dtype=np.uint8)
+        rc = self.ctx.lib.duet_comm_ef_allgather(self.handle, ctypes.byref(prob), slots.ctypes.data_as(ctypes.c_void_p) if slots.size else None,
+                                                 ctypes.c_uint32(int(n_slots)), ctypes.c_uint32(int(n_max)),
+                                                 out.ctypes.data_as(ctypes.c_void_p))
+        del keep
+        if rc:
+            self._raise(rc)
+        return out
 
     def allgather(self, block):
         import ctypes
@@ -190,8 +268,16 @@ class RcclGather(object):
         rc = self.ctx.lib.duet_comm_allgather_host(self.handle, block.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(block.size),
                                                    out.ctypes.data_as(ctypes.c_void_p))
         if rc:
-            self.ctx._raise(rc)
+            self._raise(rc)
         return out
+
+    def allgather_device(self, send_ptr, nbytes, recv_ptr, stream):
+        """device pointers, asynchronous on `stream` (duet_comm_allgather_device)"""
+        import ctypes
+        rc = self.ctx.lib.duet_comm_allgather_device(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_uint64(int(nbytes)),
+                                                     ctypes.c_void_p(recv_ptr), ctypes.c_void_p(stream))
+        if rc:
+            self._raise(rc)
 
     def close(self):
         if self.handle:

@@ -11,9 +11,15 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include <unistd.h>
+#include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "duet_ef.h"
 #include "duet_internal.h"
@@ -86,8 +92,85 @@ struct duet_comm {
     duet_ctx *ctx = nullptr;
     NcclComm comm = nullptr;
     int rank = 0, world = 1;
-    DevBuf send, recv;
+    double timeout_s = 300.0;                              // bound of every blocking step (DUET_RDZV_TIMEOUT at creation)
+    bool broken = false;                                   // a step timed out: nothing more goes through this communicator
+    DevBuf send, recv, slots;
 };
+
+namespace {
+
+double env_timeout()
+{
+    const char *t = getenv("DUET_RDZV_TIMEOUT");
+    const double v = t ? atof(t) : 0.0;
+    return v > 0.0 ? v : 300.0;
+}
+
+// Wait for everything queued on `s`, but not for ever: the stream is polled (hipStreamQuery) against a deadline.  A collective
+// whose peer never arrives leaves the stream busy for good; the caller gets DUET_ERR_TIMEOUT and is expected to exit.
+int bounded_sync(duet_comm *cm, hipStream_t s, const char *what)
+{
+    duet_ctx *ctx = cm->ctx;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return DUET_OK;
+        if (e != hipErrorNotReady) return duet_fail(ctx, DUET_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt > cm->timeout_s) {
+            cm->broken = true;
+            return duet_fail(ctx, DUET_ERR_TIMEOUT, std::string(what) + " did not finish within " + std::to_string(cm->timeout_s) +
+                                                     " s (a rank is missing or stuck)");
+        }
+        if (spin > 2000) usleep(dt < 0.01 ? 20 : 200);     // the first microseconds by spinning: a 2 MB gather takes tens of them
+    }
+}
+
+// The tail of a rank's record block: status word and the rows every CHROM-text slot keeps (pred != 0), counted where pred lives.
+// A workgroup takes 4096 consecutive candidates (contig-sorted: a handful of distinct slots), counts in LDS when the slots fit
+// (wave-aggregated: one LDS add per distinct slot and wave), and adds its non-zero counters to the block's.
+constexpr uint32_t kSlotLds = 4096;
+__global__ __launch_bounds__(256) void comm_trailer(const uint8_t *__restrict__ pred, const uint32_t *__restrict__ slot, uint32_t C,
+                                                    uint32_t n_slots, uint32_t *status_out, unsigned long long *kept, uint32_t *d_status)
+{
+    __shared__ uint32_t s_cnt[kSlotLds];
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        status_out[0] = (d_status && (d_status[0] & 1u)) ? 5u : 0u;        // duet_amd/multi.py: RC_DIV_ZERO
+        if (d_status) d_status[0] = 0;
+    }
+    if (n_slots == 0 || C == 0) return;
+    const bool lds = n_slots <= kSlotLds;
+    if (lds) {
+        for (uint32_t i = tid; i < n_slots; i += 256u) s_cnt[i] = 0;
+        __syncthreads();
+    }
+    const uint32_t c0 = blockIdx.x * 4096u;
+    for (uint32_t i = 0; i < 16u; ++i) {
+        const uint32_t c = c0 + i * 256u + tid;
+        bool todo = c < C && pred[c] != 0;
+        const uint32_t sl = todo ? slot[c] : 0u;
+        if (todo && sl >= n_slots) todo = false;                            // (the host validates; never index outside)
+        unsigned long long left = __ballot(todo);
+        while (left) {
+            const uint32_t lead = (uint32_t)__ffsll((long long)left) - 1u;
+            const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)sl, lead);
+            const unsigned long long same = __ballot(todo && sl == sv);
+            if ((tid & 63u) == lead) {
+                if (lds) atomicAdd(&s_cnt[sv], (uint32_t)__popcll(same));
+                else atomicAdd(&kept[sv], (unsigned long long)__popcll(same));
+            }
+            left &= ~same;
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t i = tid; i < n_slots; i += 256u)
+            if (s_cnt[i]) atomicAdd(&kept[i], (unsigned long long)s_cnt[i]);
+    }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -122,15 +205,53 @@ duet_comm *duet_comm_create(duet_ctx *ctx, const unsigned char *id, int rank, in
     }
     NcclUniqueId u;
     memcpy(&u, id, sizeof(u));
-    NcclComm c = nullptr;
-    const int rc = r.comm_init_rank(&c, world, u, rank);
-    if (rc) {
-        duet_fail(ctx, DUET_ERR_HIP, nccl_text(r, "ncclCommInitRank", rc));
+    // ncclCommInitRank blocks until every rank of `world` has called it -- for ever when one never does.  It runs on a helper
+    // thread; this one waits for it with a deadline.  On expiry the helper is left behind (it cannot be cancelled) and the
+    // caller is told to give up: a rank process then exits non-zero and its launcher ends the others.
+    struct InitJob {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        int rc = 0;
+        NcclComm c = nullptr;
+    };
+    auto job = std::make_shared<InitJob>();
+    const int device = ctx->device;
+    fn_comm_init_rank init = r.comm_init_rank;
+    std::thread([job, init, u, world, rank, device]() {
+        NcclComm c = nullptr;
+        int rc = hipSetDevice(device) == hipSuccess ? init(&c, world, u, rank) : -1;
+        std::lock_guard<std::mutex> g(job->m);
+        job->rc = rc;
+        job->c = c;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    const double limit = env_timeout();
+    {
+        std::unique_lock<std::mutex> g(job->m);
+        if (!job->cv.wait_for(g, std::chrono::duration<double>(limit), [&] { return job->done; })) {
+            duet_fail(ctx, DUET_ERR_TIMEOUT, "ncclCommInitRank did not finish within " + std::to_string(limit) +
+                                                 " s (DUET_RDZV_TIMEOUT): rank " + std::to_string(rank) + " of " + std::to_string(world) +
+                                                 " is waiting for a rank that never arrived");
+            return nullptr;
+        }
+    }
+    if (job->rc) {
+        duet_fail(ctx, DUET_ERR_HIP, job->rc == -1 ? std::string("hipSetDevice failed on the set-up thread") : nccl_text(r, "ncclCommInitRank", job->rc));
         return nullptr;
     }
     duet_comm *cm = new duet_comm();
-    cm->ctx = ctx; cm->comm = c; cm->rank = rank; cm->world = world;
+    cm->ctx = ctx; cm->comm = job->c; cm->rank = rank; cm->world = world;
+    cm->timeout_s = limit;
     return cm;
+}
+
+int duet_comm_set_timeout(duet_comm *cm, double seconds)
+{
+    if (!cm || !(seconds > 0.0)) return duet_fail(cm ? cm->ctx : nullptr, DUET_ERR_INVALID, "duet_comm_set_timeout: bad argument");
+    cm->timeout_s = seconds;
+    return DUET_OK;
 }
 
 int duet_comm_allgather_device(duet_comm *cm, const void *send_dev, uint64_t bytes, void *recv_dev, void *stream_)
@@ -138,6 +259,7 @@ int duet_comm_allgather_device(duet_comm *cm, const void *send_dev, uint64_t byt
     if (!cm || !cm->ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null communicator");
     duet_ctx *ctx = cm->ctx;
     if (!send_dev || !recv_dev || bytes == 0) return duet_fail(ctx, DUET_ERR_INVALID, "null buffer");
+    if (cm->broken) return duet_fail(ctx, DUET_ERR_TIMEOUT, "the communicator timed out earlier");
     Rccl &r = rccl();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int rc = r.all_gather(send_dev, recv_dev, (size_t)bytes, kNcclUint8, cm->comm, (hipStream_t)stream_);
@@ -158,8 +280,48 @@ int duet_comm_allgather_host(duet_comm *cm, const void *send_host, uint64_t byte
     HIP_TRY(ctx, hipMemcpyAsync(cm->send.ptr, send_host, (size_t)bytes, hipMemcpyHostToDevice, s));
     if ((rc = duet_comm_allgather_device(cm, cm->send.ptr, bytes, cm->recv.ptr, s))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(recv_host, cm->recv.ptr, (size_t)bytes * (size_t)cm->world, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    return DUET_OK;
+    return bounded_sync(cm, s, "the all-gather");
+}
+
+uint64_t duet_comm_block_bytes(uint32_t n_max, uint32_t n_slots)
+{
+    return ((5ull * n_max + 15ull) / 16ull) * 16ull + 16ull + 8ull * n_slots;
+}
+
+int duet_comm_ef_allgather(duet_comm *cm, const duet_ef_problem *pr, const uint32_t *cand_slot, uint32_t n_slots, uint32_t n_max,
+                           uint8_t *gathered)
+{
+    if (!cm || !cm->ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null communicator");
+    duet_ctx *ctx = cm->ctx;
+    if (!pr || !gathered || n_max == 0) return duet_fail(ctx, DUET_ERR_INVALID, "duet_comm_ef_allgather: null argument");
+    if (pr->n_cands > n_max) return duet_fail(ctx, DUET_ERR_INVALID, "the shard has more candidates than n_max");
+    if (n_slots && pr->n_cands && !cand_slot) return duet_fail(ctx, DUET_ERR_INVALID, "cand_slot is null");
+    if (cm->broken) return duet_fail(ctx, DUET_ERR_TIMEOUT, "the communicator timed out earlier");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t C = pr->n_cands;
+    const size_t rb = (size_t)(((5ull * n_max + 15ull) / 16ull) * 16ull), bytes = (size_t)duet_comm_block_bytes(n_max, n_slots);
+    int rc;
+    if ((rc = duet_reserve(ctx, cm->send, bytes))) return rc;
+    if ((rc = duet_reserve(ctx, cm->recv, bytes * (size_t)cm->world))) return rc;
+    if ((rc = duet_reserve(ctx, cm->slots, C ? (size_t)C * 4 : 16))) return rc;
+    hipStream_t s = ctx->own_stream;
+    uint8_t *block = (uint8_t *)cm->send.ptr;
+    // what the kernels do not write of the block: the slots of the ranks with more candidates, the padding, the trailer's counters
+    HIP_TRY(ctx, hipMemsetAsync(block, 0, bytes, s));
+    if (C) {
+        duet_ef_problem d;
+        if ((rc = duet_ef_upload(ctx, pr, &d, s))) return rc;
+        if (n_slots) HIP_TRY(ctx, hipMemcpyAsync(cm->slots.ptr, cand_slot, (size_t)C * 4, hipMemcpyHostToDevice, s));
+        if ((rc = duet_ef_run_device(ctx, &d, block + 4 * (size_t)n_max, (uint32_t *)block, s))) return rc;
+    }
+    hipLaunchKernelGGL(comm_trailer, dim3(C ? (C + 4095u) / 4096u : 1u), dim3(256), 0, s, block + 4 * (size_t)n_max,
+                       (const uint32_t *)cm->slots.ptr, C, n_slots, (uint32_t *)(block + rb), (unsigned long long *)(block + rb + 16),
+                       C ? ctx->d_status : (uint32_t *)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->pending_check = false;                             // (the status word went into the block)
+    if ((rc = duet_comm_allgather_device(cm, block, bytes, cm->recv.ptr, s))) return rc;      // the ONE collective of the path
+    HIP_TRY(ctx, hipMemcpyAsync(gathered, cm->recv.ptr, bytes * (size_t)cm->world, hipMemcpyDeviceToHost, s));
+    return bounded_sync(cm, s, "the rank's kernels and the all-gather");
 }
 
 void duet_comm_destroy(duet_comm *cm)
@@ -167,9 +329,10 @@ void duet_comm_destroy(duet_comm *cm)
     if (!cm) return;
     Rccl &r = rccl();
     if (cm->ctx) (void)hipSetDevice(cm->ctx->device);
-    if (cm->comm && r.comm_destroy) (void)r.comm_destroy(cm->comm);
+    if (cm->comm && r.comm_destroy && !cm->broken) (void)r.comm_destroy(cm->comm);    // (a communicator with a stuck collective would block here)
     if (cm->send.ptr) (void)hipFree(cm->send.ptr);
     if (cm->recv.ptr) (void)hipFree(cm->recv.ptr);
+    if (cm->slots.ptr) (void)hipFree(cm->slots.ptr);
     delete cm;
 }
 

@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -164,6 +165,7 @@ struct Params {
     const uint32_t *dyn_c;            // device-planned runs (DYN kernels): the candidate count lives on the device, C is an upper bound
     const uint16_t *cand_contig;      // ... and, when the plan came from the candidates' contig column, that column (else null)
     uint32_t dbg;                     // diagnostic ablation bits (0 in production)
+    uint32_t heavy_t;                 // ef_classify: candidates with more marks than this leave the lanes' serial walk for the wave-cooperative one
     unsigned long long *stamps;       // diagnostic build only: [kernel][block][8] wall-clock stamps
 };
 
@@ -216,6 +218,75 @@ __device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_t
         st.tb1 += (in_b && is1) ? pc : 0u; st.tb2 += (in_b && is2) ? pc : 0u;
     }
     st.TA1 += st.ta1; st.TA2 += st.ta2; st.ta1 = 0; st.ta2 = 0;
+}
+
+// Sum of one value per lane over the wavefront (row rotations, then the two row broadcasts of gfx9: six adds with a DPP operand,
+// nothing through LDS); the total comes back on the scalar unit.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);     // quad_perm:[1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);     // quad_perm:[2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);    // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);    // row_ror:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The wave-cooperative walk (north_star's "wavefront-reduced per-cluster haplotype vote"): the WHOLE wavefront takes marks
+// [lo, hi) of the candidate that lane `h` owns, 64 marks per step, and lane h's state advances exactly as consume_range would
+// have advanced it.  Every order rule of the serial walk is a "first lane with ..." here: the first tagged mark's PS (:191-194),
+// the first voter's PS = group A = the seed (:199-203), the first voter outside A = group B (:85-105 keeps first-seen order),
+// anything else a third group; counts are population counts of lane masks (a compare IS the ballot on this machine) and only
+// the four PC sums go through a reduction -- exact integer work throughout.  lo, hi, h are wave-uniform.
+// A serial walk costs a wave as many dependent LDS round trips as its LARGEST candidate has marks; candidates with a tail of
+// sizes (stage A0's own output, any real caller's) leave 63 lanes idle behind one.  This path bounds that chain.
+__device__ __forceinline__ void consume_heavy(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs, uint32_t lane,
+                                              uint32_t h)
+{
+    uint32_t first_ps = (uint32_t)__builtin_amdgcn_readlane((int)st.first_ps, h);
+    uint32_t ps_a = (uint32_t)__builtin_amdgcn_readlane((int)st.ps_a, h);
+    uint32_t ps_b = (uint32_t)__builtin_amdgcn_readlane((int)st.ps_b, h);
+    bool multi = false, more = false;
+    uint32_t nv = 0, n_a = 0, n_b = 0, a1 = 0, a2 = 0, b1 = 0, b2 = 0;          // wave-uniform
+    uint32_t ta1 = 0, ta2 = 0, tb1 = 0, tb2 = 0;                                // per lane
+    for (uint32_t m0 = lo; m0 < hi; m0 += 64u) {
+        const uint32_t m = m0 + lane;
+        const uint64_t tag = m < hi ? s_tag[m - cs] : kUntagged;
+        const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
+        const uint32_t pc = w & 0x3FFFFFFFu, hap = w >> 30;
+        const bool voter = pc <= kPcMax;                                        // (an absent mark: pc = 2^30 - 1, ps = kEmpty)
+        const unsigned long long tmask = __ballot(ps != kEmpty);
+        if (first_ps == kEmpty && tmask) first_ps = (uint32_t)__builtin_amdgcn_readlane((int)ps, (uint32_t)__ffsll((long long)tmask) - 1u);
+        multi = multi || __ballot(ps != first_ps && ps != kEmpty) != 0ull;
+        const unsigned long long vmask = __ballot(voter);
+        if (ps_a == kEmpty && vmask) ps_a = (uint32_t)__builtin_amdgcn_readlane((int)ps, (uint32_t)__ffsll((long long)vmask) - 1u);
+        const bool in_a = voter && ps == ps_a;
+        const unsigned long long amask = __ballot(in_a);
+        const unsigned long long rmask = vmask & ~amask;
+        if (ps_b == kEmpty && rmask) ps_b = (uint32_t)__builtin_amdgcn_readlane((int)ps, (uint32_t)__ffsll((long long)rmask) - 1u);
+        const bool in_b = voter && !in_a && ps == ps_b;
+        const unsigned long long bmask = __ballot(in_b);
+        more = more || (rmask & ~bmask) != 0ull;
+        const bool is1 = hap == 1, is2 = hap == 2;
+        const unsigned long long m1 = __ballot(is1), m2 = __ballot(is2);
+        nv += (uint32_t)__popcll(vmask);
+        n_a += (uint32_t)__popcll(amask); n_b += (uint32_t)__popcll(bmask);
+        a1 += (uint32_t)__popcll(amask & m1); a2 += (uint32_t)__popcll(amask & m2);
+        b1 += (uint32_t)__popcll(bmask & m1); b2 += (uint32_t)__popcll(bmask & m2);
+        ta1 += (in_a && is1) ? pc : 0u; ta2 += (in_a && is2) ? pc : 0u;
+        tb1 += (in_b && is1) ? pc : 0u; tb2 += (in_b && is2) ? pc : 0u;
+    }
+    // (a chunk holds 3072 marks of at most 8100 each: the sums fit 32 bits, as the serial walk's per-chunk partials do)
+    const uint32_t s_a1 = a1 ? wave_sum(ta1) : 0u, s_a2 = a2 ? wave_sum(ta2) : 0u;
+    const uint32_t s_b1 = b1 ? wave_sum(tb1) : 0u, s_b2 = b2 ? wave_sum(tb2) : 0u;
+    if (lane == h) {
+        st.first_ps = first_ps; st.multi = st.multi || multi;
+        st.ps_a = ps_a; st.ps_b = ps_b; st.more = st.more || more;
+        st.nv += nv; st.n_a += n_a; st.n_b += n_b;
+        st.a1 += a1; st.a2 += a2; st.b1 += b1; st.b2 += b2;
+        st.TA1 += s_a1; st.TA2 += s_a2; st.tb1 += s_b1; st.tb2 += s_b2;
+    }
 }
 
 struct TileShared {
@@ -443,9 +514,11 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
         STAMP(0, 1);
         const uint32_t m_begin = s_off[0], m_end = s_off[nc];
 
-        // thread t walks candidate c0 + t.  (Dealing a tile's candidates to lanes in descending order of their mark
-        // count -- so that the four waves loop 18/14/10/6 times instead of 4 x 18 -- was measured and is NOT faster: a
-        // workgroup holds its LDS until its slowest wave is done, and that wave still loops 18 times.)
+        // thread t walks candidate c0 + t.  (Dealing a tile's candidates to the lanes in descending order of their mark count -- so
+        // that the four waves loop 18/14/10/6 times instead of 4 x 18 -- was measured in rounds 1 and 4, and in round 5 with the wave
+        // that takes the long quarter rotating from tile to tile (so that no SIMD of a CU gets all the long walks): NOT faster,
+        // profiles/history/r05_ef_classify_dealt_by_size_with_rotation_REJECTED.txt.  The kernel is bound by the latency of a tile --
+        // three dependent round trips before its walk can start -- at five tiles per CU, not by the walk's issue slots.)
         const uint32_t j = tid;
         const bool live = j < nc;
         const bool active = kept && !divzero;
@@ -474,7 +547,17 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
             uint32_t lo = max(my_b, cs);
             const uint32_t hi = min(my_e, cs + (uint32_t)kChunk);
             if (!kept || (p.dbg & 4)) lo = hi;
-            consume_range(st, s_tag, lo, hi, cs);
+            // candidates with more marks than heavy_t: the wavefront walks them together, 64 marks per step, after the lanes
+            // have walked the others side by side
+            const bool heavy = lo < hi && my_e - my_b > p.heavy_t;
+            unsigned long long hm = __ballot(heavy);
+            consume_range(st, s_tag, heavy ? hi : lo, hi, cs);
+            while (hm) {
+                const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)__ffsll((long long)hm) - 1u));
+                hm &= hm - 1ull;
+                const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readlane((int)lo, h), hi_h = (uint32_t)__builtin_amdgcn_readlane((int)hi, h);
+                consume_heavy(st, s_tag, lo_h, hi_h, cs, tid & 63u, h);
+            }
             STAMP(0, 3);
             __syncthreads();
         }
@@ -1367,6 +1450,7 @@ duet_ctx *duet_ctx_create(int device_id)
     }
     duet_ctx *ctx = new duet_ctx();
     ctx->device = device_id;
+    if (const char *t = getenv("DUET_EF_HEAVY_T")) ctx->ef_heavy_t = (uint32_t)strtoul(t, nullptr, 10);   // diagnostic: sweeps of the threshold
     e = hipEventCreateWithFlags(&ctx->cl_fork, hipEventDisableTiming);
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&ctx->cl_side[i], hipStreamNonBlocking);
@@ -1471,6 +1555,7 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     p.c2_cap = (uint32_t)c2_slots((p.C + kCandPerBlock - 1) / kCandPerBlock, p.C);
     p.out_pred = out_pred; p.out_ps = out_ps;
     p.dbg = ctx->dbg;
+    p.heavy_t = (ctx->dbg & DUET_DBG_EF_HEAVY_ALL) ? 0u : ((ctx->dbg & DUET_DBG_EF_HEAVY_OFF) ? 0xFFFFFFFFu : ctx->ef_heavy_t);
     p.stamps = ctx->d_stamps;
 
     // Profiling: the start/stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL),
@@ -1592,6 +1677,7 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     p.c2_cap = (uint32_t)c2_slots((p.C + kCandPerBlock - 1) / kCandPerBlock, p.C);
     p.out_pred = out_pred; p.out_ps = out_ps;
     p.dbg = ctx->dbg;
+    p.heavy_t = (ctx->dbg & DUET_DBG_EF_HEAVY_ALL) ? 0u : ((ctx->dbg & DUET_DBG_EF_HEAVY_OFF) ? 0xFFFFFFFFu : ctx->ef_heavy_t);
     p.stamps = ctx->d_stamps;
     // the kernels stride over the real tiles: an eighth of the bound's tiles (SV-like data: ~10 marks per candidate), at least 512
     const uint32_t G = B < 512u ? B : (B / 8u > 512u ? B / 8u : 512u);

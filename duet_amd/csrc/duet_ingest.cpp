@@ -1302,6 +1302,20 @@ int duet_ingest_count_kept(duet_ingest *g, const uint8_t *pred, uint64_t *kept)
     return DUET_INGEST_OK;
 }
 
+int duet_ingest_cand_slots(duet_ingest *g, uint32_t *slot)
+{
+    if (!g || !g->parsed) return DUET_INGEST_INVALID;
+    const size_t C = g->cand_pos.size();
+    if (C && !slot) return DUET_INGEST_INVALID;
+    const int K = (int)g->contigs.size();
+    int k = 0;
+    for (size_t c = 0; c < C; ++c) {
+        while (k < K && c >= g->cand_ctg_off[k + 1]) ++k;
+        slot[c] = (uint32_t)text_slot(g, (uint32_t)k, g->c_chrom[c]);
+    }
+    return DUET_INGEST_OK;
+}
+
 int duet_ingest_emit_blocks(duet_ingest *g, const uint8_t *pred, const uint32_t *ps, const uint64_t *id_base, char **text,
                             uint64_t *len, uint64_t *slot_off, uint64_t *slot_len)
 {

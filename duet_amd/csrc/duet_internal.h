@@ -21,6 +21,7 @@ struct duet_ctx {
     int ev_mode = 0;                       // mode the pooled events were recorded with
     uint32_t prof_tick = 0;                // run counter of the sampled mode
     uint32_t dbg = 0;
+    uint32_t ef_heavy_t = 32;              // ef_classify: candidates with more marks take the wave-cooperative walk (DUET_EF_HEAVY_T overrides)
     unsigned long long *d_stamps = nullptr;
     hipStream_t own_stream = nullptr;
     uint32_t *rx_dtot = nullptr;                              // [256] digit totals of a radix pass (zero between passes)

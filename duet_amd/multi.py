@@ -9,8 +9,9 @@ process (duet_amd/launch.py).  Every rank
      every rank's candidate count are known before anything is parsed,
   2. reads ITS contigs only -- their BAMs, their records (native ingest with an ownership mask) --,
   3. runs ef_classify -> ef_seed_sort -> ef_finalize on its shard (libduet_ef.so, no data-path exchange),
-  4. contributes its block `ps u32[n_max] | pred u8[n_max] | status | rows kept per CHROM text` to ONE
-     all_gather_into_tensor (RCCL over xGMI under backend "nccl"),
+  4. contributes its block `ps u32[n_max] | pred u8[n_max] | status | rows kept per CHROM text` to ONE all-gather (RCCL over
+     xGMI inside libduet_ef.so: steps 3 and 4 are one library call, duet_comm_ef_allgather -- the kernels write into the block
+     on the device, a small kernel appends the trailer, ncclAllGather runs on the kernels' stream),
   5. numbers and formats the rows of its own contigs (it alone holds their REF / ALT texts): a CHROM text belongs to one
      contig, the file is the text blocks in byte order (sv_phasing_fn.py:229 sorts CHROM as text first), and the gathered
      counts tell every rank where its blocks' numbering starts; the blocks go to a part file beside the output,
@@ -19,8 +20,10 @@ and the parent appends the blocks, in the order of their texts, to the phased_sv
 DUET_ONE_GPU=1 is a plumbing mode for a box with a single GPU: every rank uses device 0 and the collective goes
 through gloo.  Exit codes of a rank: 0 ok, 3 the native ingest declined the input (the caller falls back to the
 single-process Python path, which raises what upstream raises), 5 division by zero (sv_phasing_fn.py:123).
-DUET_RDZV_TIMEOUT (seconds, default 300) bounds the rendezvous and the collective, DUET_RANK_TIMEOUT (default 3600) the
-whole run of the ranks: on expiry the children are killed and the call fails -- it never hangs.
+DUET_RDZV_TIMEOUT (seconds, default 300) bounds the rendezvous (the TCP star AND ncclCommInitRank inside the library) and the
+collective (the stream behind ncclAllGather is polled against a deadline): a rank that runs into it leaves with code 7 through
+os._exit, and the launcher ends the others.  DUET_RANK_TIMEOUT (default 3600) bounds the whole run of the ranks: on expiry the
+children are killed and the call fails -- it never hangs.
 """
 
 import json
@@ -35,6 +38,7 @@ from duet_amd import launch
 
 RC_DECLINED = 3
 RC_DIV_ZERO = 5
+RC_TIMEOUT = 7                    # a collective step ran into DUET_RDZV_TIMEOUT
 STATUS_BYTES = 16                 # status u32 + padding, in front of the per-text counts
 
 
@@ -177,23 +181,29 @@ def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, rank,
             logging.info('integrate read weight information')
             logging.info('calculate read weight statistics')
             logging.info('predict SV haplotypes in the callset')
-        block, status = compute(soa, svlen_thres, suppread_thres, n_max)
         rb = D.record_bytes(n_max)
         tb = trailer_bytes(K)
-        is_np = isinstance(block, np.ndarray)
-        if (block.size if is_np else block.numel()) != rb + tb:
-            raise RuntimeError('record block of %d bytes, expected %d' % (block.size if is_np else block.numel(), rb + tb))
-        mine = block if is_np else block.cpu().numpy()
-        pred, ps = D.unpack_block(mine, n_max, soa.n_cands)
-        kept = ing.count_kept(pred) if status == 0 else np.zeros(2 * K, dtype=np.int64)
-        trailer = np.zeros(tb, dtype=np.uint8)
-        trailer[:4] = np.array([status], dtype=np.uint32).view(np.uint8)
-        trailer[STATUS_BYTES:] = kept.astype(np.uint64).view(np.uint8)
         if gather is not None:
-            mine = mine.copy() if not mine.flags.writeable else mine
-            mine[rb:] = trailer
-            g = gather.allgather(mine)                                      # the ONE collective of the path
+            # the ONE collective of the path, with the rank's whole data path in front of it: the in-library RCCL gather runs the
+            # three kernels straight into the rank's record block on the device, appends the trailer (status word, rows kept per
+            # CHROM-text slot) with a small kernel and gathers on the kernels' stream -- nothing visits the host before the
+            # collective (duet_comm_ef_allgather); the TCP star of the plumbing mode / the CPU tests assembles the same block from
+            # `compute`'s output
+            g = gather.ef_allgather(soa, svlen_thres, suppread_thres, ing.cand_slots(), 2 * K, n_max, compute)
+            if g.shape != (world, rb + tb):
+                raise RuntimeError('gathered blocks of shape %s, expected (%d, %d)' % (g.shape, world, rb + tb))
+            pred, ps = D.unpack_block(g[rank], n_max, soa.n_cands)
         else:
+            block, status = compute(soa, svlen_thres, suppread_thres, n_max)
+            is_np = isinstance(block, np.ndarray)
+            if (block.size if is_np else block.numel()) != rb + tb:
+                raise RuntimeError('record block of %d bytes, expected %d' % (block.size if is_np else block.numel(), rb + tb))
+            mine = block if is_np else block.cpu().numpy()
+            pred, ps = D.unpack_block(mine, n_max, soa.n_cands)
+            kept = ing.count_kept(pred) if status == 0 else np.zeros(2 * K, dtype=np.int64)
+            trailer = np.zeros(tb, dtype=np.uint8)
+            trailer[:4] = np.array([status], dtype=np.uint32).view(np.uint8)
+            trailer[STATUS_BYTES:] = kept.astype(np.uint64).view(np.uint8)
             import torch
             if is_np:
                 block = torch.from_numpy(block)
@@ -273,6 +283,14 @@ def rank_main(argv):
             gather = comm.HostGather(star) if one_gpu else comm.RcclGather(compute.ctx, star)
             return rank_body(home, svlen_thres, suppread_thres, thread, all_ctgs, rank, world, compute, gather.name,
                              device_rows_ctx=compute.ctx, device_id=device_id, gather=gather)
+        except comm.CommTimeout as e:
+            # a step of the RCCL path ran into DUET_RDZV_TIMEOUT (a rank is missing or stuck).  A helper thread may still sit
+            # inside RCCL and the stream may never drain: no clean-up, no interpreter shutdown -- say why and leave NOW with a
+            # non-zero code (the launcher then ends the other ranks).  Never a re-exec.
+            sys.stderr.write('rank %d: %s\n' % (rank, e))
+            sys.stderr.flush()
+            logging.shutdown()
+            os._exit(RC_TIMEOUT)
         finally:
             if gather is not None:
                 gather.close()
@@ -334,6 +352,8 @@ def sv_phasing_sharded(home, svlen_thres, suppread_thres, thread, include_all_ct
         return False
     if rc == RC_DIV_ZERO:
         raise ZeroDivisionError('division by zero')         # what upstream raises (sv_phasing_fn.py:123)
+    if rc == RC_TIMEOUT:
+        raise RuntimeError('multi-GPU SV phasing: a rank gave up on the collective after DUET_RDZV_TIMEOUT (a rank is missing or stuck)')
     raise RuntimeError('multi-GPU SV phasing failed: a rank exited with code %d' % rc)
 
 

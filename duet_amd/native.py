@@ -20,7 +20,8 @@ EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'du
            'duet_ingest_parse_vcf', 'duet_ingest_parse_vcf_begin', 'duet_ingest_parse_vcf_finish', 'duet_ingest_get_arrays',
            'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
            'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks', 'duet_ingest_bam_has_alignments',
-           'duet_ingest_vcf_precount', 'duet_ingest_set_owned', 'duet_ingest_count_kept', 'duet_ingest_emit_blocks')
+           'duet_ingest_vcf_precount', 'duet_ingest_set_owned', 'duet_ingest_count_kept', 'duet_ingest_emit_blocks',
+           'duet_ingest_cand_slots')
 
 
 class IngestArrays(ctypes.Structure):
@@ -76,6 +77,7 @@ def load():
         lib.duet_ingest_vcf_precount.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.duet_ingest_set_owned.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.duet_ingest_count_kept.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.duet_ingest_cand_slots.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.duet_ingest_emit_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64),
                                                 ctypes.c_void_p, ctypes.c_void_p]
@@ -268,6 +270,13 @@ class NativeIngest(object):
         if self.lib.duet_ingest_count_kept(self.handle, pred.ctypes.data, kept.ctypes.data) != OK:
             raise RuntimeError('duet_ingest_count_kept failed')
         return kept[:2 * K].astype(np.int64)
+
+    def cand_slots(self):
+        """Every candidate's CHROM-text slot (2 * contig + spelling) -> uint32[C]"""
+        slot = np.zeros(max(self.soa.n_cands, 1), dtype=np.uint32)
+        if self.lib.duet_ingest_cand_slots(self.handle, slot.ctypes.data) != OK:
+            raise RuntimeError('duet_ingest_cand_slots failed')
+        return slot[:self.soa.n_cands]
 
     def emit_blocks(self, pred, ps, id_base):
         """This ingest's rows with the rows of slot s numbered id_base[s], id_base[s] + 1, ...

@@ -41,6 +41,9 @@ typedef enum duet_status {
     DUET_ERR_NO_DEVICE = -2,  /* no usable gfx950 device / HIP runtime failure at context creation */
     DUET_ERR_HIP = -3,        /* a HIP call failed; duet_last_error has hipGetErrorString */
     DUET_ERR_OOM = -4,        /* device allocation failed */
+    DUET_ERR_TIMEOUT = -6,    /* a collective step (communicator set-up, the all-gather) did not finish within the communicator's
+                                 time limit: a peer is missing or stuck.  The communicator is unusable afterwards and the process
+                                 should exit (a helper thread may still sit inside RCCL) */
     DUET_ERR_DIV_ZERO = -5    /* a candidate that reaches the decision has svread + refread == 0: the
                                  reference raises ZeroDivisionError there (sv_phasing_fn.py:123) */
 } duet_status;
@@ -139,6 +142,8 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 #define DUET_DBG_EF_NO_SEED_HASH 0x40u   /* E/F: ef_seed_sort orders an unsorted seed list itself instead of taking its distinct values through a hash set first */
 #define DUET_DBG_EF_FIN_TPB2 0x20u       /* E/F: ef_finalize takes two tiles of 256 candidates per workgroup whatever the size (default from 1 M candidates on) */
 #define DUET_DBG_EF_FIN_TPB4 0x80u       /* ... four (default from 8 M candidates on) */
+#define DUET_DBG_EF_HEAVY_ALL 0x80000u   /* E/F: ef_classify walks EVERY kept candidate wave-cooperatively (64 marks per step; default: those with more than 32 marks) */
+#define DUET_DBG_EF_HEAVY_OFF 0x100000u  /* ... none: every candidate by its own lane, mark after mark */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */
@@ -331,10 +336,27 @@ DUET_API int duet_eval_run_host(duet_ctx *ctx, const duet_eval_problem *prob, du
 typedef struct duet_comm duet_comm;
 DUET_API int duet_comm_unique_id(duet_ctx *ctx, unsigned char *id /* [DUET_COMM_ID_BYTES] */);
 DUET_API duet_comm *duet_comm_create(duet_ctx *ctx, const unsigned char *id, int rank, int world);
+/* Every blocking step is bounded: duet_comm_create and the synchronising calls below give up after the time limit -- the
+ * environment's DUET_RDZV_TIMEOUT in seconds (default 300) at creation, duet_comm_set_timeout afterwards -- with
+ * DUET_ERR_TIMEOUT (duet_comm_create: NULL and that text in duet_last_error) instead of waiting for a rank that never comes. */
+DUET_API int duet_comm_set_timeout(duet_comm *comm, double seconds);
 /* every rank contributes `bytes` bytes, every rank receives world * bytes (rank-major).  _device: device pointers,
  * asynchronous on `stream`; _host: host pointers, staged through device buffers of the communicator, synchronises. */
 DUET_API int duet_comm_allgather_device(duet_comm *comm, const void *send, uint64_t bytes, void *recv, void *stream);
 DUET_API int duet_comm_allgather_host(duet_comm *comm, const void *send, uint64_t bytes, void *recv);
+/* One rank's whole data path of the contig-sharded run, results never leaving the device before the collective
+ * (src/duet/sv_phasing_fn.py:189-228 on the rank's contigs, then the reassembly in front of :229):
+ *   *prob (HOST arrays, the rank's shard) is uploaded, ef_classify -> ef_seed_sort -> ef_finalize write straight into the
+ *   rank's record block on the device,
+ *       ps u32[n_max] | pred u8[n_max] | pad to 16 | status u32, 12 bytes pad | kept u64[n_slots]
+ *   (n_max = the largest shard's candidate count, the same on every rank; status = 5 when a candidate that reaches the
+ *   decision has svread + refread == 0, else 0; kept[s] = candidates c with pred != 0 and cand_slot[c] == s: the rows each
+ *   CHROM text contributes, which is what tells every rank where its rows' numbering starts), ONE ncclAllGather of the
+ *   blocks on the kernels' stream, one copy of the world * block bytes to `gathered` (host), bounded wait.
+ * duet_comm_block_bytes gives the block size.  cand_slot may be NULL when n_slots == 0. */
+DUET_API uint64_t duet_comm_block_bytes(uint32_t n_max, uint32_t n_slots);
+DUET_API int duet_comm_ef_allgather(duet_comm *comm, const duet_ef_problem *prob, const uint32_t *cand_slot, uint32_t n_slots,
+                                    uint32_t n_max, uint8_t *gathered);
 DUET_API void duet_comm_destroy(duet_comm *comm);
 
 #ifdef __cplusplus

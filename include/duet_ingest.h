@@ -77,12 +77,14 @@ void duet_ingest_free(void *p);
  * _set_owned (before the parse): owned[k] == 0 -> contig k's records are left to another rank (dropped after their first
  *   token; that rank vouches for them); header lines and the contig list stay complete.
  * _count_kept: rows (pred != 0) per CHROM-text slot, slot = 2 * contig + (0: spelled chr<name>, 1: spelled <name>).
+ * _cand_slots: every candidate's slot (what duet_comm_ef_allgather of duet_ef.h counts the kept rows by, on the device).
  * _emit_blocks: the rank's rows, the rows of slot s numbered id_base[s], id_base[s] + 1, ... ; slot_off / slot_len [2K]
  *   give each slot's byte range in *text.  A CHROM text belongs to one contig, the final file is the blocks in the byte
  *   order of their texts (sv_phasing_fn.py:229 sorts CHROM as text first). */
 int duet_ingest_vcf_precount(duet_ingest *ing, const char *vcf_path, uint64_t *n_records /* [K] */, uint64_t *n_bytes /* [K] */);
 int duet_ingest_set_owned(duet_ingest *ing, const uint8_t *owned /* [K] or NULL = all */);
 int duet_ingest_count_kept(duet_ingest *ing, const uint8_t *pred, uint64_t *kept /* [2K] */);
+int duet_ingest_cand_slots(duet_ingest *ing, uint32_t *slot /* [C] */);
 int duet_ingest_emit_blocks(duet_ingest *ing, const uint8_t *pred, const uint32_t *ps, const uint64_t *id_base /* [2K] */,
                             char **text, uint64_t *len, uint64_t *slot_off /* [2K] */, uint64_t *slot_len /* [2K] */);
 

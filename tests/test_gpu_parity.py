@@ -169,6 +169,50 @@ def test_two_ps_everywhere_summary_pool(ctx):
         check_against_c_oracle(ctx, soa, 0, 0)
 
 
+HEAVY_ALL, HEAVY_OFF = 0x80000, 0x100000     # include/duet_ef.h: DUET_DBG_EF_HEAVY_ALL / _OFF
+
+
+@pytest.mark.parametrize('case', ['fuzz', 'multi_ps', 'two_ps_pool', 'tail', 'cross_chunk', 'config2'])
+def test_wave_cooperative_walk_and_lane_walk_agree(ctx, case):
+    """ef_classify has two walks over a candidate's marks: one lane, mark after mark -- and the whole wavefront, 64 marks per
+    step (first voter by ballot and find-first-set, counts by population count, PC sums by a wave reduction), taken for
+    candidates with more than 32 marks.  Each walk forced on every candidate (debug bits), and the default mix: same bytes
+    as the oracle -- first-seen group order, the third-group flag, chunk crossings (a candidate whose marks span several LDS
+    passes re-enters the cooperative walk with its state) and absent marks included."""
+    if case == 'fuzz':
+        soas = [soa_fuzz.random_soa(4000 + i, n_contigs=1 + i % 4, sorted_pos=bool(i % 2), deg=(1, 70)) for i in range(6)]
+    elif case == 'multi_ps':
+        soas = [soa_fuzz.random_soa(77, n_contigs=2, cands_per_contig=(2000, 3000), reads_per_contig=(60, 90), n_ps=(9, 14),
+                                    deg=(4, 130), empty_contig_rate=0, no_seed_contig_rate=0),
+                soa_fuzz.random_soa(78, n_contigs=3, cands_per_contig=(1000, 2000), reads_per_contig=(40, 200), n_ps=(2, 5),
+                                    deg=(2, 12), empty_contig_rate=0, no_seed_contig_rate=0)]
+    elif case == 'two_ps_pool':
+        soas = [soa_fuzz.random_soa(79, n_contigs=2, cands_per_contig=(1500, 2500), reads_per_contig=(30, 60), n_ps=(2, 2),
+                                    deg=(4, 66), empty_contig_rate=0, no_seed_contig_rate=0)]
+    elif case == 'tail':
+        # most candidates small, one in fifty with 33..200 marks: the mix the default threshold splits
+        soas = []
+        for i, big in enumerate((33, 64, 65, 129, 200)):
+            soas.append(soa_fuzz.random_soa(4100 + i, n_contigs=2, cands_per_contig=(600, 900), reads_per_contig=(300, 500),
+                                            deg=(1, 14), big_deg=big, empty_contig_rate=0, no_seed_contig_rate=0, n_ps=(1, 4)))
+    elif case == 'cross_chunk':
+        soas = [soa_fuzz.random_soa(101, n_contigs=2, cands_per_contig=(300, 600), reads_per_contig=(500, 900), big_deg=9000,
+                                    empty_contig_rate=0, no_seed_contig_rate=0, n_ps=(1, 3)),
+                soa_fuzz.random_soa(102, n_contigs=1, cands_per_contig=(300, 400), reads_per_contig=(500, 900), big_deg=3100,
+                                    deg=(20, 90), empty_contig_rate=0, no_seed_contig_rate=0)]
+    else:
+        soas = [engine.soa_from_synth(H.case_contigs('config2', 1))]
+    for soa in soas:
+        for dbg in (HEAVY_ALL, HEAVY_OFF, 0):
+            ctx.set_debug(dbg)
+            try:
+                check_against_c_oracle(ctx, soa)
+                if case != 'config2':
+                    check_against_c_oracle(ctx, soa, 0, 0)
+            finally:
+                ctx.set_debug(0)
+
+
 def test_long_candidates_cross_lds_chunks(ctx):
     """Candidates with more marks than one LDS pass holds (4096) and than a whole workgroup's pass."""
     soa = soa_fuzz.random_soa(101, n_contigs=2, cands_per_contig=(300, 600), reads_per_contig=(500, 900),
@@ -220,12 +264,16 @@ def test_device_pointer_entry_unaligned_marks(ctx):
     from duet_amd.devmem import DeviceProblem
     soa = soa_fuzz.random_soa(11, n_contigs=3, cands_per_contig=(300, 500))
     rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
-    for mis in (4, 0):
+    for mis, dbg in ((4, 0), (0, 0), (4, HEAVY_ALL), (0, HEAVY_ALL)):
         dp = DeviceProblem(soa, 50, 2, misalign_marks=mis)
         assert (dp.problem.mark_read % 16 != 0) == bool(mis)
         torch.cuda.synchronize()
-        stream = dp.run(ctx)
-        ctx.check(stream)
+        ctx.set_debug(dbg)
+        try:
+            stream = dp.run(ctx)
+            ctx.check(stream)
+        finally:
+            ctx.set_debug(0)
         pred, ps = dp.results()
         assert np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps)
 

@@ -1,0 +1,119 @@
+# coding=utf-8
+"""-m gpu, round 5: the contig-sharded path's collective inside the library -- device-resident (duet_comm_ef_allgather: the
+kernels write into the rank's record block, a small kernel appends the trailer, ncclAllGather on the kernels' stream) and
+bounded (DUET_RDZV_TIMEOUT: a rank that waits for one that never comes gives up and leaves non-zero)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_r2 import fresh_interpreter
+
+pytestmark = pytest.mark.gpu
+
+ONE_RANK = r'''
+import os
+os.environ["DUET_NO_TORCH"] = "1"
+import numpy as np
+from duet_amd import _lib, comm, dist
+from oracle import c_oracle
+from tests import soa_fuzz
+ctx = _lib.Context(0)
+star = comm.TcpStar(0, 1)
+g = comm.RcclGather(ctx, star)
+for seed, kw in ((1, dict(n_contigs=5)), (2, dict(n_contigs=3, cands_per_contig=(3000, 9000), reads_per_contig=(500, 900))),
+                 (3, dict(n_contigs=2, allow_divzero=True, empty_contig_rate=0, no_seed_contig_rate=0)), (4, dict(n_contigs=2500, cands_per_contig=(0, 9), reads_per_contig=(4, 20)))):
+    soa = soa_fuzz.random_soa(7000 + seed, **kw)
+    supp = 0 if seed == 3 else 2
+    rc, want_pred, want_ps = c_oracle.ef(soa, 50, supp)
+    C, K = soa.n_cands, soa.n_contigs
+    rng = np.random.RandomState(seed)
+    # a slot per candidate as the ingest hands it over: 2 * contig + spelling
+    contig = np.searchsorted(soa.cand_ctg_off[1:], np.arange(C), side="right")
+    slots = (2 * contig + rng.randint(0, 2, C)).astype(np.uint32)
+    n_max = C + 37
+    out = g.ef_allgather(soa, 50, supp, slots, 2 * K, n_max)
+    rb = dist.record_bytes(n_max)
+    assert out.shape == (1, comm.block_bytes(n_max, 2 * K)) and comm.block_bytes(n_max, 2 * K) == rb + 16 + 16 * K
+    status = int(out[0, rb:rb + 4].view(np.uint32)[0])
+    pred, ps = dist.unpack_block(out[0], n_max, C)
+    if rc == -5:
+        assert status == 5, status
+        continue
+    assert rc == 0 and status == 0
+    assert np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps)
+    assert not out[0, 4 * C:4 * n_max].any() and not out[0, 4 * n_max + C:rb].any()          # the other ranks' room stays zero
+    kept = out[0, rb + 16:].view(np.uint64)
+    assert np.array_equal(kept, np.bincount(slots[want_pred != 0], minlength=2 * K).astype(np.uint64))
+# a rank without candidates (more ranks than contigs) still takes part
+empty = soa_fuzz.random_soa(1, n_contigs=1, empty_contig_rate=1)
+assert empty.n_cands == 0
+out = g.ef_allgather(empty, 50, 2, np.zeros(0, np.uint32), 2, 100)
+assert out.shape == (1, comm.block_bytes(100, 2)) and not out.any()
+g.close()
+ctx.close()
+print("EF GATHER OK")
+'''
+
+
+def test_device_resident_rank_path_one_rank():
+    """duet_comm_ef_allgather as ONE rank over real RCCL: results written into the record block on the device, the trailer
+    (status word, rows kept per CHROM-text slot) by the trailer kernel, gathered, copied back once -- against the C oracle and a
+    numpy count; thousands of slots (-a style contig universes) take the global-atomics path of the trailer kernel."""
+    r = fresh_interpreter(ONE_RANK, {}, timeout=600)
+    assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-3000:])
+    assert b'EF GATHER OK' in r.stdout
+
+
+MISSING_RANK = r'''
+import os, sys, time
+os.environ["DUET_NO_TORCH"] = "1"
+from duet_amd import _lib, comm
+ctx = _lib.Context(0)
+star = comm.TcpStar(0, 1, timeout=3.0)        # (a one-rank star: only the unique id's hand-over, nobody to wait for)
+star.world = 2                                # ... but RCCL is told there are two ranks: ncclCommInitRank waits for rank 1
+t0 = time.time()
+try:
+    comm.RcclGather(ctx, star)
+except comm.CommTimeout as e:
+    print("TIMEOUT after %.1f s: %s" % (time.time() - t0, e))
+    sys.stdout.flush()
+    os._exit(7)                               # as duet_amd/multi.py leaves: a helper thread still sits inside RCCL
+print("NO TIMEOUT")
+os._exit(0)
+'''
+
+
+def test_missing_rank_times_out_on_the_rccl_path():
+    """DUET_RDZV_TIMEOUT bounds ncclCommInitRank (a helper thread inside the library, waited for with a deadline): rank 0 of a
+    two-rank communicator whose rank 1 never shows up gives up after 3 s and the process leaves with a non-zero code -- it
+    used to sit in ctypes until the launcher's DUET_RANK_TIMEOUT (3600 s)."""
+    t0 = time.time()
+    r = fresh_interpreter(MISSING_RANK, {}, timeout=120)
+    dt = time.time() - t0
+    assert r.returncode == 7, (r.returncode, r.stdout.decode()[-1000:], r.stderr.decode()[-2000:])
+    assert b'TIMEOUT after' in r.stdout and b'did not finish within' in r.stdout
+    assert dt < 60, dt                        # (interpreter start and HIP initialisation included; the wait itself is 3 s)
+
+
+def test_two_ranks_over_real_rccl(tmp_path):
+    """`duet --gpus 2` with the in-library collective over real RCCL -- when this box has two devices (the driver's GPU box has
+    one: skipped there; an 8-GPU node runs it)."""
+    import subprocess
+    import sys
+    n = int(subprocess.check_output([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())']).decode().strip() or 0)
+    if n < 2:
+        pytest.skip('one visible device: two RCCL ranks cannot share it')
+    from duet_amd import synth
+    from tests import helpers as H
+    home = str(tmp_path / 'w')
+    synth.write_workdir(home, H.case_contigs('genome_small', 5), dialect='cutesv', seed=5, write_sam=False)
+    r = fresh_interpreter('from duet_amd.sv_phasing import sv_phasing\nsv_phasing(%r, 50, 2, 4, False)\n' % home, {}, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    one = open(home + '/phased_sv.vcf', 'rb').read()
+    os.remove(home + '/phased_sv.vcf')
+    r = fresh_interpreter('from duet_amd.sv_phasing import sv_phasing\nsv_phasing(%r, 50, 2, 4, False, gpus=2)\n' % home,
+                          {'DUET_RDZV_TIMEOUT': '120'}, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert open(home + '/phased_sv.vcf', 'rb').read() == one and one.count(b'Duet.') > 100

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 5, session B: the wave-cooperative walk of ef_classify -- parity (both walks forced), then the threshold sweep
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+T=${1:-r5b}
+mkdir -p $O
+cd $R
+timeout 1500 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu > $O/${T}_tests.log 2>&1
+echo "rc=$?" >> $O/${T}_tests.log
+tail -5 $O/${T}_tests.log
+timeout 600 python3 tools/sweep_heavy.py > $O/${T}_sweep_small.log 2>&1; cat $O/${T}_sweep_small.log | tail -20
+timeout 900 python3 tools/sweep_heavy.py big > $O/${T}_sweep_big.log 2>&1; cat $O/${T}_sweep_big.log | tail -20
