@@ -18,8 +18,9 @@ N = 1   BASELINE.json configs[1]: one contig, ~1.0 M SV support-read marks, 200 
         2e7 / 2e8 marks (BASELINE.md section 3's definition).  `roofline_clustered_and_phased.traffic`: FETCH_SIZE x 2 +
         WRITE_SIZE of every kernel of the fused pipeline per run, from the committed collection profiles/*fused_traffic*.json.
 N > 1   BASELINE.json configs[2]: the synthetic whole genome (24 contigs, 2e7 marks) as ONE problem, contigs assigned to
-        ranks longest-processing-time-first, each rank runs the three kernels on its shard, exactly ONE
-        all_gather_into_tensor (RCCL over xGMI) per problem reassembles the records; "scaling": "strong".  Rank 0 also
+        ranks longest-processing-time-first, each rank runs the three kernels on its shard, exactly ONE all-gather (RCCL over
+        xGMI) per problem reassembles the records -- through the collective the product ships, duet_comm_* inside libduet_ef.so
+        (`--collective torch`: torch.distributed "nccl"; the line's `collective` says which); "scaling": "strong".  Rank 0 also
         times the same problem on its GPU alone (`same_problem_on_1_gpu`), so the line carries its own 1-GPU reference
         (`value_vs_1gpu_same_problem` = value / that).
 Rank 0 prints ONE JSON line.
@@ -233,14 +234,135 @@ def step_kernels_profiled(ctx, dp, stream, torch, n=64):
     return iso
 
 
-def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, group):
+class TorchColl(object):
+    """Everything through torch.distributed: backend "nccl" (= RCCL; `--collective torch`) or "gloo" (DUET_BENCH_ONE_GPU=1,
+    the one-GPU plumbing mode).  Control plane and data path alike."""
+
+    def __init__(self, torch, dist_mod, backend, local_rank, group=None):
+        self.torch, self.dist, self.backend, self.group = torch, dist_mod, backend, group
+        self.name = 'torch.distributed "%s"' % backend
+        self.dev = 'cpu' if backend == 'gloo' else 'cuda'
+        self.world, self.rank = dist_mod.get_world_size(), dist_mod.get_rank()
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+    def reduce_max_sum(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.dev)
+        tmax, tsum = t.clone(), t.clone()
+        self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.dist.all_reduce(tsum, op=self.dist.ReduceOp.SUM, group=self.group)
+        return [float(x) for x in tmax], [float(x) for x in tsum]
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def all_gather_into_tensor(self, dst, src, async_op=False):
+        if self.backend == 'gloo' and src.device.type != 'cpu':
+            # plumbing mode: gloo gathers host tensors; staged (synchronously) through the host
+            h = src.cpu()
+            out = self.torch.empty(dst.numel(), dtype=dst.dtype)
+            self.dist.all_gather_into_tensor(out, h, group=self.group)
+            dst.copy_(out)
+            return _Done()
+        w = self.dist.all_gather_into_tensor(dst, src, async_op=async_op, group=self.group)
+        return w if async_op else _Done()
+
+    def version(self):
+        try:
+            return '.'.join(str(v) for v in self.torch.cuda.nccl.version())
+        except Exception:
+            return None
+
+    def close(self):
+        pass
+
+
+class _Done(object):
+    def wait(self):
+        pass
+
+
+class _StreamWork(object):
+    """What an asynchronous collective hands back: wait() makes the CURRENT stream wait for it (as torch's work objects do)."""
+
+    def __init__(self, torch, ev):
+        self.torch, self.ev = torch, ev
+
+    def wait(self):
+        self.torch.cuda.current_stream().wait_event(self.ev)
+
+
+class DuetColl(object):
+    """What `duet --gpus N` ships (default for N > 1): the DATA PATH's all-gather is the collective inside libduet_ef.so
+    (duet_comm_*: ncclCommInitRank + ncclAllGather over xGMI, RCCL loaded by the library) on a side stream beside the kernels'
+    stream; the bench's CONTROL plane -- barriers around the timed region, max-over-ranks of a few floats, the topology census,
+    the hand-over of RCCL's unique id -- goes through torch.distributed "gloo" on the host (the product's ranks use a TCP star
+    for that: duet_amd/comm.py)."""
+
+    def __init__(self, torch, dist_mod, ctx, timeout=300.0):
+        from duet_amd import comm
+        self.torch, self.dist, self.ctx = torch, dist_mod, ctx
+        self.ctl = TorchColl(torch, dist_mod, 'gloo', 0)
+        self.world, self.rank = self.ctl.world, self.ctl.rank
+        self.backend = 'duet_comm'
+        self.name = 'duet_comm_* in libduet_ef.so (RCCL ncclAllGather); control plane: torch.distributed "gloo"'
+        dist = dist_mod
+
+        class _IdCarrier(object):                       # what comm.RcclGather needs of a star: rank, world, timeout, bcast
+            rank, world = self.rank, self.world
+
+            def __init__(self, timeout):
+                self.timeout = timeout
+
+            def bcast(self, data=None):
+                box = [data]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+
+        self.gather = comm.RcclGather(ctx, _IdCarrier(float(timeout)))
+        self.stream = torch.cuda.Stream()
+
+    def barrier(self):
+        self.ctl.barrier()
+
+    def reduce_max_sum(self, values):
+        return self.ctl.reduce_max_sum(values)
+
+    def all_gather_object(self, obj):
+        return self.ctl.all_gather_object(obj)
+
+    def all_gather_into_tensor(self, dst, src, async_op=False):
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)
+        self.gather.allgather_device(src.data_ptr(), src.numel() * src.element_size(), dst.data_ptr(), self.stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        w = _StreamWork(torch, done)
+        if not async_op:
+            w.wait()
+        return w
+
+    def version(self):
+        v = int(self.ctx.lib.duet_comm_rccl_version(self.ctx.handle))
+        return '%d.%d.%d' % (v // 10000, v // 100 % 100, v % 100) if v > 0 else None
+
+    def close(self):
+        self.gather.close()
+
+
+def timed_steps(ctx, dp, steps, warmup, world, torch, coll, group):
     """W warm-up + K timed steps of (ef_classify -> ef_seed_sort -> ef_finalize [-> all-gather]).  With world > 1 the
     record blocks of `group` consecutive jobs go out in ONE asynchronous all_gather_into_tensor on RCCL's stream, which
     overlaps the kernels of the following job(s); group = 1 is one collective per problem (the sharded configs[2] run).
     Every job is gathered completely before the clock stops."""
     from duet_amd.dist import GroupedGather
     stream = torch.cuda.current_stream().cuda_stream
-    gg = GroupedGather(dp.out_storage, dp.out_blocks[0].numel(), world, group, dist_mod, always=dist_mod is not None)
+    gg = GroupedGather(dp.out_storage, dp.out_blocks[0].numel(), world, group, coll, always=coll is not None)
 
     def one():
         dp.run(ctx, stream, gg.next_slot())
@@ -252,16 +374,16 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, group):
     ctx.check(stream)
     ctx.set_profiling(3)                 # HIP start/stop events on ef_classify's own dispatch, every 8th step
     ctx.profile_collect()
-    if dist_mod is not None:
-        dist_mod.barrier()
+    if coll is not None:
+        coll.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
     gg.drain()
     torch.cuda.synchronize()
-    if dist_mod is not None:
-        dist_mod.barrier()
+    if coll is not None:
+        coll.barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_collect()
     ctx.set_profiling(0)
@@ -269,34 +391,20 @@ def timed_steps(ctx, dp, steps, warmup, world, torch, dist_mod, group):
     return dt, prof, gg
 
 
-def reduce_max_sum(torch, dist_mod, values):
-    t = torch.tensor(values, dtype=torch.float64, device='cuda')
-    tmax, tsum = t.clone(), t.clone()
-    dist_mod.all_reduce(tmax, op=dist_mod.ReduceOp.MAX)
-    dist_mod.all_reduce(tsum, op=dist_mod.ReduceOp.SUM)
-    return [float(x) for x in tmax], [float(x) for x in tsum]
-
-
-def topology(torch, dist_mod, rank, world, local_rank, one_gpu):
+def topology(torch, coll, rank, world, local_rank, one_gpu):
     """What proves N ranks on N devices: per rank its device index, name, PCI bus id and the XCD/CU count; the
-    collective backend and RCCL's version."""
+    collective path and RCCL's version."""
     props = torch.cuda.get_device_properties(local_rank)
     mine = {'rank': rank, 'device': local_rank, 'name': props.name, 'cus': props.multi_processor_count,
             'hbm_GiB': round(props.total_memory / 2 ** 30, 1),
             'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pid': os.getpid()}
-    allr = [None] * world
-    dist_mod.all_gather_object(allr, mine)
-    ver = None
-    try:
-        ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
-    except Exception:
-        pass
-    return {'backend': dist_mod.get_backend(), 'world_size': dist_mod.get_world_size(), 'rccl_version': ver,
+    allr = coll.all_gather_object(mine)
+    return {'backend': coll.backend, 'collective': coll.name, 'world_size': coll.world, 'rccl_version': coll.version(),
             'one_gpu_plumbing_mode': one_gpu, 'ranks': allr,
             'distinct_devices': len(set((r['device'], r['pci_bus_id']) for r in allr))}
 
 
-def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
+def sharded_run(args, ctx, torch, coll, rank, world, local_rank, one_gpu):
     """N > 1: BASELINE configs[2] -- the synthetic whole genome (24 contigs, 2e7 marks) as ONE problem, contigs assigned
     to ranks longest-processing-time-first on mark counts (duet_amd/dist.py), each rank runs the three kernels on its
     shard, exactly ONE all_gather_into_tensor per problem reassembles the (pred, ps) records on every rank.  Strong
@@ -316,12 +424,12 @@ def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
     stream_obj = torch.cuda.Stream()
     with torch.cuda.stream(stream_obj):
         stream = torch.cuda.current_stream().cuda_stream
-        dt, prof, gg = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod, 1)
+        dt, prof, gg = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, coll, 1)
         gathered = gg.last_job_blocks()
         # --- outside the timed region: the pieces on their own ---------------------------------------------------
         iso = step_kernels_profiled(ctx, dp, stream, torch, n=min(args.steps, 50))
         n = max(10, min(args.steps, 50))
-        dist_mod.barrier()
+        coll.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -331,13 +439,13 @@ def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
         src = dp.out_blocks[3]
         dst = torch.empty(world * src.numel(), dtype=torch.uint8, device=src.device)
         for _ in range(3):
-            dist_mod.all_gather_into_tensor(dst, src)
+            coll.all_gather_into_tensor(dst, src)
         torch.cuda.synchronize()
-        dist_mod.barrier()
+        coll.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
-            dist_mod.all_gather_into_tensor(dst, src)
+            coll.all_gather_into_tensor(dst, src)
         torch.cuda.synchronize()
         t_gather = (time.perf_counter() - t0) / n
     kms = float(prof.kernel_ms[0])
@@ -349,10 +457,9 @@ def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
             'ef_classify_frac_of_8TBs': ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else 0.0,
             'kernels_us_isolated': {k: round(float(iso.kernel_ms[i]) * 1e3, 2) for i, k in enumerate(('ef_classify', 'ef_seed_sort', 'ef_finalize'))},
             'kernels_only_ms_per_step': t_kern * 1e3, 'gather_only_us': t_gather * 1e6}
-    per_rank = [None] * world
-    dist_mod.all_gather_object(per_rank, mine)
-    (dt,), _ = reduce_max_sum(torch, dist_mod, [dt])
-    topo = topology(torch, dist_mod, rank, world, local_rank, one_gpu)
+    per_rank = coll.all_gather_object(mine)
+    (dt,), _ = coll.reduce_max_sum([dt])
+    topo = topology(torch, coll, rank, world, local_rank, one_gpu)
 
     out = None
     same = None
@@ -393,13 +500,14 @@ def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
             'plumbing_test_one_gpu': one_gpu,
             'config': {'workload': 'BASELINE configs[2]: synthetic whole genome chr1-22,X,Y, %d SV marks / %d candidates / %d '
                                    'tagged reads in %d contigs, resident in HBM, contigs LPT-sharded over %d GPUs; step = '
-                                   'classify+seed_sort+finalize per rank + ONE all_gather_into_tensor of the 5 B/candidate '
+                                   'classify+seed_sort+finalize per rank + ONE all-gather of the 5 B/candidate '
                                    'records per problem (asynchronous, overlapping the next problem\'s kernels)'
                                    % (soa.n_marks, soa.n_cands, soa.n_reads, soa.n_contigs, world),
                        'marks': soa.n_marks, 'candidates': soa.n_cands, 'reads': soa.n_reads, 'contigs': soa.n_contigs,
                        'parallelism': 'contig-sharded x%d (LPT on mark counts)' % world, 'svlen_thres': 50,
                        'suppread_thres': 2},
             'parity_vs_oracle': parity,
+            'collective': coll.name,
             'roofline': {'kernel': 'ef_classify', 'bound': 'hbm', 'achieved': slow['ef_classify_GBs'], 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': slow['ef_classify_frac_of_8TBs'], 'traffic': None,
                          'algorithmic_bytes_per_launch': slow['ef_classify_algorithmic_bytes'],
@@ -417,11 +525,11 @@ def sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu):
             # bench.py is BASELINE configs[1], a different workload; its `scaling_point_1gpu` is this problem too)
             'value_vs_1gpu_same_problem': (soa.n_marks * args.steps / dt) / same['marks_per_s'],
         }
-    dist_mod.barrier()
+    coll.barrier()
     return out
 
 
-def fused_sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank):
+def fused_sharded_run(args, ctx, torch, coll, rank, world, local_rank):
     """extra (N > 1): the CLUSTERED pipeline sharded like BASELINE configs[3] runs it (`--sv_caller svim`, 8 GPUs): the raw,
     shuffled marks of the whole-genome problem go to the rank that owns their contig (stage A0's partitions never cross a
     contig), every rank runs duet_svim_phase_device (A0 + E/F) on its marks, and ONE all_gather_into_tensor of fixed-size
@@ -449,13 +557,11 @@ def fused_sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank):
         err = '%s: %s' % (type(e).__name__, e)
     # every rank learns whether every rank got this far BEFORE the first collective of the timed part: a rank that failed
     # on its own must not leave the others waiting in an all-gather
-    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device='cuda')
-    dist_mod.all_reduce(ok, op=dist_mod.ReduceOp.MIN)
-    if float(ok.item()) == 0.0:
-        return {'error': err or 'another rank failed while setting up'}
-    counts = torch.zeros(world, dtype=torch.int64, device='cuda')
-    dist_mod.all_gather_into_tensor(counts, torch.tensor([n_mine], dtype=torch.int64, device='cuda'))
-    n_max = max(int(counts.max().item()), 1)
+    states = coll.all_gather_object({'err': err, 'n': None if err else n_mine})
+    if any(x['err'] for x in states):
+        return {'error': err or 'another rank failed while setting up: %s' % [x['err'] for x in states if x['err']][0]}
+    counts = [int(x['n']) for x in states]
+    n_max = max(max(counts), 1)
     block = torch.zeros(13 * n_max, dtype=torch.uint8, device='cuda')
     gathered = torch.empty(world * 13 * n_max, dtype=torch.uint8, device='cuda')
     ps_b = ds.out_ps.view(torch.uint8)
@@ -468,18 +574,18 @@ def fused_sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank):
         block[4 * n_max:4 * n_max + 4 * n].copy_(pos_b[:4 * n])
         block[8 * n_max:8 * n_max + 4 * n].copy_(span_b[:4 * n])
         block[12 * n_max:12 * n_max + n].copy_(pred_b[:n])
-        dist_mod.all_gather_into_tensor(gathered, block)
+        coll.all_gather_into_tensor(gathered, block)
 
     for _ in range(max(2, args.warmup // 4)):
         one()
-    dist_mod.barrier()
+    coll.barrier()
     torch.cuda.synchronize()
     steps = max(3, min(args.steps, 20))
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
     torch.cuda.synchronize()
-    dist_mod.barrier()
+    coll.barrier()
     dt = time.perf_counter() - t0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -508,10 +614,10 @@ def fused_sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank):
         g0 = gathered[:13 * n_max].cpu().numpy()
         parity = bool(rc == 0 and n_mine == N and np.array_equal(got['pred'], wp) and np.array_equal(got['ps'], ws)
                       and np.array_equal(g0[:4 * N].view(np.uint32), ws) and np.array_equal(g0[12 * n_max:12 * n_max + N], wp))
-    (dt, t_alone_max), (_, _) = reduce_max_sum(torch, dist_mod, [dt, t_alone])
-    cand = [int(x) for x in counts.cpu().numpy()]
+    (dt, t_alone_max), (_, _) = coll.reduce_max_sum([dt, t_alone])
+    cand = counts
     return {'scaling': 'strong', 'workload': 'BASELINE configs[3] in shape: %d raw shuffled SV marks of 24 contigs, contig-sharded over %d '
-                                             'GPUs; step = duet_svim_phase_device (A0 + E/F) per rank + ONE all_gather_into_tensor of 13 B '
+                                             'GPUs; step = duet_svim_phase_device (A0 + E/F) per rank + ONE all-gather of 13 B '
                                              'candidate records' % (M_all, world),
             'marks': M_all, 'marks_rank0': M_mine, 'candidates_per_rank': cand, 'steps': steps,
             'marks_per_s': M_all * steps / dt, 'ms_per_step': dt / steps * 1e3,
@@ -520,7 +626,7 @@ def fused_sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank):
             'note': 'clustering rule: parity unpinned (own rule, oracle/cluster_oracle.c); E/F pinned'}
 
 
-def weak_grouped_run(args, ctx, torch, dist_mod, rank, world, local_rank):
+def weak_grouped_run(args, ctx, torch, coll, rank, world, local_rank):
     """extra (N > 1): round 1's weak-scaling variant -- one config-2 contig per rank, the record blocks of GATHER_GROUP
     consecutive jobs in one asynchronous collective."""
     from duet_amd import dist, engine, synth
@@ -531,13 +637,13 @@ def weak_grouped_run(args, ctx, torch, dist_mod, rank, world, local_rank):
     n_max = soa.n_cands
     dp = DeviceProblem(soa, 50, 2, device='cuda:%d' % local_rank, n_cands_max=n_max, n_out=2 * GATHER_GROUP)
     with torch.cuda.stream(torch.cuda.Stream()):
-        dt, prof, gg = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, dist_mod, GATHER_GROUP)
+        dt, prof, gg = timed_steps(ctx, dp, args.steps, args.warmup, world, torch, coll, GATHER_GROUP)
         gathered = gg.last_job_blocks()
     c_oracle = cpu_leg()
     rc, want_pred, want_ps = c_oracle.ef(soa, 50, 2)
     gp, gs = dist.unpack_block(gathered[rank].cpu().numpy(), n_max, soa.n_cands)
     ok = float(rc == 0 and np.array_equal(gp, want_pred) and np.array_equal(gs, want_ps))
-    (dt, _, _), (_, marks, oks) = reduce_max_sum(torch, dist_mod, [dt, float(soa.n_marks), ok])
+    (dt, _, _), (_, marks, oks) = coll.reduce_max_sum([dt, float(soa.n_marks), ok])
     return {'scaling': 'weak', 'workload': 'one BASELINE configs[1] contig per rank, %d jobs per all-gather' % GATHER_GROUP,
             'marks_per_s': marks * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3, 'parity_vs_oracle': bool(oks == world)}
 
@@ -782,6 +888,9 @@ def main():
     ap.add_argument('--no-large', action='store_true', help='skip the 2e8-mark single-GPU point (about a minute of host-side generation)')
     ap.add_argument('--large', action='store_true', help='(default now; kept for round-1 command lines)')
     ap.add_argument('--genome-marks', type=int, default=20000000, help='N > 1: marks of the sharded whole-genome problem')
+    ap.add_argument('--collective', choices=('duet', 'torch'), default='duet',
+                    help='N > 1: the all-gather of the data path -- "duet": duet_comm_* inside libduet_ef.so, what `duet --gpus N` ships '
+                         '(default); "torch": torch.distributed backend "nccl" (rounds 1-4)')
     ap.add_argument('--launch-dry-run', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -817,12 +926,14 @@ def main():
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist_mod = None
-    # DUET_BENCH_RCCL_SELF=1 (a check on a 1-GPU box, never a measurement): the N > 1 code path as ONE rank over backend
-    # "nccl" -- communicator set-up, the asynchronous all_gather_into_tensor on RCCL's stream beside the kernels' raw
-    # stream, barriers, all-reduces -- on the sharded configs[2] problem
+    dist_mod, coll, fallback = None, None, None
+    # DUET_BENCH_RCCL_SELF=1 (a check on a 1-GPU box, never a measurement): the N > 1 code path as ONE rank over real RCCL --
+    # communicator set-up, the asynchronous all-gather on its own stream beside the kernels' raw stream, barriers, reductions --
+    # on the sharded configs[2] problem
     rccl_self = world == 1 and os.environ.get('DUET_BENCH_RCCL_SELF') == '1'
+    ctx = _lib.Context(local_rank)
     if world > 1 or rccl_self:
+        import datetime
         import torch.distributed as dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if rccl_self:
@@ -830,19 +941,39 @@ def main():
             os.environ.setdefault('MASTER_PORT', str(_launch.free_port()))
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
+        limit = float(os.environ.get('DUET_RDZV_TIMEOUT', '300'))
         if one_gpu:
-            dist_mod.init_process_group('gloo')
+            dist_mod.init_process_group('gloo', timeout=datetime.timedelta(seconds=limit))
+            coll = TorchColl(torch, dist_mod, 'gloo', local_rank)
+        elif args.collective == 'torch':
+            dist_mod.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(seconds=limit))
+            coll = TorchColl(torch, dist_mod, 'nccl', local_rank)
         else:
-            dist_mod.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            # default: the collective the product's ranks use (duet_comm_* inside libduet_ef.so); gloo carries the control plane
+            dist_mod.init_process_group('gloo', timeout=datetime.timedelta(seconds=limit))
+            err = None
+            try:
+                coll = DuetColl(torch, dist_mod, ctx, timeout=limit)
+            except Exception as e:                       # (RCCL missing, communicator set-up failed or timed out)
+                err = '%s: %s' % (type(e).__name__, e)
+            errs = [None] * world
+            dist_mod.all_gather_object(errs, err)
+            if any(errs):
+                # every rank agrees to step down to torch.distributed "nccl" -- said on the line, never silently
+                fallback = [e for e in errs if e][0]
+                if coll is not None:
+                    coll.close()
+                grp = dist_mod.new_group(backend='nccl', timeout=datetime.timedelta(seconds=limit))
+                coll = TorchColl(torch, dist_mod, 'nccl', local_rank, group=grp)
+                coll.name += ' (duet_comm_* unavailable: %s)' % fallback[:200]
 
-    ctx = _lib.Context(local_rank)
     if world == 1 and not rccl_self:
         out = single_gpu_run(args, ctx, torch)
     else:
-        out = sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank, one_gpu)
+        out = sharded_run(args, ctx, torch, coll, rank, world, local_rank, one_gpu)
         if not args.no_extra:
-            weak = weak_grouped_run(args, ctx, torch, dist_mod, rank, world, local_rank)
-            fused = fused_sharded_run(args, ctx, torch, dist_mod, rank, world, local_rank)
+            weak = weak_grouped_run(args, ctx, torch, coll, rank, world, local_rank)
+            fused = fused_sharded_run(args, ctx, torch, coll, rank, world, local_rank)
             if rank == 0:
                 out['extra'] = {'weak_grouped_config2_per_rank': weak, 'fused_clustered_and_phased_sharded': fused}
     if rank == 0:
@@ -850,10 +981,14 @@ def main():
         os.write(json_fd, (json.dumps(compact_line(out, path)) + '\n').encode())
     os.close(json_fd)
 
+    if coll is not None:
+        coll.barrier()
+        coll.close()
     if dist_mod is not None:
-        dist_mod.barrier()
         dist_mod.destroy_process_group()
     ctx.close()
+    if fallback and 'did not finish within' in fallback:
+        os._exit(0)                                      # a helper thread may still sit inside RCCL's set-up: no interpreter shutdown
 
 
 def concurrent_jobs(torch, _lib, DeviceProblem, soa, steps, n_streams=4):

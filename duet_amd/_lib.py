@@ -27,7 +27,7 @@ EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last
            'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_svim_phase_host', 'duet_rows_run_device',
            'duet_ef_rows_run_host', 'duet_eval_run_host', 'duet_comm_unique_id', 'duet_comm_create', 'duet_comm_allgather_device',
            'duet_comm_allgather_host', 'duet_comm_destroy', 'duet_comm_set_timeout', 'duet_comm_block_bytes',
-           'duet_comm_ef_allgather')
+           'duet_comm_ef_allgather', 'duet_comm_rccl_version')
 
 
 class EfProblem(ctypes.Structure):
@@ -147,6 +147,7 @@ def load():
     lib.duet_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.duet_comm_allgather_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
     lib.duet_comm_allgather_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.duet_comm_rccl_version.argtypes = [ctypes.c_void_p]
     lib.duet_comm_set_timeout.argtypes = [ctypes.c_void_p, ctypes.c_double]
     lib.duet_comm_block_bytes.restype = ctypes.c_uint64
     lib.duet_comm_block_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32]

@@ -36,6 +36,7 @@ typedef int (*fn_comm_init_rank)(NcclComm *, int, NcclUniqueId, int);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int /* ncclDataType_t */, NcclComm, hipStream_t);
 typedef int (*fn_comm_destroy)(NcclComm);
 typedef const char *(*fn_error_string)(int);
+typedef int (*fn_get_version)(int *);
 constexpr int kNcclUint8 = 1;
 
 struct Rccl {
@@ -45,6 +46,7 @@ struct Rccl {
     fn_all_gather all_gather = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
     fn_error_string error_string = nullptr;
+    fn_get_version get_version = nullptr;
     std::string why;
 };
 
@@ -75,6 +77,7 @@ void rccl_load(Rccl &r)
     r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
     r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
     r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
+    r.get_version = (fn_get_version)dlsym(r.handle, "ncclGetVersion");
     if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) {
         r.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
         r.handle = nullptr;
@@ -173,6 +176,15 @@ __global__ __launch_bounds__(256) void comm_trailer(const uint8_t *__restrict__ 
 }  // namespace
 
 extern "C" {
+
+int duet_comm_rccl_version(duet_ctx *ctx)
+{
+    Rccl &r = rccl();
+    if (!r.handle) return duet_fail(ctx, DUET_ERR_NO_DEVICE, r.why);
+    int v = 0;
+    if (!r.get_version || r.get_version(&v)) return duet_fail(ctx, DUET_ERR_HIP, "ncclGetVersion failed");
+    return v;
+}
 
 int duet_comm_unique_id(duet_ctx *ctx, unsigned char *id)
 {

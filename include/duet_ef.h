@@ -334,6 +334,7 @@ DUET_API int duet_eval_run_host(duet_ctx *ctx, const duet_eval_problem *prob, du
  * (duet_last_error(ctx)). */
 #define DUET_COMM_ID_BYTES 128
 typedef struct duet_comm duet_comm;
+DUET_API int duet_comm_rccl_version(duet_ctx *ctx);      /* ncclGetVersion's code (e.g. 22707) of the RCCL the library loaded, or a negative status */
 DUET_API int duet_comm_unique_id(duet_ctx *ctx, unsigned char *id /* [DUET_COMM_ID_BYTES] */);
 DUET_API duet_comm *duet_comm_create(duet_ctx *ctx, const unsigned char *id, int rank, int world);
 /* Every blocking step is bounded: duet_comm_create and the synchronising calls below give up after the time limit -- the

@@ -227,9 +227,14 @@ def test_bench_self_spawns_and_runs_the_sharded_genome(tmp_path):
     out = subprocess.check_output([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
                                    '--genome-marks', '400000', '--no-extra'], env=env, timeout=600).decode()
     line = [l for l in out.splitlines() if l.startswith('{')][-1]
+    assert len(line) < 8000                          # (the driver could not parse round 4's 22.5 kB line)
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 3 and d['parity_vs_oracle'] is True
-    assert d['gather']['collectives_per_problem'] == 1 and d['topology']['world_size'] == 2 and len(d['per_rank']) == 2
-    assert sum(r['marks'] for r in d['per_rank']) == d['config']['marks']
+    assert d['gather']['collectives_per_problem'] == 1 and d['topology']['world_size'] == 2 and len(d['per_rank']['marks']) == 2
+    assert sum(d['per_rank']['marks']) == d['config']['marks']
+    # ... and the complete record beside it (per rank: contigs, kernel times; topology with device names)
+    with open(os.path.join(repo, d['detail_file'])) as f:
+        full = json.loads(f.readline())
+    assert len(full['per_rank']) == 2 and sum(r['marks'] for r in full['per_rank']) == d['config']['marks']
     assert d['same_problem_on_1_gpu']['parity_vs_oracle'] is True
     assert 1.0 <= d['sharding']['lpt_imbalance_max_over_mean_marks'] < 1.2

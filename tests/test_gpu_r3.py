@@ -102,20 +102,26 @@ def test_one_rank_over_rccl(tmp_path):
     assert open(home2 + '/phased_sv.vcf').read() == one
 
 
-def test_bench_sharded_path_as_one_rank_over_rccl():
-    """bench.py's N > 1 code path -- LPT sharding, the asynchronous all_gather_into_tensor per problem on RCCL's stream beside
-    the kernels' raw stream, barriers, the all-reduced per-rank figures, the fused sharded extra -- as ONE rank over backend
-    "nccl" (DUET_BENCH_RCCL_SELF=1; two ranks cannot share this box's GPU under RCCL)."""
+@pytest.mark.parametrize('collective', ['duet', 'torch'])
+def test_bench_sharded_path_as_one_rank_over_rccl(collective):
+    """bench.py's N > 1 code path -- LPT sharding, the asynchronous all-gather per problem on its own stream beside the kernels'
+    raw stream, barriers, the reduced per-rank figures, the fused sharded extra -- as ONE rank over real RCCL
+    (DUET_BENCH_RCCL_SELF=1; two ranks cannot share this box's GPU under RCCL): through the collective the product ships
+    (duet_comm_* inside libduet_ef.so: the default) and through torch.distributed "nccl" (`--collective torch`)."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
     env['DUET_BENCH_RCCL_SELF'] = '1'
     out = subprocess.check_output([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2',
-                                   '--genome-marks', '2000000'], env=env, timeout=900).decode()
-    d = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+                                   '--genome-marks', '2000000', '--collective', collective], env=env, timeout=900).decode()
+    line = [l for l in out.splitlines() if l.startswith('{')][-1]
+    assert len(line) < 8000
+    d = json.loads(line)
     assert d['n_gpus'] == 1 and d['parity_vs_oracle'] is True
-    assert d['topology']['backend'] == 'nccl' and d['topology']['world_size'] == 1 and d['topology']['rccl_version']
+    assert d['topology']['backend'] == ('duet_comm' if collective == 'duet' else 'nccl'), d['topology']
+    assert d['topology']['world_size'] == 1 and d['topology']['rccl_version']
+    assert ('duet_comm_*' in d['collective']) == (collective == 'duet') and 'unavailable' not in d['collective']
     assert d['gather']['collectives_per_problem'] == 1
     assert d['extra']['fused_clustered_and_phased_sharded']['parity_rank0_vs_composed_oracles'] is True
 
