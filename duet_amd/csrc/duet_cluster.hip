@@ -2575,7 +2575,11 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // large inputs, record sort: cl_box is also the partition scan's last stage (no part_apply launch)
     // (small inputs keep part_apply: there the chain of the partitions of more than 64 marks is the critical path and has to start
     // beside the box test, not behind it -- measured: 315 us against 287 at 1.0 M marks)
-    const bool box_applies = rec_mode && (!small_in || big_sort);
+    // (cl_box<.., true> reads tiles[tile] as the EXCLUSIVE carry part_spine leaves: it applies exactly where the spine launch runs,
+    // i.e. never together with the spine-less part_apply<true> of `nb_sc <= kSelfSpine && !big_sort`)
+    static_assert((4u << 20) == kSelfSpine * (uint32_t)kScanTile, "small_in's bound is the spine-less scan's reach: box_applies needs part_spine's carries");
+    const bool use_spine = nb_sc > kSelfSpine || big_sort;
+    const bool box_applies = rec_mode && (!small_in || big_sort) && use_spine;
     PartSum *tiles = (PartSum *)tmpA;                             // the partition scan's tile summaries: 3 words per 2048 marks
     uint8_t *hbits = (uint8_t *)tmpA + ((((size_t)nb_sc + 1) * sizeof(PartSum) + 15) & ~(size_t)15);      // ... and the head flags, a bit per mark
     p.e_rec = (uint4 *)ctx->cl_ws[9].ptr;
@@ -2589,6 +2593,10 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         uint4 *buf[2] = {(uint4 *)ctx->cl_ws[14].ptr, (uint4 *)recs};
         const bool rs_small = nb_rs <= kRsSmallTiles && !big_sort;
         uint32_t *dtot = ctx->rx_dtot;                             // [kRsDtotCopies][2048]
+        // (every pass's rs_scatter zeroes the totals behind itself; a run cut short between a histogram and its scatter -- a launch
+        // failure, an early return on a HIP error -- would leave them dirty for every later sort on this context: ~1 us for not
+        // depending on that)
+        HIP_TRY(ctx, hipMemsetAsync(dtot, 0, (size_t)kRsDtotCopies * 2048u * sizeof(uint32_t), st));
         uint32_t *partial = hist + ((size_t)nb_rs << kRsMaxW);
         uint16_t *dig = (uint16_t *)valsB;                        // the next pass's digit of every record (rs_scatter -> rs_hist_dig)
         const uint4 *rin = nullptr;
@@ -2914,6 +2922,16 @@ int duet_svim_phase_host(duet_ctx *ctx, const duet_svim_problem *pr, const duet_
     const uint32_t M = pr->marks.n_marks;
     *res->n_cands = 0;
     if (M == 0) return DUET_OK;
+    // every array is on the host here: what the device entry has to trust is checked -- a contig id beyond the depth description
+    // would index sv_depth_off / the E/F plan outside their K + 1 entries
+    if (!res->cand_off || !res->cand_contig || !res->cand_type || !res->cand_pos || !res->cand_span)
+        return duet_fail(ctx, DUET_ERR_INVALID, "null result array");
+    for (uint32_t k = 0; k < pr->n_contigs; ++k)
+        if (pr->depth_off[k] > pr->depth_off[k + 1]) return duet_fail(ctx, DUET_ERR_INVALID, "depth_off must be non-decreasing");
+    if (!pr->marks.mark_contig) return duet_fail(ctx, DUET_ERR_INVALID, "null array");
+    for (uint32_t i = 0; i < M; ++i)
+        if (pr->marks.mark_contig[i] >= pr->n_contigs)
+            return duet_fail(ctx, DUET_ERR_INVALID, "a mark's contig id is not below n_contigs (the depth description's contig count)");
     hipStream_t s = ctx->own_stream;
     int rc;
     const size_t n_depth = pr->depth_off[pr->n_contigs];

@@ -117,3 +117,32 @@ def test_two_ranks_over_real_rccl(tmp_path):
                           {'DUET_RDZV_TIMEOUT': '120'}, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert open(home + '/phased_sv.vcf', 'rb').read() == one and one.count(b'Duet.') > 100
+
+
+def test_svim_host_entry_refuses_contig_ids_beyond_the_depth_description():
+    """duet_svim_phase_host has every array on the host: a mark whose contig id is not below n_contigs (= the depth
+    description's contig count) would index the depth offsets and the E/F plan outside their K + 1 entries on the device; a
+    depth_off that is not non-decreasing likewise.  Refused with DUET_ERR_INVALID before anything is uploaded."""
+    from duet_amd import _lib, engine, synth
+    from tests import helpers as H
+    contigs = H.case_contigs('genome_small', 5)
+    soa = engine.soa_from_synth(contigs)
+    marks = synth.raw_marks(contigs, 1, reads_of=soa)
+    depth, depth_off = synth.depth_bins(contigs, 1000, 1)
+    ctx = _lib.Context(0)
+    try:
+        good = ctx.svim_host(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
+        assert len(good['pred']) > 100
+        bad = dict(marks)
+        bad['contig'] = marks['contig'].copy()
+        bad['contig'][len(bad['contig']) // 2] = len(depth_off) - 1            # one id too far
+        with pytest.raises(_lib.DuetLibraryError, match='contig id'):
+            ctx.svim_host(bad, soa.read_tag, depth, depth_off, 1000, 50, 2)
+        off = depth_off.copy()
+        off[2] = off[3] + 1
+        with pytest.raises(_lib.DuetLibraryError, match='non-decreasing'):
+            ctx.svim_host(marks, soa.read_tag, depth, off, 1000, 50, 2)
+        again = ctx.svim_host(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)     # the context is still good
+        assert np.array_equal(again['pred'], good['pred']) and np.array_equal(again['ps'], good['ps'])
+    finally:
+        ctx.close()
