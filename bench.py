@@ -869,10 +869,13 @@ def single_gpu_run(args, ctx, torch):
         out['summed_kernels_frac_B_EF'] = sk
         ex['A0_clustering_config2_marks'] = cluster_point(ctx, torch, synth, [contig])
         ex['fused_clustered_and_phased_config2'] = fused
+        tailed = {}
         ex['fused_clustered_and_phased_2e7_marks'] = fused_point(ctx, torch, engine, synth,
-                                                                  synth.bench_genome(20000000, 3), runs=5)
+                                                                  synth.bench_genome(20000000, 3), runs=5, tailed=tailed)
+        ex['ef_tailed_sizes_2e7'] = tailed
         ex['fused_clustered_and_phased_2e7_marks_scan_order'] = fused_point(ctx, torch, engine, synth,
                                                                              synth.bench_genome(20000000, 3), runs=5, scan_order=True)
+        ex['config2_literal_8d_generator'] = literal_8d_point(ctx, torch, engine, synth, DeviceProblem, args.steps)
         ex['three_timed_regions_config2'] = abi_and_e2e(ctx, soa, contig, float(iso.total_ms))
         ex['concurrent_jobs_config2'] = concurrent_jobs(torch, _lib, DeviceProblem, soa, args.steps)
     return out
@@ -989,6 +992,50 @@ def main():
     ctx.close()
     if fallback and 'did not finish within' in fallback:
         os._exit(0)                                      # a helper thread may still sit inside RCCL's set-up: no interpreter shutdown
+
+
+def ef_point(ctx, torch, DeviceProblem, soa, steps):
+    """One E/F problem resident in HBM: wall time per step of `steps` back-to-back steps, then every kernel's own duration
+    (HIP events on its dispatch), parity against the C oracle."""
+    dp = DeviceProblem(soa, 50, 2)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        dp.run(ctx, stream)
+    ctx.check(stream)
+    torch.cuda.synchronize()
+    n = max(20, min(int(steps), 200))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        dp.run(ctx, stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    ctx.set_profiling(2)
+    ctx.profile_collect()
+    for _ in range(20):
+        dp.run(ctx, stream)
+    torch.cuda.synchronize()
+    prof = ctx.profile_collect()
+    ctx.set_profiling(0)
+    ctx.check(stream)
+    pred, ps = dp.results()
+    rc, want_pred, want_ps = cpu_leg().ef(soa, 50, 2)
+    ok = bool(rc == 0 and np.array_equal(pred, want_pred) and np.array_equal(ps, want_ps))
+    del dp
+    torch.cuda.empty_cache()
+    return {'marks': soa.n_marks, 'candidates': soa.n_cands, 'reads': soa.n_reads, 'ms_per_step': dt * 1e3, 'marks_per_s': soa.n_marks / dt,
+            'parity_vs_oracle': ok,
+            'kernels_us': {k: round(float(prof.kernel_ms[i]) * 1e3, 2) for i, k in enumerate(('ef_classify', 'ef_seed_sort', 'ef_finalize'))}}
+
+
+def literal_8d_point(ctx, torch, engine, synth, DeviceProblem, steps):
+    """BASELINE configs[1] on SURVEY 8d's generator TO THE LETTER (20 % of the marks' names without a SAM line, pc = floor(Exp(600));
+    the headline's default generator: 5 % and a geometric PC) -- the reference's sha256 for these inputs is
+    tests/golden/seeded_r5.json (tests/test_gpu_r5.py runs the text path against it)."""
+    soa = engine.soa_from_synth([synth.bench_contig('1', 200000, 100000, 1, spelled='chr1', literal_8d=True)])
+    out = ef_point(ctx, torch, DeviceProblem, soa, steps)
+    out['marks_absent_share'] = float((soa.mark_read == engine.MARK_ABSENT).mean())
+    out['reference_sha256_pin'] = 'tests/golden/seeded_r5.json'
+    return out
 
 
 def concurrent_jobs(torch, _lib, DeviceProblem, soa, steps, n_streams=4):
@@ -1116,7 +1163,7 @@ def cluster_point(ctx, torch, synth, contigs):
             'note': 'latency-bound at this size: ~20 small launches; the partitions with the most groups left are on the critical path'}
 
 
-def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False):
+def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False, tailed=None):
     """The metric read literally -- marks clustered AND phased: duet_svim_phase_device on raw shuffled marks
     (A0 sort + linkage + emit, adapter, E/F) resident in HBM, checked against the two C oracles composed."""
     from duet_amd.devmem import DeviceSvim
@@ -1156,11 +1203,28 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False):
     ok = bool(rc == 0 and ds.n_found == N and np.array_equal(got['pred'], wp) and np.array_equal(got['ps'], ws)
               and np.array_equal(got['cand_off'], cl['cand_off']) and np.array_equal(got['order'], cl['order'])
               and np.array_equal(got_async['pred'], wp) and np.array_equal(got_async['ps'], ws))
+    if tailed is not None:
+        # step E/F ALONE on exactly the candidates stage A0 found (sizes with a tail: a real caller's shape; the bench's own E/F
+        # problems have sizes U{2..18}) -- the honest figure for ef_classify beside the uniform-size roofline points
+        from duet_amd.devmem import DeviceProblem
+        deg = np.diff(ref.cand_off.astype(np.int64))
+        pad = (-len(deg)) % 64
+        mx = np.concatenate([deg, np.zeros(pad, dtype=deg.dtype)]).reshape(-1, 64).max(axis=1)
+        del ds
+        torch.cuda.empty_cache()
+        t = ef_point(ctx, torch, DeviceProblem, ref, 20)
+        t.update({'degree_mean': float(deg.mean()), 'degree_p99': int(np.percentile(deg, 99)), 'degree_max': int(deg.max()),
+                  'lane_efficiency': float(deg.sum() / (64.0 * mx.sum())), 'ef_classify_us': t['kernels_us']['ef_classify'],
+                  'ef_classify_GBs_algorithmic': classify_bytes(ref) / (t['kernels_us']['ef_classify'] * 1e-6) / 1e9})
+        tailed.update(t)
+        n_found = N
+    else:
+        n_found = int(ds.n_found)
     M = len(marks['pos'])
-    b_a0, b_ef = 18 * M, 12 * M + 27 * int(ds.n_found) + 8 * soa.n_reads
+    b_a0, b_ef = 18 * M, 12 * M + 27 * n_found + 8 * soa.n_reads
     gbs = (b_a0 + b_ef) / dt / 1e9
     traffic, per_kernel, tsrc = fused_traffic(M)
-    return {'marks': M, 'candidates_found': int(ds.n_found), 'phased': int((got['pred'] != 0).sum()),
+    return {'marks': M, 'candidates_found': n_found, 'phased': int((got['pred'] != 0).sum()),
             'ms_per_run': dt * 1e3, 'marks_per_s': M / dt, 'ms_per_run_with_count_returned': dt_wait * 1e3,
             'parity_vs_composed_oracles': ok,
             'roofline': {'kernels': 'duet_svim_phase_device: A0 (sort, partitions, linkage, emit) + E/F, ~25 launches',

@@ -889,7 +889,9 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
             todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 2);
             if (todo) count_runs();
         }
-        if (todo && n >= 256u && !(p.dbg & 0x40u)) {
+        // (a handful of long ascending runs -- stage A0's candidates: one run per type once the rounds above have dealt with the
+        // local disorder -- are merged by rank below, two rounds of binary searches; the hash set is for real disorder)
+        if (todo && n >= 256u && s_nruns > kFewRuns && !(p.dbg & 0x40u)) {
             // What two odd-even rounds did not fix is unsorted because of the ORDER of the candidates (stage A0 emits them by type,
             // then position; a caller's VCF may not be position-sorted), not because there are many different seeds: a contig has a few
             // hundred phase sets.  The distinct values through a hash set, then those few are ranked -- instead of ordering
@@ -1212,19 +1214,25 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
         }
         return;
     }
-    // (device-planned runs stride over the real tiles like ef_classify)
-    for (uint32_t tile = blockIdx.x; !DYN || tile * 256u < n_cands; tile += gridDim.x) {
-        const uint32_t c0 = tile * 256u;
-        const uint32_t c = c0 + tid;
-        const bool live = c < n_cands;
-        const uint8_t code = live ? p.out_pred[c] : 0;
-        const uint32_t ps_in = live ? p.out_ps[c] : 0;
+    // (device-planned runs stride over the real tiles like ef_classify; TPB > 1 only with the candidates' contig column)
+    for (uint32_t tile = blockIdx.x; !DYN || tile * (256u * (p.cand_contig ? TPB : 1)) < n_cands; tile += gridDim.x) {
         if (DYN && p.cand_contig) {
-            // device-planned run with the candidates' contig column: the tile's first and last contig from the column (they leave
-            // with the codes), then the contig's offset and seed count, then the seeds -- every thread the same (scalar) loads,
-            // not thread 0 walking them in front of a barrier
-            const uint32_t last = min(c0 + 255u, n_cands - 1);
-            const uint32_t k0 = p.cand_contig[c0], k1 = p.cand_contig[last];
+            // device-planned run with the candidates' contig column: the first and last contig of the workgroup's TPB tiles from the
+            // column (they leave with the codes), then the contig's offset and seed count, then the seeds -- every thread the same
+            // (scalar) loads, not thread 0 walking them in front of a barrier; with TPB > 1 (large inputs) those round trips and the
+            // seeds' way into LDS are paid once per 256 x TPB candidates, as in the host-planned variant above
+            const uint32_t g0 = tile * (256u * TPB);
+            if (g0 >= n_cands) break;
+            uint8_t codes[TPB];
+            uint32_t pss[TPB];
+#pragma unroll
+            for (int r = 0; r < TPB; ++r) {
+                const uint32_t cc = g0 + 256u * r + tid;
+                codes[r] = cc < n_cands ? p.out_pred[cc] : 0;
+                pss[r] = cc < n_cands ? p.out_ps[cc] : 0;
+            }
+            const uint32_t last = min(g0 + 256u * TPB - 1u, n_cands - 1);
+            const uint32_t k0 = p.cand_contig[g0], k1 = p.cand_contig[last];
             uint32_t any = 0;
             for (uint32_t k = k0; k <= k1; ++k) any |= (p.n_one[k] == 0) ? 1u : 0u;
             const uint32_t n0 = p.n_one[k0], base = p.ctg_off[k0] + k0 + 1;
@@ -1232,10 +1240,19 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
             if (lds_mode)
                 for (uint32_t i = tid; i < n0; i += 256u) s_one[i] = p.onebuf[base + i];
             __syncthreads();
-            if (live) finalize_candidate(p, c, code, ps_in, k0, lds_mode, s_one, n0, any);
+#pragma unroll
+            for (int r = 0; r < TPB; ++r) {
+                const uint32_t cc = g0 + 256u * r + tid;
+                if (cc < n_cands) finalize_candidate(p, cc, codes[r], pss[r], k0, lds_mode, s_one, n0, any);
+            }
             __syncthreads();                                   // s_one is reused
             continue;
         }
+        const uint32_t c0 = tile * 256u;
+        const uint32_t c = c0 + tid;
+        const bool live = c < n_cands;
+        const uint8_t code = live ? p.out_pred[c] : 0;
+        const uint32_t ps_in = live ? p.out_ps[c] : 0;
         if (tid == 0) {
             const uint32_t last = min(c0 + 255u, n_cands - 1);
             // (a device-planned run with the candidates' contig column reads the tile's contig there: no table of the tiles' contigs)
@@ -1686,7 +1703,11 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     else
         hipLaunchKernelGGL((ef_classify<false, true>), dim3(G), dim3(kCandPerBlock), 0, stream, p);
     hipLaunchKernelGGL(ef_seed_sort, dim3(K), dim3(kSortThreads), 0, stream, p);
-    hipLaunchKernelGGL(ef_finalize<true>, dim3(G), dim3(256), 0, stream, p);
+    // (two tiles per workgroup where the bound says millions of candidates: the per-workgroup round trips once per 512)
+    if (d_cand_contig && (C >= 8000000u || (ctx->dbg & DUET_DBG_EF_FIN_TPB2)))
+        hipLaunchKernelGGL((ef_finalize<true, 2>), dim3(G), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(ef_finalize<true>, dim3(G), dim3(256), 0, stream, p);
     HIP_TRY(ctx, hipGetLastError());
     ctx->pending_check = true;
     return DUET_OK;

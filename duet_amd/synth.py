@@ -172,11 +172,13 @@ def pack_tags(hap, pc, ps):
 # ------------------------------------------------------------------------------------------
 
 def bench_contig(label, n_reads, n_cands, seed, spelled=None, length=None, deg_lo=2, deg_hi=18,
-                 ps_block=500000, window=24):
+                 ps_block=500000, window=24, literal_8d=False):
     """One contig of the section-8d workload: reads U[1,L), 80 % tagged, hap U{1,2},
     pc 97 % exp-like(mean ~600) / 3 % U[8101,20000], ps = floor(pos/ps_block)*ps_block+17;
     candidates at sorted positions, degree U{deg_lo..deg_hi}, marks drawn with replacement from the
-    `window` reads nearest in position, 5 % of marks replaced by names that have no SAM line."""
+    `window` reads nearest in position, 5 % of marks replaced by names that have no SAM line.
+    literal_8d: SURVEY.md section 8d to the letter where the default departs from it -- pc = floor(Exp(mean 600)) (the default:
+    geometric(1/2) * 400 + U[0, 400), capped at 8100) and 20 % of the marks' names absent (the default: 5 %)."""
     rng = SplitMix(seed)
     length = HG19_LENGTHS.get(label, 100000000) if length is None else length
     c = SynthContig(label, spelled or ('chr' + label), length)
@@ -187,6 +189,9 @@ def bench_contig(label, n_reads, n_cands, seed, spelled=None, length=None, deg_l
     c.line_tagged = rng.chance(R, 4, 5)
     c.line_hap = rng.between(R, 1, 2)
     pc = _expish(rng, R, 400)
+    if literal_8d:
+        u = (rng.below(R, 1 << 52).astype(np.float64) + 0.5) / float(1 << 52)
+        pc = np.floor(-600.0 * np.log(u)).astype(np.int64)
     hi = rng.chance(R, 3, 100)
     pc = np.where(hi, rng.between(R, 8101, 20000), np.minimum(pc, 8100))
     c.line_pc = pc
@@ -201,7 +206,7 @@ def bench_contig(label, n_reads, n_cands, seed, spelled=None, length=None, deg_l
     w = min(window, R)
     start = np.clip(i0 - w // 2, 0, R - w)
     mark = np.repeat(start, deg) + rng.below(M, w)
-    foreign = rng.chance(M, 1, 20)
+    foreign = rng.chance(M, 1, 5 if literal_8d else 20)
     mark = np.where(foreign, R + rng.below(M, 1 << 20), mark)
     c.cand_pos = cpos
     tsel = rng.below(C, 100)

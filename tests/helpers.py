@@ -33,6 +33,8 @@ def case_contigs(kind, seed):
         return [synth.bench_contig('21', 1500, 1500, seed, deg_lo=2, deg_hi=14)]
     if kind == 'config2':
         return [synth.bench_contig('1', 200000, 100000, seed)]
+    if kind == 'config2_8d':            # SURVEY 8d's config-2 generator to the letter (20 % absent names, exponential PC)
+        return [synth.bench_contig('1', 200000, 100000, seed, literal_8d=True)]
     if kind == 'genome_small':
         return synth.bench_genome(200000, seed)
     raise ValueError(kind)

@@ -83,3 +83,29 @@ def test_direct_soa_matches_text_path(tmp_path):
     assert rc == 0
     assert soa_direct.n_cands == soa_text.n_cands and soa_direct.n_marks == soa_text.n_marks
     assert np.array_equal(pred_d, pred_t) and np.array_equal(ps_d, ps_t)
+
+
+def test_config2_on_the_literal_8d_generator(tmp_path):
+    """BASELINE configs[1] on SURVEY 8d's generator to the letter (20 % of the marks' names absent, pc = floor(Exp(600))):
+    tests/golden/seeded_r5.json holds the unmodified reference's sha256 for it (make_golden_r5.py).  The regenerated inputs
+    hash the same, and the C oracle's per-candidate results through the host formatter give the reference's bytes."""
+    import json
+    with open(os.path.join(H.GOLDEN, 'seeded_r5.json')) as f:
+        p = json.load(f)[0]
+    home = str(tmp_path / 'config2_8d')
+    contigs = H.build_case(home, p['kind'], p['seed'], p['dialect'], write_sam=False)
+    assert int(contigs[0].cand_off[-1]) == p['marks']
+    from duet_amd import engine
+    soa = engine.soa_from_synth(contigs)
+    tagged = soa.read_tag != np.uint64(0xFFFFFFFFFFFFFFFF)
+    absent = (soa.mark_read == engine.MARK_ABSENT).mean()
+    # 20 % of the names have no SAM line at all, and a fifth of the others belong to reads without tags (the default generator:
+    # 5 % + a fifth of the rest = 24 % -- which is the other way to read 8d's "20 % of names absent from the tagged subset")
+    assert 0.35 < absent < 0.37
+    pc = ((soa.read_tag[tagged] >> np.uint64(32)) & np.uint64(0x3FFFFFFF)).astype(np.int64)
+    low = pc[pc <= 8100]
+    assert 560 < low.mean() < 640 and (pc > 8100).mean() > 0.02
+    got, soa2, _, _ = host_path_with_checker(home, p['svlen_thres'], p['suppread_thres'])
+    assert soa2.n_marks == p['marks']
+    assert sum(1 for l in got.splitlines() if not l.startswith('#')) == p['rows']
+    assert H.sha256_bytes(got.encode()) == p['output_sha256']

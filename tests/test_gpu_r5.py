@@ -146,3 +146,20 @@ def test_svim_host_entry_refuses_contig_ids_beyond_the_depth_description():
         assert np.array_equal(again['pred'], good['pred']) and np.array_equal(again['ps'], good['ps'])
     finally:
         ctx.close()
+
+
+def test_config2_on_the_literal_8d_generator_text_sha(tmp_path):
+    """BASELINE configs[1] on SURVEY 8d's generator to the letter (20 % of the marks' names absent, pc = floor(Exp(600)):
+    duet_amd.synth.bench_contig(literal_8d=True)) through the whole product path -- native ingest and Python host path, the HIP
+    kernels, the rows on the device -- byte-identical to the unmodified reference's phased_sv.vcf (tests/golden/seeded_r5.json
+    from make_golden_r5.py).  bench.py's extra.config2_literal_8d_generator times the same problem."""
+    import json
+    from tests import helpers as H
+    from tests.test_gpu_parity import run_product
+    with open(os.path.join(H.GOLDEN, 'seeded_r5.json')) as f:
+        p = json.load(f)[0]
+    home = str(tmp_path / 'config2_8d')
+    H.build_case(home, p['kind'], p['seed'], p['dialect'], write_sam=False)
+    got = run_product(home, p['svlen_thres'], p['suppread_thres'])
+    assert sum(1 for l in got.splitlines() if not l.startswith('#')) == p['rows']
+    assert H.sha256_bytes(got.encode()) == p['output_sha256']
