@@ -194,7 +194,7 @@ struct CandState {
 // thread walks marks [lo, hi) of its candidate; tags of mark m sit at s_tag[m - cs].
 // An absent mark is the all-ones word: its "ps" is kEmpty and its "pc" 2^30-1, so it is neither a new PS nor a voter
 // without a separate test.
-__device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs)
+__device__ __forceinline__ void consume_range_r4(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs)
 {
     for (uint32_t m = lo; m < hi; ++m) {
         const uint64_t tag = s_tag[m - cs];
@@ -218,6 +218,59 @@ __device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_t
         st.tb1 += (in_b && is1) ? pc : 0u; st.tb2 += (in_b && is2) ? pc : 0u;
     }
     st.TA1 += st.ta1; st.TA2 += st.ta2; st.ta1 = 0; st.ta2 = 0;
+}
+
+// The same walk with a shorter body (round 5; the counters put the vector units at 80 % busy and the walk at 18 x 35 of a wave's 1,012
+// vector instructions, and every restructuring with control flow in it lost -- so: the same straight line, fewer instructions).
+//   * haplotype 1 / 2 as ONE signed compare each on the tag's upper word (hap | pc): hap 1 <=> (int)w >= 0x40000000,
+//     hap 2 <=> (int)w < -0x40000000 -- no shift;
+//   * "one phase set or several" from a running minimum and maximum of the tagged marks' PS (an absent mark's PS is all ones: the
+//     minimum ignores it, and the maximum runs over PS + 1, where it is zero) instead of first-PS bookkeeping: three instructions for four;
+//   * every hap count rides in the top byte of its PC sum: a lane walks at most 255 marks per call (longer candidates are the
+//     wavefront's), a PC that counts is at most 8100, so count < 2^8 and sum < 2^21 share a word and ONE select + ONE add replace an
+//     add-with-carry, a select and an add -- four times;
+//   * the marks are walked by LDS address, not by index + address.
+// Exact: the same integers come out (tests force this walk, round 4's, and the wavefront's on every candidate).
+__device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs)
+{
+    uint32_t mn = st.first_ps;                                     // min over the tagged marks' PS (kEmpty: none yet)
+    uint32_t mx = st.first_ps == kEmpty ? 0u : st.first_ps + 1u;   // max over PS + 1
+    uint32_t pa1 = 0, pa2 = 0, pb1 = 0, pb2 = 0;                   // count << 24 | PC sum
+    bool has_a = st.ps_a != kEmpty, has_b = st.ps_b != kEmpty;     // (lane masks on the scalar unit: "group A / B has its PS")
+    uint32_t nv = 0, nb = 0;
+    // (a candidate that lies in front of or behind this pass has lo >= hi: an empty range, not a wrapped one)
+    const uint64_t *q = s_tag + (lo < hi ? lo - cs : 0u), *qe = q + (lo < hi ? hi - lo : 0u);
+    for (; q < qe; ++q) {
+        const uint64_t tag = *q;
+        const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
+        const uint32_t pc = w & 0x3FFFFFFFu;
+        const bool voter = pc <= kPcMax;
+        const bool is1 = (int32_t)w >= 0x40000000, is2 = (int32_t)w < -0x40000000;
+        mn = min(mn, ps);
+        mx = max(mx, ps + 1u);
+        nv += voter;
+        st.ps_a = (voter && !has_a) ? ps : st.ps_a;
+        has_a = has_a || voter;
+        const bool in_a = voter && ps == st.ps_a;
+        const bool rest = voter != in_a;                           // (in_a implies voter: the voters outside A)
+        st.ps_b = (rest && !has_b) ? ps : st.ps_b;
+        has_b = has_b || rest;
+        const bool in_b = rest && ps == st.ps_b;
+        st.more = st.more || (rest != in_b);                       // (in_b implies rest: a voter outside A and B)
+        nb += in_b;
+        const uint32_t pcx = pc | (1u << 24);
+        pa1 += (in_a && is1) ? pcx : 0u; pa2 += (in_a && is2) ? pcx : 0u;
+        pb1 += (in_b && is1) ? pcx : 0u; pb2 += (in_b && is2) ? pcx : 0u;
+    }
+    st.multi = st.multi || (mn != kEmpty && mn + 1u != mx);
+    st.first_ps = mn;                                              // (any tagged mark's PS serves while there is one phase set)
+    // group A's voters are not counted per mark: they are the voters that are not B's -- unless a third group exists, and then
+    // nobody reads n_a (decide_store: such a candidate gets no summary; classes 0 and 1 never look at it) beyond "is it zero"
+    st.nv += nv; st.n_b += nb;
+    st.n_a = st.more ? (has_a ? 1u : 0u) : st.nv - st.n_b;
+    st.a1 += pa1 >> 24; st.a2 += pa2 >> 24; st.b1 += pb1 >> 24; st.b2 += pb2 >> 24;
+    st.TA1 += pa1 & 0xFFFFFFu; st.TA2 += pa2 & 0xFFFFFFu;
+    st.tb1 += pb1 & 0xFFFFFFu; st.tb2 += pb2 & 0xFFFFFFu;
 }
 
 // Sum of one value per lane over the wavefront (row rotations, then the two row broadcasts of gfx9: six adds with a DPP operand,
@@ -549,9 +602,10 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
             if (!kept || (p.dbg & 4)) lo = hi;
             // candidates with more marks than heavy_t: the wavefront walks them together, 64 marks per step, after the lanes
             // have walked the others side by side
-            const bool heavy = lo < hi && my_e - my_b > p.heavy_t;
+            const bool heavy = lo < hi && my_e - my_b > min(p.heavy_t, 255u);      // (the lane walk packs counts into bytes)
             unsigned long long hm = __ballot(heavy);
-            consume_range(st, s_tag, heavy ? hi : lo, hi, cs);
+            if (p.dbg & DUET_DBG_EF_WALK_R4) consume_range_r4(st, s_tag, heavy ? hi : lo, hi, cs);
+            else consume_range(st, s_tag, heavy ? hi : lo, hi, cs);
             while (hm) {
                 const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)__ffsll((long long)hm) - 1u));
                 hm &= hm - 1ull;

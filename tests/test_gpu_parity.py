@@ -169,7 +169,7 @@ def test_two_ps_everywhere_summary_pool(ctx):
         check_against_c_oracle(ctx, soa, 0, 0)
 
 
-HEAVY_ALL, HEAVY_OFF = 0x80000, 0x100000     # include/duet_ef.h: DUET_DBG_EF_HEAVY_ALL / _OFF
+HEAVY_ALL, HEAVY_OFF, WALK_R4 = 0x80000, 0x100000, 0x200000     # include/duet_ef.h: DUET_DBG_EF_HEAVY_ALL / _OFF / _WALK_R4
 
 
 @pytest.mark.parametrize('case', ['fuzz', 'multi_ps', 'two_ps_pool', 'tail', 'cross_chunk', 'config2'])
@@ -203,7 +203,7 @@ def test_wave_cooperative_walk_and_lane_walk_agree(ctx, case):
     else:
         soas = [engine.soa_from_synth(H.case_contigs('config2', 1))]
     for soa in soas:
-        for dbg in (HEAVY_ALL, HEAVY_OFF, 0):
+        for dbg in (HEAVY_ALL, HEAVY_OFF, 0, WALK_R4, WALK_R4 | HEAVY_OFF):
             ctx.set_debug(dbg)
             try:
                 check_against_c_oracle(ctx, soa)
