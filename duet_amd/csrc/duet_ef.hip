@@ -231,43 +231,68 @@ __device__ __forceinline__ void consume_range_r4(CandState &st, const uint64_t *
 //     add-with-carry, a select and an add -- four times;
 //   * the marks are walked by LDS address, not by index + address.
 // Exact: the same integers come out (tests force this walk, round 4's, and the wavefront's on every candidate).
+// (the three vector instructions the walk is made of besides compares, min / max and adds -- spelled out, with the predicate as the
+// lane mask it is: written in C++ the compiler issues a second compare for every negated predicate and a select + add for every
+// "counter += predicate")
+__device__ __forceinline__ uint32_t sel0(unsigned long long mask, uint32_t v)                  // mask ? v : 0
+{
+    uint32_t d;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(d) : "v"(v), "s"(mask));
+    return d;
+}
+__device__ __forceinline__ uint32_t selv(unsigned long long mask, uint32_t a, uint32_t b)      // mask ? b : a
+{
+    uint32_t d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask));
+    return d;
+}
+__device__ __forceinline__ uint32_t inc(uint32_t x, unsigned long long mask)                   // x + (this lane's bit of mask)
+{
+    uint32_t d;
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(d) : "v"(x), "s"(mask) : "vcc");
+    return d;
+}
+
 __device__ __forceinline__ void consume_range(CandState &st, const uint64_t *s_tag, uint32_t lo, uint32_t hi, uint32_t cs)
 {
     uint32_t mn = st.first_ps;                                     // min over the tagged marks' PS (kEmpty: none yet)
     uint32_t mx = st.first_ps == kEmpty ? 0u : st.first_ps + 1u;   // max over PS + 1
     uint32_t pa1 = 0, pa2 = 0, pb1 = 0, pb2 = 0;                   // count << 24 | PC sum
-    bool has_a = st.ps_a != kEmpty, has_b = st.ps_b != kEmpty;     // (lane masks on the scalar unit: "group A / B has its PS")
-    uint32_t nv = 0, nb = 0;
+    // per-lane flags as the lane masks they are (scalar registers): group A / B has its PS; a voter outside both was seen
+    unsigned long long has_a = __ballot(st.ps_a != kEmpty), has_b = __ballot(st.ps_b != kEmpty), more = 0;
+    uint32_t nv = 0, nb = 0, ps_a = st.ps_a, ps_b = st.ps_b;
     // (a candidate that lies in front of or behind this pass has lo >= hi: an empty range, not a wrapped one)
     const uint64_t *q = s_tag + (lo < hi ? lo - cs : 0u), *qe = q + (lo < hi ? hi - lo : 0u);
     for (; q < qe; ++q) {
         const uint64_t tag = *q;
         const uint32_t ps = (uint32_t)tag, w = (uint32_t)(tag >> 32);
         const uint32_t pc = w & 0x3FFFFFFFu;
-        const bool voter = pc <= kPcMax;
-        const bool is1 = (int32_t)w >= 0x40000000, is2 = (int32_t)w < -0x40000000;
+        const unsigned long long vm = __ballot(pc <= kPcMax);                                  // voters
+        const unsigned long long m1 = __ballot((int32_t)w >= 0x40000000), m2 = __ballot((int32_t)w < -0x40000000);
         mn = min(mn, ps);
         mx = max(mx, ps + 1u);
-        nv += voter;
-        st.ps_a = (voter && !has_a) ? ps : st.ps_a;
-        has_a = has_a || voter;
-        const bool in_a = voter && ps == st.ps_a;
-        const bool rest = voter != in_a;                           // (in_a implies voter: the voters outside A)
-        st.ps_b = (rest && !has_b) ? ps : st.ps_b;
-        has_b = has_b || rest;
-        const bool in_b = rest && ps == st.ps_b;
-        st.more = st.more || (rest != in_b);                       // (in_b implies rest: a voter outside A and B)
-        nb += in_b;
+        nv = inc(nv, vm);
+        ps_a = selv(vm & ~has_a, ps_a, ps);
+        has_a |= vm;
+        const unsigned long long ina = vm & __ballot(ps == ps_a), rest = vm ^ ina;             // (ina is part of vm)
+        ps_b = selv(rest & ~has_b, ps_b, ps);
+        has_b |= rest;
+        const unsigned long long inb = rest & __ballot(ps == ps_b);
+        more |= rest ^ inb;                                                                    // (inb is part of rest)
+        nb = inc(nb, inb);
         const uint32_t pcx = pc | (1u << 24);
-        pa1 += (in_a && is1) ? pcx : 0u; pa2 += (in_a && is2) ? pcx : 0u;
-        pb1 += (in_b && is1) ? pcx : 0u; pb2 += (in_b && is2) ? pcx : 0u;
+        pa1 += sel0(ina & m1, pcx); pa2 += sel0(ina & m2, pcx);
+        pb1 += sel0(inb & m1, pcx); pb2 += sel0(inb & m2, pcx);
     }
+    const uint32_t lane = threadIdx.x & 63u;
+    st.ps_a = ps_a; st.ps_b = ps_b;
+    st.more = st.more || ((more >> lane) & 1ull) != 0ull;
     st.multi = st.multi || (mn != kEmpty && mn + 1u != mx);
     st.first_ps = mn;                                              // (any tagged mark's PS serves while there is one phase set)
     // group A's voters are not counted per mark: they are the voters that are not B's -- unless a third group exists, and then
-    // nobody reads n_a (decide_store: such a candidate gets no summary; classes 0 and 1 never look at it) beyond "is it zero"
+    // nobody reads n_a (decide_store: such a candidate gets no summary; classes 0 and 1 never look at it)
     st.nv += nv; st.n_b += nb;
-    st.n_a = st.more ? (has_a ? 1u : 0u) : st.nv - st.n_b;
+    st.n_a = st.more ? (st.ps_a != kEmpty ? 1u : 0u) : st.nv - st.n_b;
     st.a1 += pa1 >> 24; st.a2 += pa2 >> 24; st.b1 += pb1 >> 24; st.b2 += pb2 >> 24;
     st.TA1 += pa1 & 0xFFFFFFu; st.TA2 += pa2 & 0xFFFFFFu;
     st.tb1 += pb1 & 0xFFFFFFu; st.tb2 += pb2 & 0xFFFFFFu;
