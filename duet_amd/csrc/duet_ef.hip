@@ -139,6 +139,8 @@ __device__ __forceinline__ uint32_t find_contig(const uint32_t *__restrict__ ctg
 
 struct Params {
     uint32_t K, C, M;
+    uint32_t n_reads;                 // entries of read_tag (an index at or beyond it: the mark has no tag)
+    const uint64_t *untagged;         // the context's all-ones word (what such a mark gathers instead)
     const uint64_t *read_tag;
     const uint32_t *cand_pos, *cand_svlen, *cand_svread, *cand_refread;
     const uint8_t *cand_gt_ok;
@@ -506,36 +508,33 @@ __device__ __forceinline__ void stage_load_marks(const Params &p, uint4 (&r)[kSt
     }
 }
 
-// Tag gathers, branch-free for the same reason: absent / out-of-range marks read entry 0 (the host makes sure
-// read_tag always points at >= 1 readable word) and `valid` remembers which of the 16 are real; stage_store
-// substitutes the "untagged" word when the values are finally consumed.
-__device__ __forceinline__ void stage_gather(const Params &p, uint64_t (&t)[4 * kStageIt], uint32_t &valid, const uint4 (&r)[kStageIt],
-                                             uint32_t cs, uint32_t m_end, uint32_t tid)
+// Tag gathers, branch-free for the same reason -- and with nothing left to do once the tags arrive: a mark without a tag (an absent
+// name: index all ones) gathers the context's own "untagged" word instead of a table entry, by ADDRESS (one compare of the index
+// with the table's size, the address, two selects), so that what comes back goes to LDS as it is.  (Round 4 gathered entry 0 for such
+// marks, kept twelve validity bits packed in a word and unpacked them again for a select per tag half: 8.5 vector instructions per
+// mark where this takes 4 -- the counters put this kernel at 80 % vector issue.)  The compare also covers the indices a 16-byte load
+// picks up behind the last mark of the array (anything below the table's size is a harmless gather into an LDS slot nobody reads).
+__device__ __forceinline__ void stage_gather(const Params &p, uint64_t (&t)[4 * kStageIt], const uint4 (&r)[kStageIt])
 {
-    valid = 0;
 #pragma unroll
     for (int it = 0; it < kStageIt; ++it) {
-        const uint32_t m = cs + 4u * (tid + it * kCandPerBlock);
-        const bool in = m < m_end;
         const uint32_t idx[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool ok = in && m + j < p.M && idx[j] != kEmpty;
-            valid |= ok ? (1u << (4 * it + j)) : 0u;
-            t[4 * it + j] = p.read_tag[ok ? idx[j] : 0u];
+            const uint64_t *a = idx[j] < p.n_reads ? p.read_tag + idx[j] : p.untagged;
+            t[4 * it + j] = *a;
         }
     }
 }
 
-__device__ __forceinline__ void stage_store(uint64_t *s_tag, const uint64_t (&t)[4 * kStageIt], uint32_t valid, uint32_t cs,
-                                            uint32_t m_end, uint32_t tid)
+__device__ __forceinline__ void stage_store(uint64_t *s_tag, const uint64_t (&t)[4 * kStageIt], uint32_t cs, uint32_t m_end, uint32_t tid)
 {
 #pragma unroll
     for (int it = 0; it < kStageIt; ++it) {
         const uint32_t i = 4u * (tid + it * kCandPerBlock);
         if (cs + i < m_end) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_tag[i + j] = ((valid >> (4 * it + j)) & 1u) ? t[4 * it + j] : kUntagged;
+            for (int j = 0; j < 4; ++j) s_tag[i + j] = t[4 * it + j];
         }
     }
 }
@@ -609,10 +608,9 @@ __global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
             if (VEC) {
                 uint4 r[kStageIt];
                 uint64_t t[4 * kStageIt];
-                uint32_t valid;
                 stage_load_marks(p, r, cs, m_end, tid);
-                stage_gather(p, t, valid, r, cs, m_end, tid);
-                stage_store(s_tag, t, valid, cs, m_end, tid);
+                stage_gather(p, t, r);
+                stage_store(s_tag, t, cs, m_end, tid);
             } else {
                 for (uint32_t i = tid; i < kChunk && cs + i < m_end; i += kCandPerBlock) {
                     const uint32_t r = p.mark_read[cs + i];
@@ -1555,6 +1553,8 @@ duet_ctx *duet_ctx_create(int device_id)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->plan_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->rx_dtot, 8 * 2048 * sizeof(uint32_t));        // kDtotCopies x 256 (key sort) / x 2048 (record sort)
     if (e == hipSuccess) e = hipMemset(ctx->rx_dtot, 0, 8 * 2048 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_untagged, 64);
+    if (e == hipSuccess) e = hipMemset(ctx->d_untagged, 0xFF, 64);                                  // the tag word of a mark without a tag
     if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         duet_g_last_error = std::string("context resources: ") + hipGetErrorString(e);
         duet_ctx_destroy(ctx);                               // releases whatever was created
@@ -1584,6 +1584,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     if (ctx->eval_ws.ptr) (void)hipFree(ctx->eval_ws.ptr);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->rx_dtot) (void)hipFree(ctx->rx_dtot);
+    if (ctx->d_untagged) (void)hipFree(ctx->d_untagged);
     for (int i = 0; i < 3; ++i) {
         if (ctx->cl_side[i]) (void)hipStreamDestroy(ctx->cl_side[i]);
         if (ctx->cl_join[i]) (void)hipEventDestroy(ctx->cl_join[i]);
@@ -1636,6 +1637,7 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     memset(&p, 0, sizeof(p));
     p.K = pr->n_contigs; p.C = pr->n_cands; p.M = pr->n_marks;
     p.read_tag = pr->n_reads ? pr->read_tag : (const uint64_t *)ctx->d_n_one;   // always >= 1 readable word
+    p.n_reads = pr->n_reads; p.untagged = ctx->d_untagged;
     p.cand_pos = pr->cand_pos; p.cand_svlen = pr->cand_svlen; p.cand_svread = pr->cand_svread;
     p.cand_refread = pr->cand_refread; p.cand_gt_ok = pr->cand_gt_ok;
     p.cand_off = pr->cand_off; p.mark_read = pr->mark_read;
@@ -1759,6 +1761,7 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
     p.dyn_c = d_n_cands;
     p.cand_contig = d_cand_contig;
     p.read_tag = pr->n_reads ? pr->read_tag : (const uint64_t *)ctx->d_n_one;
+    p.n_reads = pr->n_reads; p.untagged = ctx->d_untagged;
     p.cand_pos = pr->cand_pos; p.cand_svlen = pr->cand_svlen; p.cand_svread = pr->cand_svread;
     p.cand_refread = pr->cand_refread; p.cand_gt_ok = pr->cand_gt_ok;
     p.cand_off = pr->cand_off; p.mark_read = pr->mark_read;

@@ -24,6 +24,7 @@ struct duet_ctx {
     uint32_t ef_heavy_t = 32;              // ef_classify: candidates with more marks take the wave-cooperative walk (DUET_EF_HEAVY_T overrides)
     unsigned long long *d_stamps = nullptr;
     hipStream_t own_stream = nullptr;
+    uint64_t *d_untagged = nullptr;                           // one all-ones word: what ef_classify gathers for a mark without a tag
     uint32_t *rx_dtot = nullptr;                              // [256] digit totals of a radix pass (zero between passes)
     // E/F plan (workspace keyed by the contig layout)
     std::vector<uint32_t> plan_off;        // cached cand_ctg_off
