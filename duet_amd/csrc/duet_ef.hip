@@ -126,6 +126,65 @@ __device__ int decide(int cls, const Vote &v, uint32_t deg, uint32_t svread, uin
     return pred;
 }
 
+// The same decision for classes 0 and 1 WITHOUT the four binary64 divisions (round 5: they were 80 of the 151 vector instructions of
+// the decision, a fifth of what a wave of ef_classify issues) -- in integers, wherever integers provably give what the binary64
+// expressions of :112-183 give; `need_fp` says where they do not, and the caller then takes decide() for that candidate.
+//   * sv_ratio = fl(s / (s + r)) against 0.24, 0.9, 0.3, 0.45, 0.75 (and == 1): s, r < 2^32.  For a decimal c = p / q (q <= 25) and
+//     its nearest double c_d:  s / (s + r) != c  =>  |s / (s + r) - c| >= 1 / (q (s + r)) > 4e-12, five orders of magnitude beyond
+//     |c_d - c| + the quotient's rounding (< 3e-16): the same side.  s / (s + r) == c  =>  the correctly rounded quotient IS c_d (the
+//     literal's value is RN(c) by definition): "<=" holds, as s q <= p (s + r) says.  Exact, always.  == 1.0 <=> r == 0.
+//   * hapX_avgsc = fl(tX / hapX), diff = |a2 - a1| <= 2400.  One haplotype without votes: diff is ONE rounded quotient, rounding is
+//     monotone and 2400 a double: fl(t / h) <= 2400 <=> t <= 2400 h.  Exact.  Both with votes: N = t2 h1 - t1 h2, B = 2400 h1 h2;
+//     |N| != B  =>  ||a2 - a1| - 2400| >= 1 / (h1 h2) >= 2^-32 for h < 2^16, against < 2e-12 of accumulated rounding (quotients
+//     <= 8100): the same side.  |N| == B with both sums positive, or numbers beyond 2^31 / 2^16: need_fp.
+//   * totsc_ratio = fl(hi / lo) <= 9.72 = 243 / 25, lo > 0: 25 hi != 243 lo => |hi / lo - 9.72| >= 1 / (25 lo) > 2e-9 for lo < 2^24,
+//     against ~1e-15: the same side; 25 hi == 243 lo => the quotient rounds to RN(9.72): "<=" holds.  lo >= 2^24: need_fp.
+//   * hap1_avgsc > 0 <=> hap1 > 0 and t1 > 0.
+// tests: the 38 known answers of SURVEY 8c and the 20,000 boundary-biased random vectors (tests/golden/kat_*), which sit on exactly
+// these thresholds, through the device (tests/test_gpu_parity.py::test_decision_known_answers_on_the_device) -- and every golden / fuzz case.
+__device__ __forceinline__ int decide01_int(int cls, const Vote &v, uint32_t deg, uint32_t svread, uint32_t refread, bool &need_fp)
+{
+    need_fp = false;
+    const uint64_t sr = (uint64_t)svread + (uint64_t)refread;                         // > 0: the caller has dealt with :123
+    if (cls == 0) return (refread == 0 && svread >= 4) ? 3 : 0;                       // :145-147
+    auto sv_le = [&](uint32_t pn, uint32_t qd) -> bool { return (uint64_t)svread * qd <= (uint64_t)pn * sr; };
+    const bool hp_le = deg != 0 && 4ull * v.allhap <= 3ull * deg, hp_gt = deg != 0 && !hp_le;
+    const uint64_t t1 = v.t1, t2 = v.t2;
+    const uint32_t h1 = v.hap1, h2 = v.hap2;
+    const uint64_t lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+    bool diff_le = true;                                                              // |a2 - a1| <= 2400 (:132, :161-166)
+    if (h1 != 0 && h2 != 0) {
+        if (((t1 | t2) >> 31) != 0 || ((h1 | h2) >> 16) != 0) {
+            need_fp = true;
+        } else {
+            const int64_t N = (int64_t)(t2 * h1) - (int64_t)(t1 * h2);
+            const uint64_t A = (uint64_t)(N < 0 ? -N : N), B = 2400ull * h1 * h2;
+            need_fp = A == B && t1 != 0 && t2 != 0;
+            diff_le = A <= B;
+        }
+    } else if ((h1 | h2) != 0) {
+        diff_le = (h1 != 0 ? t1 : t2) <= 2400ull * (uint64_t)(h1 | h2);
+    }
+    const bool gate = (hp_le && diff_le) || hp_gt;
+    int pred = 0;
+    if (lo == 0 && hi != 0) {                                                         // onehap_totsc != 0 (:159-167)
+        if (sv_le(6, 25)) pred = 0;
+        else if (sv_le(9, 10)) { if (gate) pred = (h1 != 0 && t1 != 0) ? 1 : 2; }
+        else { if (gate) pred = 3; }
+    } else {                                                                          // :168-182
+        bool ratio_le = true;                                                         // totsc_ratio <= 9.72 (0 when a sum is 0)
+        if (lo != 0) {
+            if ((lo >> 24) != 0) need_fp = true;
+            else ratio_le = 25ull * hi <= 243ull * lo;
+        }
+        if (sv_le(3, 10)) pred = 0;
+        else if (sv_le(9, 20)) pred = refread > 10 ? 0 : (t1 > t2 ? 1 : 2);
+        else if (sv_le(3, 4)) pred = ratio_le ? 3 : (t1 > t2 ? 1 : 2);
+        else pred = 3;
+    }
+    return pred;
+}
+
 // index k of the contig owning candidate c: last k with ctg_off[k] <= c
 __device__ __forceinline__ uint32_t find_contig(const uint32_t *__restrict__ ctg_off, uint32_t K, uint32_t c)
 {
@@ -426,7 +485,14 @@ __device__ __forceinline__ uint32_t decide_store(const Params &p, TileShared &sh
                 v.hap1 = st.a1; v.hap2 = st.a2; v.hap0 = 0;
                 v.allhap = st.a1 + st.a2;
                 v.t1 = st.TA1; v.t2 = st.TA2;
-                code = (p.dbg & 2) ? 0 : (uint8_t)decide((int)n_ps, v, deg, svread, refread);
+                // (in integers where integers provably agree with :112-183's binary64; the few candidates for which they might
+                // not -- an exact tie of two rounded quotients, sums beyond 2^31 -- take decide(): a wave without such a
+                // candidate never issues its four divisions)
+                bool need_fp = false;
+                int pred = (p.dbg & DUET_DBG_EF_FP_DECIDE) ? 0 : decide01_int((int)n_ps, v, deg, svread, refread, need_fp);
+                need_fp = need_fp || (p.dbg & DUET_DBG_EF_FP_DECIDE) != 0;
+                if (need_fp) pred = decide((int)n_ps, v, deg, svread, refread);
+                code = (p.dbg & 2) ? 0 : (uint8_t)pred;
                 ps_out = st.ps_a == kEmpty ? 0u : st.ps_a;                // class 1: the single PS = last voter's PS (:77)
                 if (n_ps == 0 || (st.a1 == 0 && st.a2 == 0)) code |= kNeedNearest;                 // :106
             }

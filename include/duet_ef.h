@@ -145,6 +145,8 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 #define DUET_DBG_EF_HEAVY_ALL 0x80000u   /* E/F: ef_classify walks EVERY kept candidate wave-cooperatively (64 marks per step; default: those with more than 32 marks) */
 #define DUET_DBG_EF_HEAVY_OFF 0x100000u  /* ... only those of more than 255 marks (the lane walk keeps its counts in bytes): every other candidate by its own lane, mark after mark */
 #define DUET_DBG_EF_WALK_R4 0x200000u    /* E/F: ef_classify's lane walk with round 4's loop body (35 vector instructions per mark) instead of round 5's shorter one */
+#define DUET_DBG_EF_FP_DECIDE 0x400000u  /* E/F: ef_classify takes every class-0 / class-1 decision through the binary64 expressions (rounds 1-4) instead of the
+                                            integer form with the binary64 fallback */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */

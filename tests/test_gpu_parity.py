@@ -169,7 +169,7 @@ def test_two_ps_everywhere_summary_pool(ctx):
         check_against_c_oracle(ctx, soa, 0, 0)
 
 
-HEAVY_ALL, HEAVY_OFF, WALK_R4 = 0x80000, 0x100000, 0x200000     # include/duet_ef.h: DUET_DBG_EF_HEAVY_ALL / _OFF / _WALK_R4
+HEAVY_ALL, HEAVY_OFF, WALK_R4, FP_DECIDE = 0x80000, 0x100000, 0x200000, 0x400000     # include/duet_ef.h: DUET_DBG_EF_HEAVY_ALL / _OFF / _WALK_R4 / _FP_DECIDE
 
 
 @pytest.mark.parametrize('case', ['fuzz', 'multi_ps', 'two_ps_pool', 'tail', 'cross_chunk', 'config2'])
@@ -203,7 +203,7 @@ def test_wave_cooperative_walk_and_lane_walk_agree(ctx, case):
     else:
         soas = [engine.soa_from_synth(H.case_contigs('config2', 1))]
     for soa in soas:
-        for dbg in (HEAVY_ALL, HEAVY_OFF, 0, WALK_R4, WALK_R4 | HEAVY_OFF):
+        for dbg in (HEAVY_ALL, HEAVY_OFF, 0, WALK_R4, WALK_R4 | HEAVY_OFF, FP_DECIDE, FP_DECIDE | WALK_R4 | HEAVY_OFF):
             ctx.set_debug(dbg)
             try:
                 check_against_c_oracle(ctx, soa)
@@ -211,6 +211,88 @@ def test_wave_cooperative_walk_and_lane_walk_agree(ctx, case):
                     check_against_c_oracle(ctx, soa, 0, 0)
             finally:
                 ctx.set_debug(0)
+
+
+def decision_boundary_soa():
+    """One contig, one phase set (every candidate class 1 or 0), candidates built ON the thresholds of predict_hp
+    (sv_phasing_fn.py:142-183) and one step to either side: sv_ratio = svread / (svread + refread) at 0.24, 0.3, 0.45, 0.75, 0.9, 1
+    (small and 32-bit-sized counts), totsc_ratio = max / min of the two PC sums at 9.72, |hap2_avgsc - hap1_avgsc| at 2400 with
+    quotients that are not exact (thirds, sevenths), hapread_ratio at 0.75, one-haplotype and two-haplotype votes, PC 0."""
+    PS = 5017
+    sv_pairs = []
+    for pn, qd in ((6, 25), (3, 10), (9, 20), (3, 4), (9, 10), (1, 1)):
+        for k in (1, 7, 1000, 40000000, 170000000):
+            s0, tot = pn * k, qd * k
+            if tot >= 2 ** 32:
+                continue
+            for ds in (-1, 0, 1):
+                s = s0 + ds
+                if 2 <= s <= tot:
+                    sv_pairs.append((s, tot - s))
+    sv_pairs += [(4, 0), (3, 0), (5, 1), (2 ** 32 - 1, 0), (2 ** 31, 2 ** 31 - 1), (11, 11), (20, 20)]
+    votes = []                                     # (pcs of hap-1 voters, pcs of hap-2 voters, untagged marks)
+    def split(t, h):
+        base = [t // h] * h
+        for i in range(t - (t // h) * h):
+            base[i] += 1
+        assert max(base) <= 8100 and sum(base) == t
+        return base
+    # totsc_ratio around 9.72 (both sums positive)
+    for k in (1, 3, 17):
+        for d in (-1, 0, 1):
+            votes.append((split(972 * k + d, max(1, k)), split(100 * k, 1), 0))
+            votes.append((split(100 * k, 1), split(972 * k + d, max(1, k)), 1))
+    # |a2 - a1| around 2400 with inexact quotients: t2 / 7 - t1 / 3 = 2400 <=> 3 t2 - 7 t1 = 50400
+    for t1 in (3000, 3001, 2999):
+        for d in (-1, 0, 1):
+            t2 = (50400 + 7 * t1) // 3 + d
+            votes.append((split(t1, 3), split(t2, 7), 0))
+            votes.append((split(t2, 7), split(t1, 3), 0))
+            votes.append((split(t1, 3), split(t2, 7), 5))          # hapread_ratio <= 0.75: the gate looks at the difference
+    # one haplotype only: the difference is one quotient, around 2400 (t = 2400 h, +- 1), with untagged marks so that hp <= 0.75
+    for h in (1, 3, 7):
+        for d in (-1, 0, 1):
+            votes.append((split(2400 * h + d, h), [], h))
+            votes.append(([], split(2400 * h + d, h), h + 1))
+            votes.append((split(2400 * h + d, h), [], 0))
+    # PC 0 votes (sums 0 with votes present), no votes at all, hapread_ratio exactly 0.75
+    votes += [([0, 0], [], 0), ([0], [0], 0), ([], [], 4), ([300, 300, 300], [], 1), ([300], [100], 2), ([8100], [8100, 8100], 0)]
+    tags, mark_read, cand_off = [], [], [0]
+    cols = dict(pos=[], svlen=[], svread=[], refread=[], gt=[])
+    pos = 1000
+    for (p1, p2, n_un) in votes:
+        for (sv, rf) in sv_pairs:
+            for pc in p1:
+                mark_read.append(len(tags)); tags.append((1, pc, PS))
+            for pc in p2:
+                mark_read.append(len(tags)); tags.append((2, pc, PS))
+            mark_read += [engine.MARK_ABSENT] * n_un
+            cand_off.append(len(mark_read))
+            cols['pos'].append(pos); pos += 3
+            cols['svlen'].append(100); cols['svread'].append(sv); cols['refread'].append(rf); cols['gt'].append(1)
+    hap = np.array([t[0] for t in tags]); pc = np.array([t[1] for t in tags]); ps = np.array([t[2] for t in tags])
+    C = len(cols['pos'])
+    return engine.EfSoA(cand_ctg_off=[0, C], read_tag=engine.pack_tags(hap, pc, ps), cand_pos=cols['pos'], cand_svlen=cols['svlen'],
+                        cand_svread=np.array(cols['svread'], dtype=np.uint64), cand_refread=np.array(cols['refread'], dtype=np.uint64),
+                        cand_gt_ok=cols['gt'], cand_off=cand_off, mark_read=np.array(mark_read, dtype=np.uint64))
+
+
+def test_decision_on_the_thresholds_integer_and_binary64(ctx):
+    """ef_classify decides classes 0 and 1 in integers wherever integers provably give what the binary64 expressions of
+    sv_phasing_fn.py:112-183 give (and falls back to those expressions for an exact tie of two rounded quotients or sums beyond
+    2^31): candidates ON every threshold and one step to either side -- sv_ratio at 0.24 / 0.3 / 0.45 / 0.75 / 0.9 / 1 with counts
+    from 6 to 4e9, totsc_ratio at 9.72, the average-score difference at 2400 with inexact quotients, one-haplotype votes -- against
+    the C oracle (binary64, pinned to the reference's known answers), with the integer form, and with DUET_DBG_EF_FP_DECIDE."""
+    soa = decision_boundary_soa()
+    assert soa.n_cands > 5000
+    rc, want_pred, _ = c_oracle.ef(soa, 50, 2)
+    assert rc == 0 and len(set(want_pred.tolist())) == 4           # every outcome occurs
+    for dbg in (0, FP_DECIDE, HEAVY_ALL, WALK_R4):
+        ctx.set_debug(dbg)
+        try:
+            check_against_c_oracle(ctx, soa, 50, 2)
+        finally:
+            ctx.set_debug(0)
 
 
 def test_long_candidates_cross_lds_chunks(ctx):
