@@ -129,57 +129,55 @@ __device__ int decide(int cls, const Vote &v, uint32_t deg, uint32_t svread, uin
 // The same decision for classes 0 and 1 WITHOUT the four binary64 divisions (round 5: they were 80 of the 151 vector instructions of
 // the decision, a fifth of what a wave of ef_classify issues) -- in integers, wherever integers provably give what the binary64
 // expressions of :112-183 give; `need_fp` says where they do not, and the caller then takes decide() for that candidate.
-//   * sv_ratio = fl(s / (s + r)) against 0.24, 0.9, 0.3, 0.45, 0.75 (and == 1): s, r < 2^32.  For a decimal c = p / q (q <= 25) and
+//   * sv_ratio = fl(s / (s + r)) against 0.24, 0.9, 0.3, 0.45, 0.75 (and == 1): s + r < 2^26 here (the argument holds up to 2^33).  For a decimal c = p / q (q <= 25) and
 //     its nearest double c_d:  s / (s + r) != c  =>  |s / (s + r) - c| >= 1 / (q (s + r)) > 4e-12, five orders of magnitude beyond
 //     |c_d - c| + the quotient's rounding (< 3e-16): the same side.  s / (s + r) == c  =>  the correctly rounded quotient IS c_d (the
 //     literal's value is RN(c) by definition): "<=" holds, as s q <= p (s + r) says.  Exact, always.  == 1.0 <=> r == 0.
 //   * hapX_avgsc = fl(tX / hapX), diff = |a2 - a1| <= 2400.  One haplotype without votes: diff is ONE rounded quotient, rounding is
 //     monotone and 2400 a double: fl(t / h) <= 2400 <=> t <= 2400 h.  Exact.  Both with votes: N = t2 h1 - t1 h2, B = 2400 h1 h2;
-//     |N| != B  =>  ||a2 - a1| - 2400| >= 1 / (h1 h2) >= 2^-32 for h < 2^16, against < 2e-12 of accumulated rounding (quotients
-//     <= 8100): the same side.  |N| == B with both sums positive, or numbers beyond 2^31 / 2^16: need_fp.
-//   * totsc_ratio = fl(hi / lo) <= 9.72 = 243 / 25, lo > 0: 25 hi != 243 lo => |hi / lo - 9.72| >= 1 / (25 lo) > 2e-9 for lo < 2^24,
-//     against ~1e-15: the same side; 25 hi == 243 lo => the quotient rounds to RN(9.72): "<=" holds.  lo >= 2^24: need_fp.
+//     |N| != B  =>  ||a2 - a1| - 2400| >= 1 / (h1 h2) >= 2^-16 for h < 2^8, against < 2e-12 of accumulated rounding (quotients
+//     <= 8100): the same side.  |N| == B with both sums positive, or numbers outside the ranges below: need_fp.
+//   * totsc_ratio = fl(hi / lo) <= 9.72 = 243 / 25, lo > 0: 25 hi != 243 lo => |hi / lo - 9.72| >= 1 / (25 lo) > 1e-8 for lo < 2^21,
+//     against ~1e-15: the same side; 25 hi == 243 lo => the quotient rounds to RN(9.72): "<=" holds.
 //   * hap1_avgsc > 0 <=> hap1 > 0 and t1 > 0.
 // tests: the 38 known answers of SURVEY 8c and the 20,000 boundary-biased random vectors (tests/golden/kat_*), which sit on exactly
 // these thresholds, through the device (tests/test_gpu_parity.py::test_decision_known_answers_on_the_device) -- and every golden / fuzz case.
+// (32-bit arithmetic throughout, products by 24-bit multiplies and shift-adds -- full-rate instructions; a first form with 64-bit
+// products took 23 v_mad_u64_u32, quarter rate, and cost what the four divisions did.  Hence the narrower ranges: read counts below
+// 2^26, PC sums below 2^21, haplotype votes below 2^8, degree below 2^28 -- every candidate a lane walks is inside them; outside: need_fp.)
 __device__ __forceinline__ int decide01_int(int cls, const Vote &v, uint32_t deg, uint32_t svread, uint32_t refread, bool &need_fp)
 {
-    need_fp = false;
-    const uint64_t sr = (uint64_t)svread + (uint64_t)refread;                         // > 0: the caller has dealt with :123
-    if (cls == 0) return (refread == 0 && svread >= 4) ? 3 : 0;                       // :145-147
-    auto sv_le = [&](uint32_t pn, uint32_t qd) -> bool { return (uint64_t)svread * qd <= (uint64_t)pn * sr; };
-    const bool hp_le = deg != 0 && 4ull * v.allhap <= 3ull * deg, hp_gt = deg != 0 && !hp_le;
-    const uint64_t t1 = v.t1, t2 = v.t2;
-    const uint32_t h1 = v.hap1, h2 = v.hap2;
-    const uint64_t lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+    const uint64_t sr64 = (uint64_t)svread + (uint64_t)refread;                       // > 0: the caller has dealt with :123
+    const uint32_t sr = (uint32_t)sr64, s = svread;
+    const uint32_t t1 = (uint32_t)v.t1, t2 = (uint32_t)v.t2, h1 = v.hap1, h2 = v.hap2;
+    need_fp = (sr64 >> 26) != 0 || ((v.t1 | v.t2) >> 21) != 0 || ((h1 | h2) >> 8) != 0 || (deg >> 28) != 0;
+    if (cls == 0) return (refread == 0 && svread >= 4) ? 3 : 0;                       // :145-147 (exact for any counts)
+    // sv_ratio <= p / q  <=>  s q <= p (s + r): the multiples by shift-adds (all below 2^31)
+    const uint32_t s4 = s << 2, s10 = (s << 3) + (s << 1), s20 = s10 << 1, s25 = (s << 4) + (s << 3) + s;
+    const uint32_t sr3 = (sr << 1) + sr, sr6 = sr3 << 1, sr9 = (sr << 3) + sr;
+    const bool le024 = s25 <= sr6, le09 = s10 <= sr9, le03 = s10 <= sr3, le045 = s20 <= sr9, le075 = s4 <= sr3;
+    const bool hp_le = deg != 0 && (v.allhap << 2) <= (deg << 1) + deg, hp_gt = deg != 0 && !hp_le;
+    const uint32_t lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
     bool diff_le = true;                                                              // |a2 - a1| <= 2400 (:132, :161-166)
     if (h1 != 0 && h2 != 0) {
-        if (((t1 | t2) >> 31) != 0 || ((h1 | h2) >> 16) != 0) {
-            need_fp = true;
-        } else {
-            const int64_t N = (int64_t)(t2 * h1) - (int64_t)(t1 * h2);
-            const uint64_t A = (uint64_t)(N < 0 ? -N : N), B = 2400ull * h1 * h2;
-            need_fp = A == B && t1 != 0 && t2 != 0;
-            diff_le = A <= B;
-        }
+        const int32_t N = (int32_t)__umul24(t2, h1) - (int32_t)__umul24(t1, h2);      // (t < 2^21, h < 2^8: below 2^29)
+        const uint32_t A = (uint32_t)(N < 0 ? -N : N), B = __umul24(__umul24(h1, h2), 2400u);
+        need_fp = need_fp || (A == B && t1 != 0 && t2 != 0);
+        diff_le = A <= B;
     } else if ((h1 | h2) != 0) {
-        diff_le = (h1 != 0 ? t1 : t2) <= 2400ull * (uint64_t)(h1 | h2);
+        diff_le = (h1 != 0 ? t1 : t2) <= __umul24(h1 | h2, 2400u);
     }
     const bool gate = (hp_le && diff_le) || hp_gt;
     int pred = 0;
     if (lo == 0 && hi != 0) {                                                         // onehap_totsc != 0 (:159-167)
-        if (sv_le(6, 25)) pred = 0;
-        else if (sv_le(9, 10)) { if (gate) pred = (h1 != 0 && t1 != 0) ? 1 : 2; }
+        if (le024) pred = 0;
+        else if (le09) { if (gate) pred = (h1 != 0 && t1 != 0) ? 1 : 2; }
         else { if (gate) pred = 3; }
     } else {                                                                          // :168-182
-        bool ratio_le = true;                                                         // totsc_ratio <= 9.72 (0 when a sum is 0)
-        if (lo != 0) {
-            if ((lo >> 24) != 0) need_fp = true;
-            else ratio_le = 25ull * hi <= 243ull * lo;
-        }
-        if (sv_le(3, 10)) pred = 0;
-        else if (sv_le(9, 20)) pred = refread > 10 ? 0 : (t1 > t2 ? 1 : 2);
-        else if (sv_le(3, 4)) pred = ratio_le ? 3 : (t1 > t2 ? 1 : 2);
+        const bool ratio_le = lo == 0 || __umul24(hi, 25u) <= __umul24(lo, 243u);     // totsc_ratio <= 9.72 (0 when a sum is 0)
+        if (le03) pred = 0;
+        else if (le045) pred = refread > 10 ? 0 : (t1 > t2 ? 1 : 2);
+        else if (le075) pred = ratio_le ? 3 : (t1 > t2 ? 1 : 2);
         else pred = 3;
     }
     return pred;
