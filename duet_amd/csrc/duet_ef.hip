@@ -607,8 +607,9 @@ __device__ __forceinline__ void stage_store(uint64_t *s_tag, const uint64_t (&t)
 // round trips of tile i+1 / i+2 under the LDS walk of tile i was measured at 2e7 marks and was NOT faster --
 // 80 us vs 72 us: with four workgroups per CU in different phases the staging latency is already hidden and
 // the kernel is bound by the sum of VALU issue (consume + fp64 decision) and memory time; see DESIGN.md.)
+// (six waves per SIMD: what the 26.7 KB of LDS allow -- the device-planned variant came out at 83 registers, five waves, without the bound)
 template <bool VEC, bool DYN = false>
-__global__ __launch_bounds__(kCandPerBlock) void ef_classify(const Params p)
+__global__ __launch_bounds__(kCandPerBlock, 6) void ef_classify(const Params p)
 {
     __shared__ uint64_t s_tag[kChunk];
     __shared__ uint32_t s_off[kCandPerBlock + 1];
