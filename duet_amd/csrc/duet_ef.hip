@@ -370,6 +370,40 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// the value of lane (lane ^ J): inside a row of 16 lanes as DPP operands (J = 4: the two directions by bank mask), across rows
+// through the LDS crossbar
+template <uint32_t J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
+{
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);       // quad_perm:[1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
+    else if constexpr (J == 4) {
+        const int r = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);                        // row_shl:4 into banks 0, 2
+        return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xF, 0xA, false);                          // row_shr:4 into banks 1, 3
+    } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false); // row_ror:8
+    else return (uint32_t)__shfl_xor((int)v, (int)J, 64);
+}
+
+// 64 values, one per lane, into ascending order over the lanes (bitonic network: 21 exchanges, 18 of them inside rows)
+template <uint32_t KK, uint32_t J>
+__device__ __forceinline__ uint32_t bitonic_step(uint32_t v, uint32_t lane)
+{
+    const uint32_t o = lane_xor<J>(v);
+    const bool up = KK == 64u || (lane & KK) == 0u, low = (lane & J) == 0u;
+    v = (low == up) ? min(v, o) : max(v, o);
+    if constexpr (J > 1) return bitonic_step<KK, J / 2>(v, lane);
+    else return v;
+}
+__device__ __forceinline__ uint32_t wave_sort64(uint32_t v, uint32_t lane)
+{
+    v = bitonic_step<2, 1>(v, lane);
+    v = bitonic_step<4, 2>(v, lane);
+    v = bitonic_step<8, 4>(v, lane);
+    v = bitonic_step<16, 8>(v, lane);
+    v = bitonic_step<32, 16>(v, lane);
+    return bitonic_step<64, 32>(v, lane);
+}
+
 // The wave-cooperative walk (north_star's "wavefront-reduced per-cluster haplotype vote"): the WHOLE wavefront takes marks
 // [lo, hi) of the candidate that lane `h` owns, 64 marks per step, and lane h's state advances exactly as consume_range would
 // have advanced it.  Every order rule of the serial walk is a "first lane with ..." here: the first tagged mark's PS (:191-194),
@@ -837,7 +871,7 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
 
 __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
 {
-    __shared__ uint32_t s_key[kSortLds];
+    __shared__ __align__(16) uint32_t s_key[kSortLds];
     __shared__ uint32_t s_part[kSortThreads / 64 + 1];
     __shared__ uint32_t s_unsorted;
     __shared__ uint32_t s_nruns, s_run[kMaxRuns + 1];
@@ -1027,7 +1061,9 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
                 }
             __syncthreads();
         };
-        if (todo && s_nruns > kFewRuns) {
+        // (the device-planned launch is the fused pipeline's: its candidates come by type, the rounds would be wasted -- 1.5 us)
+        const bool type_major = p.dyn_c != nullptr && !(p.dbg & 0x40u);
+        if (todo && s_nruns > kFewRuns && !type_major) {
             todo = !oddeven_rounds(s_key, n, tid, kSortThreads, &s_unsorted, 2);
             if (todo) count_runs();
         }
@@ -1055,7 +1091,7 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
             __syncthreads();
             const uint32_t u = s_ndist;
             if (s_unsorted == 0 && u <= kSeedTab / 2u) {
-                // compact the set (four slots per thread), rank the values, store them in order
+                // compact the set (four slots per thread), order the values (blocks of 64 in registers, places by lower bounds), store them
                 uint32_t mine[kSeedTab / kSortThreads], cnt = 0;
 #pragma unroll
                 for (uint32_t j = 0; j < kSeedTab / kSortThreads; ++j) {
@@ -1068,12 +1104,53 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
 #pragma unroll
                 for (uint32_t j = 0; j < kSeedTab / kSortThreads; ++j)
                     if (mine[j] != kEmpty) s_key[at++] = mine[j];
+                // The u distinct values in order.  Ranking every value against every other one is u x u compares on ONE compute
+                // unit (4.6 of this kernel's 13.9 us for 499 values, whether the columns come as LDS broadcasts -- the CU's LDS
+                // port -- or rotate through the lanes by DPP -- 2 vector instructions per compare); instead: every wavefront
+                // orders blocks of 64 values in its registers (wave_sort64: no barrier), and a value's place
+                // is the sum of its lower bounds in all blocks (its own included: the values are distinct) -- seven reads per
+                // block, four blocks side by side, the blocks of a value shared by 1024 / U threads.
+                const uint32_t U = (u + 63u) & ~63u, nblk = U >> 6, lane = tid & 63u;
+                if (tid < U - u) s_key[u + tid] = kEmpty;                     // (pads the last block: sorts behind every seed)
+                for (uint32_t i = tid; i < U; i += kSortThreads) s_tab[i] = 0u;
                 __syncthreads();
-                for (uint32_t i = tid; i < u; i += kSortThreads) {
-                    const uint32_t me = s_key[i];
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < u; ++j) rank += s_key[j] < me ? 1u : 0u;
-                    glist[rank] = me;
+                for (uint32_t b = tid >> 6; b < nblk; b += kSortThreads / 64) {
+                    s_key[b * 64u + lane] = wave_sort64(s_key[b * 64u + lane], lane);
+                }
+                __syncthreads();
+                {
+                    const uint32_t P = max(1u, (uint32_t)kSortThreads / U), per_part = (nblk + P - 1u) / P;
+                    for (uint32_t w = tid; w < U * P; w += kSortThreads) {
+                        const uint32_t part = w / U, i = w - part * U;
+                        const uint32_t b0 = min(part * per_part, nblk), b1 = min(b0 + per_part, nblk);
+                        const uint32_t me = s_key[i];
+                        uint32_t rank = 0;
+                        for (uint32_t b = b0; b < b1; b += 4u) {
+                            const uint32_t *blk[4];
+                            uint32_t pos[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                blk[t] = s_key + min(b + (uint32_t)t, b1 - 1u) * 64u;
+                                pos[t] = 0;
+                            }
+#pragma unroll
+                            for (uint32_t st = 32; st > 0; st >>= 1)
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) pos[t] += blk[t][pos[t] + st - 1u] < me ? st : 0u;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                pos[t] += blk[t][pos[t]] < me ? 1u : 0u;
+                                rank += b + (uint32_t)t < b1 ? pos[t] : 0u;
+                            }
+                        }
+                        if (P == 1u) s_tab[i] = rank;
+                        else if (rank) atomicAdd(&s_tab[i], rank);
+                    }
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < U; i += kSortThreads) {
+                    const uint32_t v = s_key[i];
+                    if (v != kEmpty) glist[s_tab[i]] = v;
                 }
                 if (tid == 0) { p.n_one[k] = u; region[0] = u; }
                 STAMP(1, 3);

@@ -126,7 +126,7 @@ def test_finalize_with_two_and_four_tiles_per_workgroup(ctx, seed):
             ctx.set_debug(0)
 
 
-@pytest.mark.parametrize('n_ps', [3, 40, 700, 1900, 2300, 6000])
+@pytest.mark.parametrize('n_ps', [3, 40, 130, 300, 500, 700, 1900, 2300, 6000])
 def test_unsorted_candidates_seed_set_paths(ctx, n_ps):
     """Candidates NOT in position order with n_ps phase sets per contig: the seed list arrives unsorted.  Few distinct seeds go
     through ef_seed_sort's hash set (up to 2048 of them), more through the run merges / the bitonic network; each case also with

@@ -63,3 +63,5 @@ for k in range(3):
         continue
     d = np.diff(rel[:, :len(names[k])], axis=1)
     print('  phase durations (median us):', ' '.join('%s=%.2f' % (names[k][i + 1], np.median(d[:, i])) for i in range(d.shape[1])))
+if st[1][1][0] > 0:                         # (a diagnostic build may leave (n << 32 | distinct) of contig 0's seed list there)
+    print('seed list of contig 0: n %d distinct %d' % (int(st[1][1][0]) >> 32, int(st[1][1][0]) & 0xFFFFFFFF))
