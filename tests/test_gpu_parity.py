@@ -145,6 +145,62 @@ def test_unsorted_candidates_seed_set_paths(ctx, n_ps):
         ctx.set_debug(0)
 
 
+def seed_list_soa(seqs):
+    """One contig per sequence; candidate i of a contig is a class-1 candidate whose two marks are one read of phase set seq[i]:
+    ef_seed_sort's list for the contig is seq with consecutive repeats dropped."""
+    tags, mark_read, cand_off, ctg_off, read_off = [], [], [0], [0], [0]
+    cols = dict(pos=[], svlen=[], svread=[], refread=[], gt=[])
+    for seq in seqs:
+        base = len(tags)
+        for i, ps in enumerate(seq):
+            tags.append((1 + i % 2, 10 + i % 50, ps))
+            mark_read += [i, i]                                # (contig-local read ids)
+            cand_off.append(len(mark_read))
+            cols['pos'].append(1000 + 7 * i); cols['svlen'].append(100); cols['svread'].append(5); cols['refread'].append(5); cols['gt'].append(1)
+        ctg_off.append(len(cols['pos'])); read_off.append(len(tags))
+    hap = np.array([t[0] for t in tags]); pc = np.array([t[1] for t in tags]); ps = np.array([t[2] for t in tags])
+    # mark_read: global read index = contig's read offset + local id
+    mr = np.array(mark_read, dtype=np.uint64)
+    co = np.array(cand_off)
+    for k in range(len(seqs)):
+        lo, hi = co[ctg_off[k]], co[ctg_off[k + 1]]
+        mr[lo:hi] += read_off[k]
+    return engine.EfSoA(cand_ctg_off=ctg_off, read_off=read_off, read_tag=engine.pack_tags(hap, pc, ps), cand_pos=cols['pos'],
+                        cand_svlen=cols['svlen'], cand_svread=cols['svread'], cand_refread=cols['refread'], cand_gt_ok=cols['gt'],
+                        cand_off=cand_off, mark_read=mr)
+
+
+def test_seed_lists_with_local_disorder(ctx):
+    """ef_seed_sort exchanges the two entries of every descent at once when each looks like one transposition, and lets
+    unique_copy check the order: lists where that is all it takes (A B A B at phase-set boundaries), lists where two exchanges two
+    places apart disturb each other (1 5 2 6 3: the check fails, the ladder runs after all -- few descents: the run merge; many:
+    the hash set), descents in a row, a descending list, and tiles of 256 candidates cut anywhere through the patterns; each also
+    with the hash set and the exchanges switched off (debug bit 0x40).  The seed arrays are np.sort(list(set(...))) of the
+    sequence."""
+    rng = np.random.default_rng(5)
+    blocks = lambda pat, reps, step: [x + step * j for j in range(reps) for x in pat]
+    seqs = [
+        blocks([10, 50], 300, 100),                                        # ascending outright
+        blocks([10, 50, 10, 50, 10, 90], 150, 100),                        # A B A B A C: one exchange each
+        blocks([10, 50, 20, 60, 30], 100, 100),                            # exchanges that disturb each other, many of them
+        [10, 50, 20, 60, 30],                                              # ... and few
+        blocks([30, 20, 10], 120, 100),                                    # descents in a row
+        list(range(5000, 0, -7)),                                          # descending
+        [7],                                                               # one seed
+        blocks([10, 50, 10], 2, 100) + list(range(1000, 4000, 3)),         # a few descents in front of a long ascending run
+        (np.sort(rng.integers(1, 1 << 30, size=3000)) + rng.integers(-2, 3, size=3000)).tolist(),     # jitter on an ascending list
+    ]
+    soa = seed_list_soa(seqs)
+    for dbg in (0, 0x40):
+        ctx.set_debug(dbg)
+        try:
+            check_against_c_oracle(ctx, soa)
+            for k, seq in enumerate(seqs):
+                assert np.array_equal(ctx.seed_ps(k), np.unique(np.array(seq, dtype=np.uint32))), (dbg, k)
+        finally:
+            ctx.set_debug(0)
+
+
 def test_multi_ps_heavy(ctx):
     """Most candidates see several phase sets (more than the 4 groups a summary holds, and more
     multi-PS candidates per workgroup than summary slots): exercises both ef_finalize paths."""
