@@ -63,7 +63,21 @@ namespace {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// Diagnostic build (-DDUET_STAMPS, tools/stamps_cl.py): a log of (tag, wall clock) per workgroup of the agglomeration kernels -- the
+// partitions are chains of dependent steps on one wavefront, and what a chain spends where does not show in a kernel trace.
+#ifdef DUET_STAMPS
+__shared__ uint32_t g_clst_area, g_clst_n;
+#define CL_STAMP_INIT(area) do { if (threadIdx.x == 0) { g_clst_area = (area); g_clst_n = 0; } } while (0)
+#define CL_STAMP(tag) do { if (threadIdx.x == 0 && p.stamps && g_clst_area) { const uint32_t n_ = g_clst_n++; \
+    if (n_ < 62u && blockIdx.x < 8192u) p.stamps[((size_t)g_clst_area * 65536 + (size_t)blockIdx.x * 8) * 8 + 2 + n_] = \
+        ((unsigned long long)(tag) << 56) | ((unsigned long long)wall_clock64() & 0x00FFFFFFFFFFFFFFull); } } while (0)
+#else
+#define CL_STAMP_INIT(area) do { } while (0)
+#define CL_STAMP(tag) do { } while (0)
+#endif
+
 struct ClParams {
+    unsigned long long *stamps;                       // (diagnostic build only, else null)
     uint32_t M;
     uint32_t part_gap, part_max;
     double max_dist, normalizer;
@@ -971,6 +985,7 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
     auto rowbase = [](uint32_t i) -> int { return (int)(__umul24(i, 2u * NMAX - i - 1u) >> 1) - (int)i - 1; };
     auto at = [&](uint32_t a, uint32_t b) -> int { return a < b ? rowbase(a) + (int)b : rowbase(b) + (int)a; };
     const uint32_t nn_ = go ? n : 0u;
+    CL_STAMP(0x20);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1021,6 +1036,7 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
         }
     }
     __syncthreads();
+    CL_STAMP(0x21);
     // state: this lane's rows' roots (every row) and, for the clusters they name, alive / size in LDS + the group's alive set
     uint32_t root[R];
     bool alive[R];
@@ -1240,7 +1256,9 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
             __syncthreads();
         }
     }
+    CL_STAMP(0x22);
     for (uint32_t round = 0; round < 2u * NMAX && p.mergeable; ++round) {
+        CL_STAMP(0x23);
         // nearest neighbour of every cluster: smallest mean, ties to the smallest index (the list is ascending).  All lanes of
         // a group walk the same list; lane `me` looks at entry {me, k}
         double bs[R], bn[R];
@@ -1295,6 +1313,7 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
         merge_round(dead, dies, bk);
     }
     // the clusters as bit sets: every row adds its bit at its root
+    CL_STAMP(0x24);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1421,6 +1440,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
     const uint32_t part = has ? list[li] : 0u;
     const uint32_t s = has ? p.part_start[part] : 0u;
     const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+    CL_STAMP(0x10);
     __syncthreads();
     uint32_t pk[R], spk[R], ek[R], ck[R], mk[R], rd[R];
     bool bad = false;
@@ -1449,6 +1469,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
         bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits: leave it to the exact path
     }
     __syncthreads();
+    CL_STAMP(0x11);
     BitSet<NW> F[R];                                     // the final cluster of each of this lane's marks
     bool solved = n < 2;
 #pragma unroll
@@ -1532,6 +1553,7 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
             for (int r = 0; r < R; ++r) F[r] = N0[r];
         }
     }
+    CL_STAMP(0x12);
     const bool wide = group_any(bad);
     const bool take = MODE == kLinkUnfit ? (wide || !p.fast) : true;
     const bool need = has && !solved && take;
@@ -1541,7 +1563,9 @@ __device__ __forceinline__ void fast_unit(const ClParams &p, const WorkList &lis
     }
     static_assert(sizeof(LinkSmem<GROUP, R, NCAP>) >= sizeof(unsigned long long) * 2 * (64 / GROUP) * NMAX, "emit_prep's sums do not fit the linkage's scratch");
     unsigned long long (*sums)[2] = reinterpret_cast<unsigned long long (*)[2]>(smem_link) + (size_t)sub * NMAX;
+    CL_STAMP(0x13);
     emit_prep<GROUP, R, NW, NMAX>(p, has && take, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], sums, mk, rd);
+    CL_STAMP(0x14);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1610,6 +1634,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
     const uint32_t part = has ? list[li] : 0u;
     const uint32_t s = has ? p.part_start[part] : 0u;
     const uint32_t n = has ? p.part_start[part + 1] - s : 0u;
+    CL_STAMP(0x30);
     __syncthreads();
     uint32_t pk[R], spk[R], ek[R], ck[R], mk[R], rd[R];
     double ik[R];
@@ -1643,6 +1668,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
         bad = bad || ek[r] < pk[r];                      // end does not fit 32 bits
     }
     __syncthreads();
+    CL_STAMP(0x31);
     const bool unfit = group_any(bad) || !p.fast;
     const bool act = has && n >= 2 && !unfit;            // (uniform within a group)
     const uint32_t na = act ? n : 0u;
@@ -1911,6 +1937,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
         }
         exact_rows(T_{}, F_{}, row, nocols);
     }
+    CL_STAMP(0x32);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         N0[r].set_if(row[r], sl + r * GROUP);
@@ -1947,6 +1974,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
     };
     bool ok0[R], open[R];
     clique_rows(N0, row, ok0);
+    CL_STAMP(0x33);
     bool any_open = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1978,9 +2006,11 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
             g2[r].set_if(open[r], sl + r * GROUP);
             if (!open[r]) { g1[r].clear(); g2[r].clear(); }
         }
+        CL_STAMP(0x34);
         bool ok1[R], ok2[R], head[R];
         clique_rows(g1, open, ok1);
         clique_rows(g2, open, ok2);
+        CL_STAMP(0x35);
         // (b): the groups, named by their smallest member
         uint32_t into[R], gsz[R];
 #pragma unroll
@@ -2012,6 +2042,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
         auto rowbase = [](uint32_t i) -> int { return (int)(__umul24(i, 2u * KC - i - 1u) >> 1) - (int)i - 1; };
         for (uint32_t i = sl; i < (uint32_t)KT + 2u; i += GROUP) D[i] = i == (uint32_t)KT ? kNothing : 0.0;
         __syncthreads();
+        CL_STAMP(0x36);
         // (c): every unordered pair of rows once -- row i takes i+1 .. i+n/2 (mod n), for even n the distance-n/2 pairs only from
         // the lower half -- and the pairs of open rows of different groups go into their groups' cell
         {
@@ -2035,6 +2066,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
             }
         }
         __syncthreads();
+        CL_STAMP(0x37);
         // the rounds of link_unit on the groups: lane a < k owns group a (a cluster keeps the index of its smallest group,
         // which is the rank of its smallest member: the oracle's tie order)
         const uint32_t a = sl;
@@ -2045,6 +2077,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
         constexpr unsigned long long km = KC == 64 ? ~0ull : ((1ull << (KC & 63)) - 1ull);
         uint32_t nl = kk;                                    // clusters left
         for (uint32_t round = 0; round < (uint32_t)KC; ++round) {
+            CL_STAMP(0x38);
             // nearest neighbour of every cluster: smallest mean, ties to the smallest index -- the list of what is left is
             // ascending, read four entries at a time
             const double sizeA = aliveA ? (double)S.gsize[sub][a] : 1.0;
@@ -2105,6 +2138,7 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
             __syncthreads();
         }
         // the clusters as bit sets: every open row adds its bit at the smallest member of its group's cluster
+        CL_STAMP(0x39);
         __syncthreads();
         if (mine) S.nn[sub][a] = (uint8_t)rootA;
 #pragma unroll
@@ -2133,7 +2167,9 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
     // hand on what this unit does not vouch for
     const bool over = has && n >= 2 && (unfit || too_many);
     if (!TIER2 && over && sl == 0) over_append(p, over_items, over_counts, part, s);
+    CL_STAMP(0x3A);
     emit_prep<GROUP, R, NW, NMAX>(p, has && !over, part, s, n, sub, sl, F, S.mask[sub], S.ps[sub], S.sum[sub], mk, rd);
+    CL_STAMP(0x3B);
     return __ballot(has && n >= 2 && unfit) != 0ull;     // (some partition of this wave was not vouched for)
 }
 // one size class per launch: what large inputs use (the fused kernel needs the registers of all variants at once; with
@@ -2142,6 +2178,7 @@ template <int GROUP, int R, int KC>
 __global__ __launch_bounds__(64) void cl_tight_one(const ClParams p, uint32_t *items /* the class's lists */, const uint32_t *counts /* [kShards] */,
                                                    uint32_t *over_counts /* [kShards] */)
 {
+    CL_STAMP_INIT(0);
     __shared__ __align__(16) unsigned char smem[sizeof(TightSmem<GROUP, R, KC>)];
     __shared__ uint32_t s_pref[kShards + 1];
     worklist_prefix(counts, s_pref);
@@ -2158,6 +2195,7 @@ template <int KC>
 __global__ __launch_bounds__(64) void cl_tight_big(const ClParams p, uint32_t *over_items, uint32_t *over_counts /* [kShards] */,
                                                    uint32_t *found /* how many there were (statistics) */)
 {
+    CL_STAMP_INIT(3);
     __shared__ __align__(16) unsigned char smem[sizeof(TightSmem<64, 2, KC>)];
     const uint32_t n_parts = *p.n_parts, lane = threadIdx.x;
     const WorkList all{nullptr, nullptr, n_parts, 0u};
@@ -2185,6 +2223,7 @@ constexpr size_t kTightSmemBytes = cmax(cmax(sizeof(TightSmem<64, 1, kK64>), siz
 __global__ __launch_bounds__(64, 6) void cl_tight_all(const ClParams p, uint32_t *lists, const uint32_t *cnts /* [kClasses][kShards] */,
                                                    uint32_t *over_cnts /* [kClasses][kShards] */)
 {
+    CL_STAMP_INIT(0);
     __shared__ __align__(16) unsigned char smem[kTightSmemBytes];
     __shared__ uint32_t s_pref[4][kShards + 1];
 #pragma unroll
@@ -2212,6 +2251,7 @@ constexpr size_t kLinkSmemBytes = cmax(cmax(sizeof(LinkSmem<64, 1, 64>), sizeof(
 
 __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts /* [kClasses][kShards] */)
 {
+    CL_STAMP_INIT(4);
     __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
     __shared__ __align__(16) unsigned char smem_link[kLinkSmemBytes];
     __shared__ uint32_t s_pref[kShards + 1];               // the running sums of ONE class's shard counters at a time
@@ -2265,6 +2305,7 @@ constexpr size_t kTier2SmemBytes = cmax(cmax(Tier2Smem<64, 1, 64>::bytes, Tier2S
 __global__ __launch_bounds__(64) void cl_tier2_all(const ClParams p, const uint32_t *lists, const uint32_t *over_cnts /* [kClasses][kShards] */,
                                                    uint32_t with64 /* 0: the class of 33..64 marks has a launch of its own */)
 {
+    CL_STAMP_INIT(0);
     __shared__ __align__(16) unsigned char smem[kTier2SmemBytes];
     __shared__ uint32_t s_pref[4][kShards + 1];
 #pragma unroll
@@ -2287,6 +2328,7 @@ __global__ __launch_bounds__(64) void cl_tier2_all(const ClParams p, const uint3
 template <int GROUP, int R, int NCAP>
 __global__ __launch_bounds__(64) void cl_tier2_one(const ClParams p, const uint32_t *items, const uint32_t *over_counts /* [kShards] */)
 {
+    CL_STAMP_INIT(0);
     __shared__ __align__(16) unsigned char smem[Tier2Smem<GROUP, R, NCAP>::bytes];
     __shared__ uint32_t s_pref[kShards + 1];
     worklist_prefix(over_counts, s_pref);
@@ -2301,6 +2343,7 @@ __global__ __launch_bounds__(64) void cl_tier2_one(const ClParams p, const uint3
 template <int GROUP, int R, int NCAP>
 __global__ __launch_bounds__(64) void cl_link_one(const ClParams p, const uint32_t *items, const uint32_t *over_counts /* [kShards] */)
 {
+    CL_STAMP_INIT(5);
     __shared__ __align__(16) unsigned char smem[sizeof(FastSmem<GROUP, R>)];
     __shared__ __align__(16) unsigned char smem_link[sizeof(LinkSmem<GROUP, R, NCAP>)];
     __shared__ uint32_t s_pref[kShards + 1];
@@ -2705,6 +2748,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.mergeable = pr->max_dist >= 0 ? 1u : 0u;
     p.kc = (ctx->dbg & DUET_DBG_CLUSTER_KC2) ? 2u : 64u;
     p.sym = (ctx->dbg & DUET_DBG_CLUSTER_NOSYM) ? 0u : 1u;
+    p.stamps = ctx->d_stamps;
     const uint32_t gridw = std::min(32768u, std::max(1024u, M / 256u));     // (a wavefront per virtual block, striding)
     const bool small = M <= (4u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_LARGE);
     const bool cap100 = p.part_max <= 100u;          // no unit has more rows than part_max

@@ -1751,7 +1751,7 @@ int duet_ctx_set_profiling(duet_ctx *ctx, int enabled)
 #ifdef DUET_STAMPS
 DUET_API int duet_dbg_stamps(duet_ctx *ctx, int enable, unsigned long long *host_out)
 {
-    const size_t bytes = (size_t)3 * 65536 * 8 * 8;
+    const size_t bytes = (size_t)6 * 65536 * 8 * 8;        // [0..2] the E/F kernels, [3..5] stage A0's agglomeration chains (duet_cluster.hip)
     if (enable && !ctx->d_stamps) { if (hipMalloc((void **)&ctx->d_stamps, bytes) != hipSuccess) return -1; }
     if (enable) { (void)hipMemset(ctx->d_stamps, 0, bytes); return 0; }
     if (ctx->d_stamps && host_out) { (void)hipDeviceSynchronize(); (void)hipMemcpy(host_out, ctx->d_stamps, bytes, hipMemcpyDeviceToHost); }
