@@ -2178,7 +2178,7 @@ template <int GROUP, int R, int KC>
 __global__ __launch_bounds__(64) void cl_tight_one(const ClParams p, uint32_t *items /* the class's lists */, const uint32_t *counts /* [kShards] */,
                                                    uint32_t *over_counts /* [kShards] */)
 {
-    CL_STAMP_INIT(0);
+    CL_STAMP_INIT(GROUP == 64 ? 4 : (GROUP == 32 ? 5 : 0));       // (large inputs: cl_fast_all's and cl_link_one's areas are free / shared)
     __shared__ __align__(16) unsigned char smem[sizeof(TightSmem<GROUP, R, KC>)];
     __shared__ uint32_t s_pref[kShards + 1];
     worklist_prefix(counts, s_pref);

@@ -34,7 +34,7 @@ lib.duet_dbg_stamps(ctx.handle, 1, None)
 ds.run_fused(ctx, wait=True)
 buf = np.zeros(6 * 65536 * 8, dtype=np.uint64)
 lib.duet_dbg_stamps(ctx.handle, 0, buf.ctypes.data)
-for area, name in ((3, 'cl_tight_big'), (4, 'cl_fast_all'), (5, 'cl_link_one')):
+for area, name in ((3, 'cl_tight_big'), (4, 'cl_fast_all (1.0 M marks) / cl_tight_one<64> (large inputs)'), (5, 'cl_link_one + cl_tight_one<32> (large inputs)')):
     log = buf[area * 65536 * 8:(area + 1) * 65536 * 8].reshape(8192, 64)[:, 2:]
     used = (log != 0).sum(axis=1)
     blocks = np.nonzero(used)[0]
