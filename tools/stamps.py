@@ -39,9 +39,9 @@ torch.cuda.synchronize()
 lib.duet_dbg_stamps(ctx.handle, 1, None)
 dp.run(ctx, stream)
 torch.cuda.synchronize()
-buf = np.zeros(3 * 65536 * 8, dtype=np.uint64)
+buf = np.zeros(6 * 65536 * 8, dtype=np.uint64)          # (areas 3..5: stage A0's chains, tools/stamps_cl.py)
 lib.duet_dbg_stamps(ctx.handle, 0, buf.ctypes.data)
-st = buf.reshape(3, 65536, 8).astype(np.int64)
+st = buf[:3 * 65536 * 8].reshape(3, 65536, 8).astype(np.int64)
 t0 = st[0][st[0][:, 0] > 0][:, 0].min()
 names = [['start', 'offsets', 'staged', 'consumed', 'loop_end', 'decided', 'end'],
          ['start', 'gathered', 'sorted', 'end', 'recs', 'counted', 'written', 'runs'],
