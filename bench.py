@@ -324,6 +324,13 @@ class DuetColl(object):
 
         self.gather = comm.RcclGather(ctx, _IdCarrier(float(timeout)))
         self.stream = torch.cuda.Stream()
+        # before anything is timed: every rank gathers a rank-stamped pattern through the communicator and checks every slot
+        # (duet_comm_selftest), and RCCL itself is asked how many ranks it connected (duet_comm_info -> the line's rccl_ranks_seen)
+        self.selftest = None
+        if os.environ.get('DUET_COMM_SELFTEST', '1') != '0':
+            self.gather.selftest(4096)
+            self.selftest = 'ok: 4096 rank-stamped words per rank, every slot checked on every rank'
+        self.info = self.gather.info()
 
     def barrier(self):
         self.ctl.barrier()
@@ -398,8 +405,16 @@ def topology(torch, coll, rank, world, local_rank, one_gpu):
     mine = {'rank': rank, 'device': local_rank, 'name': props.name, 'cus': props.multi_processor_count,
             'hbm_GiB': round(props.total_memory / 2 ** 30, 1),
             'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pid': os.getpid()}
+    info = getattr(coll, 'info', None)
+    if isinstance(info, dict):
+        mine['rccl'] = info                                   # what ncclCommCount / ncclCommUserRank / ncclCommCuDevice say on this rank
     allr = coll.all_gather_object(mine)
+    seen = [r['rccl'].get('rccl_ranks') for r in allr if isinstance(r.get('rccl'), dict)]
     return {'backend': coll.backend, 'collective': coll.name, 'world_size': coll.world, 'rccl_version': coll.version(),
+            # the smallest communicator size any rank's RCCL reports (ncclCommCount through duet_comm_info): == world_size when RCCL
+            # itself connected every rank; null on the torch.distributed paths
+            'rccl_ranks_seen': (min(seen) if seen and len(seen) == len(allr) else None),
+            'comm_selftest': getattr(coll, 'selftest', None),
             'one_gpu_plumbing_mode': one_gpu, 'ranks': allr,
             'distinct_devices': len(set((r['device'], r['pci_bus_id']) for r in allr))}
 
@@ -497,6 +512,7 @@ def sharded_run(args, ctx, torch, coll, rank, world, local_rank, one_gpu):
             'metric': METRIC, 'value': soa.n_marks * args.steps / dt, 'unit': 'marks/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+            'value_is': VALUE_IS.replace('value_clustered_and_phased', 'extra.fused_clustered_and_phased_sharded.marks_per_s'),
             'plumbing_test_one_gpu': one_gpu,
             'config': {'workload': 'BASELINE configs[2]: synthetic whole genome chr1-22,X,Y, %d SV marks / %d candidates / %d '
                                    'tagged reads in %d contigs, resident in HBM, contigs LPT-sharded over %d GPUs; step = '
@@ -688,7 +704,7 @@ def compact_line(full, detail_path=None):
     top = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
            'dtype', 'data', 'parity_vs_oracle', 'plumbing_test_one_gpu', 'kernels_us_isolated', 'value_clustered_and_phased',
            'ms_per_step_clustered_and_phased', 'parity_clustered_and_phased_vs_composed_oracles', 'value_vs_1gpu_same_problem',
-           'collective')
+           'collective', 'value_is')
     out = {k: full[k] for k in top if k in full}
     cfg = full.get('config', {})
     out['config'] = _pick(cfg, ('workload', 'marks', 'candidates', 'reads', 'contigs', 'marks_per_gpu', 'candidates_per_gpu',
@@ -723,7 +739,8 @@ def compact_line(full, detail_path=None):
                            'kernels_only_us': [round(r.get('kernels_only_ms_per_step', 0) * 1e3, 2) for r in pr]}
     if 'topology' in full:
         tp = full['topology']
-        out['topology'] = _pick(tp, ('backend', 'world_size', 'rccl_version', 'one_gpu_plumbing_mode', 'distinct_devices'))
+        out['topology'] = _pick(tp, ('backend', 'world_size', 'rccl_version', 'rccl_ranks_seen', 'comm_selftest', 'one_gpu_plumbing_mode', 'distinct_devices'))
+        out['rccl_ranks_seen'] = tp.get('rccl_ranks_seen')
         out['topology']['devices'] = ['%s@%s' % (r.get('device'), r.get('pci_bus_id')) for r in tp.get('ranks', [])]
     if 'same_problem_on_1_gpu' in full and full['same_problem_on_1_gpu']:
         out['same_problem_on_1_gpu'] = _pick(full['same_problem_on_1_gpu'], ('ms_per_step', 'marks_per_s', 'parity_vs_oracle'))
@@ -777,6 +794,7 @@ def write_detail(full, world):
 
 
 METRIC = 'SV support-read marks clustered+phased /sec; bit-exact phased_sv.vcf vs ref'
+VALUE_IS = 'phased_only (step E/F on pre-clustered candidates); the literal clustered+phased figure is value_clustered_and_phased'
 DTYPE = 'u32/u64 integer + f64 threshold compares'
 
 
@@ -809,6 +827,9 @@ def single_gpu_run(args, ctx, torch):
         'metric': METRIC, 'value': soa.n_marks * args.steps / dt, 'unit': 'marks/s', 'n_gpus': 1, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+        # `value` is the PHASING step (E/F) on candidates that are already clustered; the metric read
+        # literally -- the same marks raw, clustered (stage A0) and phased in one device pipeline -- is value_clustered_and_phased
+        'value_is': VALUE_IS,
         'config': {'workload': 'BASELINE configs[1]: synthetic 1 contig, %d SV marks / %d candidates / %d tagged reads, '
                                'resident in HBM; step = classify+seed_sort+finalize (phasing, E/F); the clustered+phased '
                                'figure for the same marks is value_clustered_and_phased'
@@ -1203,6 +1224,7 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False, t
     ok = bool(rc == 0 and ds.n_found == N and np.array_equal(got['pred'], wp) and np.array_equal(got['ps'], ws)
               and np.array_equal(got['cand_off'], cl['cand_off']) and np.array_equal(got['order'], cl['order'])
               and np.array_equal(got_async['pred'], wp) and np.array_equal(got_async['ps'], ws))
+    n_found = int(ds.n_found)                           # (what the DEVICE found, not the oracle's count: ADVICE round 5)
     if tailed is not None:
         # step E/F ALONE on exactly the candidates stage A0 found (sizes with a tail: a real caller's shape; the bench's own E/F
         # problems have sizes U{2..18}) -- the honest figure for ef_classify beside the uniform-size roofline points
@@ -1217,9 +1239,6 @@ def fused_point(ctx, torch, engine, synth, contigs, runs=20, scan_order=False, t
                   'lane_efficiency': float(deg.sum() / (64.0 * mx.sum())), 'ef_classify_us': t['kernels_us']['ef_classify'],
                   'ef_classify_GBs_algorithmic': classify_bytes(ref) / (t['kernels_us']['ef_classify'] * 1e-6) / 1e9})
         tailed.update(t)
-        n_found = N
-    else:
-        n_found = int(ds.n_found)
     M = len(marks['pos'])
     b_a0, b_ef = 18 * M, 12 * M + 27 * n_found + 8 * soa.n_reads
     gbs = (b_a0 + b_ef) / dt / 1e9

@@ -27,7 +27,7 @@ EXPORTS = ('duet_abi_version', 'duet_ctx_create', 'duet_ctx_destroy', 'duet_last
            'duet_ef_profile_collect', 'duet_ef_get_seed_ps', 'duet_cluster_run_device', 'duet_cluster_run_host', 'duet_svim_phase_device', 'duet_svim_phase_host', 'duet_rows_run_device',
            'duet_ef_rows_run_host', 'duet_eval_run_host', 'duet_comm_unique_id', 'duet_comm_create', 'duet_comm_allgather_device',
            'duet_comm_allgather_host', 'duet_comm_destroy', 'duet_comm_set_timeout', 'duet_comm_block_bytes',
-           'duet_comm_ef_allgather', 'duet_comm_rccl_version')
+           'duet_comm_ef_allgather', 'duet_comm_rccl_version', 'duet_comm_info', 'duet_comm_selftest')
 
 
 class EfProblem(ctypes.Structure):
@@ -153,6 +153,8 @@ def load():
     lib.duet_comm_block_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     lib.duet_comm_ef_allgather.argtypes = [ctypes.c_void_p, ctypes.POINTER(EfProblem), ctypes.c_void_p, ctypes.c_uint32,
                                            ctypes.c_uint32, ctypes.c_void_p]
+    lib.duet_comm_info.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 5
+    lib.duet_comm_selftest.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
     lib.duet_comm_destroy.restype = None
     lib.duet_comm_destroy.argtypes = [ctypes.c_void_p]
     _lib = lib

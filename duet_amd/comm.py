@@ -222,21 +222,28 @@ class RcclGather(object):
         import ctypes
         self.ctx, self.star = ctx, star
         lib = ctx.lib
+        # The hand-over is symmetric: rank 0 ALWAYS broadcasts -- the 128-byte id, or why it has none -- so that no rank is left
+        # inside the broadcast while rank 0 has moved on to another collective (an RCCL that cannot be loaded on
+        # rank 0 used to hang the others until the rendezvous timeout); every rank then raises the same error.
         ident = None
         if star.rank == 0:
             buf = (ctypes.c_ubyte * 128)()
             rc = lib.duet_comm_unique_id(ctx.handle, buf)
-            if rc:
-                ctx._raise(rc)
-            ident = bytes(buf)
+            ident = (b'\x00' + bytes(buf)) if rc == 0 else b'\x01' + ('duet_comm_unique_id: %s' % ctx.last_error()).encode('utf-8', 'replace')
         ident = star.bcast(ident)
-        arr = (ctypes.c_ubyte * 128).from_buffer_copy(ident)
+        if not isinstance(ident, (bytes, bytearray)) or len(ident) != 129 or ident[:1] != b'\x00':
+            why = bytes(ident)[1:].decode('utf-8', 'replace') if ident else 'rank 0 sent no id'
+            raise CommError(why or 'rank 0 sent no id')
+        arr = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(ident)[1:])
         # bounded inside the library by DUET_RDZV_TIMEOUT (ncclCommInitRank on a helper thread, waited for with a deadline)
         os.environ['DUET_RDZV_TIMEOUT'] = repr(float(star.timeout))
         self.handle = lib.duet_comm_create(ctx.handle, arr, star.rank, star.world)
         if not self.handle:
             why = ctx.last_error()
             raise (CommTimeout if 'did not finish within' in why else CommError)('duet_comm_create: %s' % why)
+        if os.environ.get('DUET_COMM_SELFTEST') == '1':
+            # before any result travels: a rank-stamped pattern through the same communicator, every slot checked on every rank
+            self.selftest()
 
     def _raise(self, rc):
         from duet_amd import _lib
@@ -276,6 +283,22 @@ class RcclGather(object):
         import ctypes
         rc = self.ctx.lib.duet_comm_allgather_device(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_uint64(int(nbytes)),
                                                      ctypes.c_void_p(recv_ptr), ctypes.c_void_p(stream))
+        if rc:
+            self._raise(rc)
+
+    def info(self):
+        """What RCCL itself reports about the communicator (duet_comm_info): {'rank', 'world', 'rccl_ranks', 'rccl_rank',
+        'rccl_device'} -- rccl_ranks == world is the evidence that RCCL connected every rank."""
+        import ctypes
+        v = [ctypes.c_int(-1) for _ in range(5)]
+        rc = self.ctx.lib.duet_comm_info(self.handle, *[ctypes.byref(x) for x in v])
+        if rc:
+            self._raise(rc)
+        return dict(zip(('rank', 'world', 'rccl_ranks', 'rccl_rank', 'rccl_device'), (int(x.value) for x in v)))
+
+    def selftest(self, words=4096):
+        """Every rank gathers a rank-stamped pattern and checks every slot (duet_comm_selftest; collective)."""
+        rc = self.ctx.lib.duet_comm_selftest(self.handle, int(words))
         if rc:
             self._raise(rc)
 

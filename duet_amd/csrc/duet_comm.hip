@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "duet_ef.h"
 #include "duet_internal.h"
@@ -37,6 +38,7 @@ typedef int (*fn_all_gather)(const void *, void *, size_t, int /* ncclDataType_t
 typedef int (*fn_comm_destroy)(NcclComm);
 typedef const char *(*fn_error_string)(int);
 typedef int (*fn_get_version)(int *);
+typedef int (*fn_comm_int)(NcclComm, int *);
 constexpr int kNcclUint8 = 1;
 
 struct Rccl {
@@ -47,6 +49,7 @@ struct Rccl {
     fn_comm_destroy comm_destroy = nullptr;
     fn_error_string error_string = nullptr;
     fn_get_version get_version = nullptr;
+    fn_comm_int comm_count = nullptr, comm_user_rank = nullptr, comm_cu_device = nullptr;   // (optional: duet_comm_info)
     std::string why;
 };
 
@@ -78,6 +81,9 @@ void rccl_load(Rccl &r)
     r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
     r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
     r.get_version = (fn_get_version)dlsym(r.handle, "ncclGetVersion");
+    r.comm_count = (fn_comm_int)dlsym(r.handle, "ncclCommCount");
+    r.comm_user_rank = (fn_comm_int)dlsym(r.handle, "ncclCommUserRank");
+    r.comm_cu_device = (fn_comm_int)dlsym(r.handle, "ncclCommCuDevice");
     if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) {
         r.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
         r.handle = nullptr;
@@ -306,34 +312,92 @@ int duet_comm_ef_allgather(duet_comm *cm, const duet_ef_problem *pr, const uint3
     if (!cm || !cm->ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null communicator");
     duet_ctx *ctx = cm->ctx;
     if (!pr || !gathered || n_max == 0) return duet_fail(ctx, DUET_ERR_INVALID, "duet_comm_ef_allgather: null argument");
-    if (pr->n_cands > n_max) return duet_fail(ctx, DUET_ERR_INVALID, "the shard has more candidates than n_max");
-    if (n_slots && pr->n_cands && !cand_slot) return duet_fail(ctx, DUET_ERR_INVALID, "cand_slot is null");
     if (cm->broken) return duet_fail(ctx, DUET_ERR_TIMEOUT, "the communicator timed out earlier");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t C = pr->n_cands;
     const size_t rb = (size_t)(((5ull * n_max + 15ull) / 16ull) * 16ull), bytes = (size_t)duet_comm_block_bytes(n_max, n_slots);
     int rc;
+    // the block and the receive buffer first: without them this rank cannot take part in the collective at all
     if ((rc = duet_reserve(ctx, cm->send, bytes))) return rc;
     if ((rc = duet_reserve(ctx, cm->recv, bytes * (size_t)cm->world))) return rc;
-    if ((rc = duet_reserve(ctx, cm->slots, C ? (size_t)C * 4 : 16))) return rc;
     hipStream_t s = ctx->own_stream;
     uint8_t *block = (uint8_t *)cm->send.ptr;
-    // what the kernels do not write of the block: the slots of the ranks with more candidates, the padding, the trailer's counters
-    HIP_TRY(ctx, hipMemsetAsync(block, 0, bytes, s));
-    if (C) {
-        duet_ef_problem d;
-        if ((rc = duet_ef_upload(ctx, pr, &d, s))) return rc;
-        if (n_slots) HIP_TRY(ctx, hipMemcpyAsync(cm->slots.ptr, cand_slot, (size_t)C * 4, hipMemcpyHostToDevice, s));
-        if ((rc = duet_ef_run_device(ctx, &d, block + 4 * (size_t)n_max, (uint32_t *)block, s))) return rc;
+    // The rank's own part.  Whatever fails in it -- the arguments (checked BEFORE any array is touched: ADVICE round 5), memory, the
+    // upload, a launch -- this rank still contributes a block (zeros, and a status word with the top bit set) to the ONE collective:
+    // its peers then fail at once with that status instead of waiting for DUET_RDZV_TIMEOUT.
+    auto local = [&]() -> int {
+        int rc2;
+        if ((rc2 = duet_ef_validate(ctx, pr))) return rc2;
+        const uint32_t C = pr->n_cands;
+        if (C > n_max) return duet_fail(ctx, DUET_ERR_INVALID, "the shard has more candidates than n_max");
+        if (n_slots && C && !cand_slot) return duet_fail(ctx, DUET_ERR_INVALID, "cand_slot is null");
+        if ((rc2 = duet_reserve(ctx, cm->slots, C ? (size_t)C * 4 : 16))) return rc2;
+        // what the kernels do not write of the block: the slots of the ranks with more candidates, the padding, the trailer's counters
+        HIP_TRY(ctx, hipMemsetAsync(block, 0, bytes, s));
+        if (C) {
+            duet_ef_problem d;
+            if ((rc2 = duet_ef_upload(ctx, pr, &d, s))) return rc2;
+            if (n_slots) HIP_TRY(ctx, hipMemcpyAsync(cm->slots.ptr, cand_slot, (size_t)C * 4, hipMemcpyHostToDevice, s));
+            if ((rc2 = duet_ef_run_device(ctx, &d, block + 4 * (size_t)n_max, (uint32_t *)block, s))) return rc2;
+        }
+        hipLaunchKernelGGL(comm_trailer, dim3(C ? (C + 4095u) / 4096u : 1u), dim3(256), 0, s, block + 4 * (size_t)n_max,
+                           (const uint32_t *)cm->slots.ptr, C, n_slots, (uint32_t *)(block + rb), (unsigned long long *)(block + rb + 16),
+                           C ? ctx->d_status : (uint32_t *)nullptr);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->pending_check = false;                         // (the status word went into the block)
+        return DUET_OK;
+    };
+    const int local_rc = local();
+    std::string local_why;
+    if (local_rc) {
+        local_why = ctx->err;
+        const uint32_t st = DUET_COMM_STATUS_RANK_FAILED | ((uint32_t)(-local_rc) & 0xFFFFu);
+        if (hipMemsetAsync(block, 0, bytes, s) != hipSuccess ||
+            hipMemcpyAsync(block + rb, &st, 4, hipMemcpyHostToDevice, s) != hipSuccess)
+            return duet_fail(ctx, local_rc, local_why);     // (the device itself is gone: the peers' timeout is all that is left)
     }
-    hipLaunchKernelGGL(comm_trailer, dim3(C ? (C + 4095u) / 4096u : 1u), dim3(256), 0, s, block + 4 * (size_t)n_max,
-                       (const uint32_t *)cm->slots.ptr, C, n_slots, (uint32_t *)(block + rb), (unsigned long long *)(block + rb + 16),
-                       C ? ctx->d_status : (uint32_t *)nullptr);
-    HIP_TRY(ctx, hipGetLastError());
-    ctx->pending_check = false;                             // (the status word went into the block)
-    if ((rc = duet_comm_allgather_device(cm, block, bytes, cm->recv.ptr, s))) return rc;      // the ONE collective of the path
+    if ((rc = duet_comm_allgather_device(cm, block, bytes, cm->recv.ptr, s))) return local_rc ? duet_fail(ctx, local_rc, local_why) : rc;      // the ONE collective of the path
     HIP_TRY(ctx, hipMemcpyAsync(gathered, cm->recv.ptr, bytes * (size_t)cm->world, hipMemcpyDeviceToHost, s));
-    return bounded_sync(cm, s, "the rank's kernels and the all-gather");
+    rc = bounded_sync(cm, s, "the rank's kernels and the all-gather");
+    if (local_rc) return duet_fail(ctx, local_rc, local_why);
+    return rc;
+}
+
+int duet_comm_info(duet_comm *cm, int *rank, int *world, int *rccl_ranks, int *rccl_rank, int *rccl_device)
+{
+    if (!cm || !cm->ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null communicator");
+    Rccl &r = rccl();
+    if (rank) *rank = cm->rank;
+    if (world) *world = cm->world;
+    int n = -1, u = -1, d = -1;
+    if (cm->comm && !cm->broken) {
+        if (r.comm_count && r.comm_count(cm->comm, &n)) n = -1;
+        if (r.comm_user_rank && r.comm_user_rank(cm->comm, &u)) u = -1;
+        if (r.comm_cu_device && r.comm_cu_device(cm->comm, &d)) d = -1;
+    }
+    if (rccl_ranks) *rccl_ranks = n;
+    if (rccl_rank) *rccl_rank = u;
+    if (rccl_device) *rccl_device = d;
+    return DUET_OK;
+}
+
+// A pattern that names its rank and its place: what every slot of the gathered buffer must hold.
+static inline uint32_t selftest_word(uint32_t rank, uint32_t i) { return (rank + 1u) * 0x9E3779B1u ^ (i * 0x85EBCA6Bu + 0xC2B2AE35u); }
+
+int duet_comm_selftest(duet_comm *cm, uint32_t words)
+{
+    if (!cm || !cm->ctx) return duet_fail(nullptr, DUET_ERR_INVALID, "null communicator");
+    duet_ctx *ctx = cm->ctx;
+    if (words == 0 || words > (1u << 24)) return duet_fail(ctx, DUET_ERR_INVALID, "duet_comm_selftest: 1 .. 2^24 words");
+    std::vector<uint32_t> mine(words), all((size_t)words * (size_t)cm->world);
+    for (uint32_t i = 0; i < words; ++i) mine[i] = selftest_word((uint32_t)cm->rank, i);
+    int rc = duet_comm_allgather_host(cm, mine.data(), (uint64_t)words * 4u, all.data());
+    if (rc) return rc;
+    for (int r = 0; r < cm->world; ++r)
+        for (uint32_t i = 0; i < words; ++i)
+            if (all[(size_t)r * words + i] != selftest_word((uint32_t)r, i))
+                return duet_fail(ctx, DUET_ERR_HIP, "duet_comm_selftest: rank " + std::to_string(cm->rank) + " received a wrong word " +
+                                                    std::to_string(i) + " in the slot of rank " + std::to_string(r));
+    return DUET_OK;
 }
 
 void duet_comm_destroy(duet_comm *cm)
@@ -341,10 +405,15 @@ void duet_comm_destroy(duet_comm *cm)
     if (!cm) return;
     Rccl &r = rccl();
     if (cm->ctx) (void)hipSetDevice(cm->ctx->device);
-    if (cm->comm && r.comm_destroy && !cm->broken) (void)r.comm_destroy(cm->comm);    // (a communicator with a stuck collective would block here)
-    if (cm->send.ptr) (void)hipFree(cm->send.ptr);
-    if (cm->recv.ptr) (void)hipFree(cm->recv.ptr);
-    if (cm->slots.ptr) (void)hipFree(cm->slots.ptr);
+    // A communicator that timed out may still have a collective stuck on the stream: ncclCommDestroy would block on it, and so
+    // would hipFree (it synchronises the device) -- its device buffers are leaked, the process is expected to exit
+    // (include/duet_ef.h says so)
+    if (!cm->broken) {
+        if (cm->comm && r.comm_destroy) (void)r.comm_destroy(cm->comm);
+        if (cm->send.ptr) (void)hipFree(cm->send.ptr);
+        if (cm->recv.ptr) (void)hipFree(cm->recv.ptr);
+        if (cm->slots.ptr) (void)hipFree(cm->slots.ptr);
+    }
     delete cm;
 }
 

@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kCandPerBlock, 6) void ef_classify(const Params p)
             } else {
                 for (uint32_t i = tid; i < kChunk && cs + i < m_end; i += kCandPerBlock) {
                     const uint32_t r = p.mark_read[cs + i];
-                    s_tag[i] = r == kEmpty ? kUntagged : p.read_tag[r];
+                    s_tag[i] = r < p.n_reads ? p.read_tag[r] : kUntagged;        // (as stage_gather: an index beyond the table has no tag)
                 }
             }
             __syncthreads();
@@ -2000,6 +2000,8 @@ int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t 
 }
 
 }  // extern "C"
+
+int duet_ef_validate(duet_ctx *ctx, const duet_ef_problem *pr) { return validate(ctx, pr, (const void *)1, (const void *)1); }
 
 // host arrays of *pr -> the context's staging buffers (asynchronous on `s`); *d = the same problem with device pointers.
 // Also reserves the result buffers h_out[0] (pred) / h_out[1] (ps).

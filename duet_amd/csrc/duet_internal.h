@@ -85,6 +85,9 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
                                   const uint32_t *d_ctg_off /* or null ... */, const uint16_t *d_cand_contig /* ... then the candidates' contig column */,
                                   uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream, bool planned);
 
+// argument checks of an E/F problem (host or device arrays alike: pointers and counts only)
+int duet_ef_validate(duet_ctx *ctx, const duet_ef_problem *pr);
+
 // host arrays of an E/F problem -> the context's staging buffers (duet_ef.hip)
 int duet_ef_upload(duet_ctx *ctx, const duet_ef_problem *pr, duet_ef_problem *d, hipStream_t s);
 

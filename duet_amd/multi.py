@@ -214,7 +214,12 @@ def rank_body(home, svlen_thres, suppread_thres, thread, include_all_ctgs, rank,
             g = gathered.cpu().numpy()
         total = np.zeros(2 * K, dtype=np.int64)
         for r in range(world):
-            if int(g[r, rb:rb + 4].view(np.uint32)[0]) == RC_DIV_ZERO:
+            st = int(g[r, rb:rb + 4].view(np.uint32)[0])
+            if st & 0x80000000:
+                # (include/duet_ef.h, DUET_COMM_STATUS_RANK_FAILED: that rank's own part failed; it contributed a block so that
+                # nobody waits for the time limit, and says why itself)
+                raise RuntimeError('rank %d failed before the collective (duet_status %d)' % (r, -(st & 0xFFFF)))
+            if st == RC_DIV_ZERO:
                 return RC_DIV_ZERO
             total += g[r, rb + STATUS_BYTES:rb + tb].view(np.uint64).astype(np.int64)
         # where each CHROM text's rows start counting: after the rows of every text that sorts before it

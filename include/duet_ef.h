@@ -361,6 +361,18 @@ DUET_API int duet_comm_allgather_host(duet_comm *comm, const void *send, uint64_
 DUET_API uint64_t duet_comm_block_bytes(uint32_t n_max, uint32_t n_slots);
 DUET_API int duet_comm_ef_allgather(duet_comm *comm, const duet_ef_problem *prob, const uint32_t *cand_slot, uint32_t n_slots,
                                     uint32_t n_max, uint8_t *gathered);
+/* A rank whose own part of duet_comm_ef_allgather fails (arguments, memory, upload, a launch) still contributes a block to
+ * the collective -- zeros, with this bit set in the status word and the negated duet_status in the low 16 bits -- so that its
+ * peers fail at once instead of waiting for the time limit; the failing rank returns its own error after the collective. */
+#define DUET_COMM_STATUS_RANK_FAILED 0x80000000u
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 where the loaded RCCL
+ * lacks the call): `rccl_ranks` == world is the evidence that RCCL, not a stand-in, connected every rank. */
+DUET_API int duet_comm_info(duet_comm *comm, int *rank, int *world, int *rccl_ranks, int *rccl_rank, int *rccl_device);
+/* Every rank all-gathers `words` 32-bit words of a pattern that names its rank and the word's place, and checks every slot
+ * of what comes back (collective: every rank must call it with the same `words`).  DUET_OK or the first wrong word. */
+DUET_API int duet_comm_selftest(duet_comm *comm, uint32_t words);
+/* Frees the communicator.  On one that timed out (DUET_ERR_TIMEOUT) nothing of the device is touched -- a collective may be
+ * stuck on the stream, ncclCommDestroy and hipFree would wait for it: its buffers are leaked, the process is expected to exit. */
 DUET_API void duet_comm_destroy(duet_comm *comm);
 
 #ifdef __cplusplus
