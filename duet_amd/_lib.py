@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libduet_ef.so')
 
 DUET_OK = 0
+DUET_ERR_INVALID = -1
 DUET_ERR_DIV_ZERO = -5
 DUET_ERR_TIMEOUT = -6
 MARK_ABSENT = 0xFFFFFFFF
@@ -220,7 +221,8 @@ class Context(object):
         pred = np.zeros(C, dtype=np.uint8)
         ps = np.zeros(C, dtype=np.uint32)
         stats = EfStats()
-        rc = self.lib.duet_ef_run_host(self.handle, ctypes.byref(prob), _ptr(pred), _ptr(ps), ctypes.byref(stats))
+        # (statistics only when asked for: the seed count behind a two-launch run costs an ef_seed_sort launch of its own)
+        rc = self.lib.duet_ef_run_host(self.handle, ctypes.byref(prob), _ptr(pred), _ptr(ps), ctypes.byref(stats) if want_stats else None)
         del keep
         if rc:
             self._raise(rc)

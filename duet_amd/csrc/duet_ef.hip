@@ -1502,6 +1502,303 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// kernels 2 + 3 in ONE launch for problems of the size real genomes have (round 6): every finalize tile builds the seed
+// set of its contig ITSELF
+// ---------------------------------------------------------------------------------------------
+// at BASELINE configs[1] (and at SURVEY 8d's estimate of real ONT genomes, 1e5 .. 1e6 marks) the step
+// was three dependent launches, ~15 us of launch and first-round-trip floors for ~2 us of traffic.  ef_seed_sort -- ONE
+// workgroup per contig between two grid-wide launches -- was 6.9 us of config 2's 23.9.  Here it is gone: a finalize tile reads the
+// seed entries of ALL tiles of its contig (32 bytes per tile beside a handful of overflow entries: 12.5 KB at config 2, out of
+// L2 / the Infinity Cache, in the same round trip that fetches the tile's own codes), takes their distinct values through a hash set
+// in LDS, orders the few hundred that are left (blocks of 64 in registers, places by lower bounds: ef_seed_sort's own scheme) and goes
+// on with :106-111 / :85-105 / :209-210 on an array in LDS.  The work is redundant -- T tiles each read T records -- which is why
+// it is only taken up to kOwnMaxTiles tiles (T x T x 32 B = 33 MB of cache reads at the limit); no workgroup waits for another one,
+// the launch boundary behind ef_classify is the only synchronisation (a single cooperative launch was priced and measured
+// instead of built: DESIGN.md section 3, profiles/history/r06_single_launch_*).  Only the SET of seeds matters downstream
+// (np.sort(list(oneps_set)), :107): candidate order, repeats and the neighbour rule of ef_seed_sort's gather are immaterial.
+// More than kOwnKeys distinct seeds in a contig (an unsorted VCF over thousands of phase sets): the tile answers its few
+// questions -- is this PS a seed, which seed is nearest -- by walking the contig's entries where they lie.  The ascending array
+// the ABI can hand out (duet_ef_get_seed_ps, duet_ef_stats.n_seed_ps) is made on demand by ef_seed_sort from the same entries.
+constexpr uint32_t kOwnMaxTiles = 1024;
+constexpr uint32_t kOwnTab = 4096;                 // hash-set slots (open addressing)
+constexpr uint32_t kOwnKeys = 2048;                // distinct seeds ordered in LDS
+
+// what the array-free walk needs of the kernel's arguments, by value: the walk is a rare path behind a real call, and a call that
+// took the 600-byte argument block by reference would make EVERY launch copy that block to scratch memory first
+struct OwnArgs {
+    const ulonglong4 *recs;
+    const uint64_t *seed_ent, *read_tag;
+    const uint32_t *cand_pos, *cand_off, *cand_svread, *cand_refread, *mark_read, *c2rec;
+    uint32_t *out_ps, *status;
+    uint8_t *out_pred;
+    uint32_t c_lo, c_hi;
+};
+
+// f(ps) for every seed entry of contig [c_lo, c_hi), tiles dealt out with a stride
+template <class F>
+__device__ __forceinline__ void own_each_entry(const ulonglong4 *recs, const uint64_t *seed_ent, uint32_t c_lo, uint32_t c_hi, uint32_t first,
+                                               uint32_t stride, F f)
+{
+    const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
+    for (uint32_t b = b_lo + first; b <= b_hi; b += stride) {
+        const ulonglong4 rec = recs[b];
+        const uint32_t cnt = (uint32_t)rec.x;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint64_t e = j == 0 ? rec.y : (j == 1 ? rec.z : (j == 2 ? rec.w : seed_ent[(size_t)b * kCandPerBlock + j]));
+            const uint32_t c = (uint32_t)(e >> 32);
+            if (c >= c_lo && c < c_hi) f((uint32_t)e);
+        }
+    }
+}
+
+// the two questions without an array: the thread walks all entries of the contig (rare: see above)
+__device__ __forceinline__ uint32_t own_nearest_walk(const OwnArgs &a, uint32_t pos)
+{
+    uint32_t best = 0;
+    int64_t bd = -1;
+    own_each_entry(a.recs, a.seed_ent, a.c_lo, a.c_hi, 0u, 1u, [&](uint32_t ps) {
+        const int64_t d = llabs((int64_t)pos - (int64_t)ps);
+        // nearest_ps: the left neighbour only when strictly nearer -- among equally near seeds the larger one
+        if (bd < 0 || d < bd || (d == bd && ps > best)) { bd = d; best = ps; }
+    });
+    return best;
+}
+__device__ __forceinline__ bool own_member_walk(const OwnArgs &a, uint32_t key)
+{
+    bool hit = false;
+    own_each_entry(a.recs, a.seed_ent, a.c_lo, a.c_hi, 0u, 1u, [&](uint32_t ps) { hit = hit || ps == key; });
+    return hit;
+}
+
+template <class F>
+__device__ __forceinline__ void own_each_tag(const OwnArgs &a, uint32_t b, uint32_t e, F f)
+{
+    for (uint32_t m = b; m < e; ++m) {
+        const uint32_t r = a.mark_read[m];
+        f(r == kEmpty ? kUntagged : a.read_tag[r]);
+    }
+}
+
+// one candidate of a contig whose seeds did not fit the LDS set (finalize_candidate's logic, array-free; the contig has seeds)
+__device__ __noinline__ void finalize_candidate_walk(OwnArgs a, uint32_t c, uint32_t code, uint32_t ps_in)
+{
+    if (code & kDivZero) {
+        atomicOr(&a.status[0], 1u);
+        a.out_pred[c] = 0;
+        a.out_ps[c] = 0;
+        return;
+    }
+    const uint32_t c_pos = a.cand_pos[c];
+    if (code & (kClass2 | kClass2Slow)) {
+        Vote v = {0, 0, 0, 0, 0, 0};
+        uint32_t ps = 0;
+        const uint32_t mb = a.cand_off[c], me = a.cand_off[c + 1];
+        if (code & kClass2) {
+            const uint32_t *rec = a.c2rec + (size_t)ps_in * kC2Words;
+            v.allhap = rec[0];
+            const uint32_t ng = rec[1];
+            uint32_t best = 0;
+            for (uint32_t k = 0; k < (uint32_t)kC2Groups; ++k) {
+                const uint32_t *g = rec + 2 + 6 * k;
+                if (k < ng && g[1] > best && own_member_walk(a, g[0])) {
+                    best = g[1];
+                    ps = g[0];
+                    v.hap1 = g[2]; v.hap2 = g[3];
+                    v.t1 = g[4]; v.t2 = g[5];
+                    v.hap0 = v.allhap - v.hap1 - v.hap2;       // only with a winner (:105)
+                }
+            }
+        } else {                                               // (class2_from_marks, membership by walking)
+            uint32_t best = 0;
+            own_each_tag(a, mb, me, [&](uint64_t t) {
+                if (t != kUntagged && tag_pc(t) <= kPcMax) ++v.allhap;
+            });
+            uint32_t done_ps = kEmpty;
+            own_each_tag(a, mb, me, [&](uint64_t t) {
+                if (t == kUntagged || tag_pc(t) > kPcMax) return;
+                const uint32_t g = tag_ps(t);
+                if (g == done_ps || (g == ps && best)) return;
+                if (!own_member_walk(a, g)) return;            // :91
+                uint32_t n = 0, n1 = 0, n2 = 0;
+                uint64_t s1 = 0, s2 = 0;
+                own_each_tag(a, mb, me, [&](uint64_t u) {
+                    if (u == kUntagged || tag_pc(u) > kPcMax || tag_ps(u) != g) return;
+                    ++n;
+                    const uint32_t hap = tag_hap(u);
+                    if (hap == 1) { ++n1; s1 += tag_pc(u); }
+                    else if (hap == 2) { ++n2; s2 += tag_pc(u); }
+                });
+                done_ps = g;
+                if (n > best) {                                // strict: the first-seen group wins ties (:101)
+                    best = n; ps = g;
+                    v.hap1 = n1; v.hap2 = n2; v.t1 = s1; v.t2 = s2;
+                    v.hap0 = v.allhap - n1 - n2;
+                }
+            });
+        }
+        if (v.hap1 == 0 && v.hap2 == 0) ps = own_nearest_walk(a, c_pos);                 // :106
+        a.out_pred[c] = (uint8_t)decide(2, v, me - mb, a.cand_svread[c], a.cand_refread[c]);
+        a.out_ps[c] = ps;
+        return;
+    }
+    a.out_pred[c] = (uint8_t)(code & 3u);
+    a.out_ps[c] = own_nearest_walk(a, c_pos);
+}
+
+__global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
+{
+    __shared__ uint32_t s_tab[kOwnTab];                        // the hash set; afterwards the ascending array
+    __shared__ uint32_t s_key[kOwnKeys];                       // the distinct seeds, compacted, then in sorted blocks of 64
+    __shared__ uint32_t s_part[256 / 64];
+    __shared__ uint32_t s_ndist, s_over;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    STAMP(2, 0);
+    if (blockIdx.x == 0 && tid == 0) p.status[1] = 0;          // the summary pool's counter, for the next run's ef_classify
+    const uint32_t n_cands = p.C;
+    const uint32_t c0 = blockIdx.x * 256u, c = c0 + tid;
+    const bool live = c < n_cands;
+    const uint32_t last = min(c0 + 255u, n_cands - 1);
+    uint32_t lo = 0, hi = p.n_small;                           // the last k with ctg_small[k] <= c0 (scalar unit, no memory)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p.ctg_small[mid] <= c0) lo = mid; else hi = mid;
+    }
+    const uint32_t keys_cap = (p.dbg & DUET_DBG_EF_OWN_SMALLTAB) ? 8u : kOwnKeys;
+    const ulonglong4 *recs = reinterpret_cast<const ulonglong4 *>(p.blk_rec);
+    // ONE round trip in front of everything: the candidate's code, PS and position (a candidate that needs the nearest seed
+    // would fetch its position one trip later), and -- below -- up to four tiles' seed records of the first contig
+    const uint8_t code = live ? p.out_pred[c] : 0;
+    const uint32_t ps_in = live ? p.out_ps[c] : 0;
+    const uint32_t c_pos = live ? p.cand_pos[c] : 0;
+    for (uint32_t k = lo; k < p.n_small && p.ctg_small[k] <= last; ++k) {
+        const uint32_t c_lo = p.ctg_small[k], c_hi = p.ctg_small[k + 1];
+        if (c_lo == c_hi) continue;
+        // ---- the contig's distinct seeds ---------------------------------------------------------
+        const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
+        ulonglong4 rec[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t b = b_lo + tid + 256u * i;
+            rec[i] = recs[b <= b_hi ? b : b_lo];               // (loads in flight while the table is cleared)
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kOwnTab / 256u; ++i) s_tab[tid + 256u * i] = kEmpty;
+        if (tid == 0) { s_ndist = 0; s_over = 0; }
+        __syncthreads();
+        STAMP(2, 1);
+        auto insert = [&](uint64_t e) {
+            const uint32_t cc = (uint32_t)(e >> 32), key = (uint32_t)e;        // (a PS is at most 2^32 - 2: kEmpty is free)
+            if (cc < c_lo || cc >= c_hi) return;
+            uint32_t h = (key * 2654435761u) >> 20;
+            for (uint32_t probes = 0; probes < kOwnTab; ++probes) {
+                const uint32_t old = atomicCAS(&s_tab[h], kEmpty, key);
+                if (old == kEmpty) {
+                    if (atomicAdd(&s_ndist, 1u) >= keys_cap) s_over = 1;          // (whether this happens depends on the SET only)
+                    break;
+                }
+                if (old == key) break;
+                h = (h + 1u) & (kOwnTab - 1u);
+            }
+        };
+        auto tile = [&](uint32_t b, const ulonglong4 &r) {
+            const uint32_t cnt = (uint32_t)r.x;
+            if (cnt > 0) insert(r.y);
+            if (cnt > 1) insert(r.z);
+            if (cnt > 2) insert(r.w);
+            for (uint32_t j = 3; j < cnt; ++j) insert(p.seed_ent[(size_t)b * kCandPerBlock + j]);
+        };
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t b = b_lo + tid + 256u * i;
+            if (b <= b_hi) tile(b, rec[i]);
+        }
+        for (uint32_t b = b_lo + tid + 1024u; b <= b_hi; b += 256u) tile(b, recs[b]);      // (more than 1024 tiles: DUET_DBG_EF_OWN_ALL only)
+        __syncthreads();
+        STAMP(2, 2);
+        const uint32_t u = s_ndist;
+        const bool over = s_over != 0 || u > keys_cap;
+        const bool mine = live && c >= c_lo && c < c_hi;
+        if (!over && u != 0) {
+            // compact the set -- sixteen slots per thread, 256 apart (neighbouring lanes read neighbouring words; the order of a set is
+            // free) --, order the values: every wavefront orders blocks of 64 in its registers, a value's place is the sum of its
+            // lower bounds in all blocks (its own included: the values are distinct)
+            uint32_t mv[kOwnTab / 256u], cnt = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kOwnTab / 256u; ++j) {
+                mv[j] = s_tab[tid + 256u * j];
+                cnt += mv[j] != kEmpty ? 1u : 0u;
+            }
+            uint32_t x = cnt;                                               // inclusive running count inside the wavefront
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if ((int)lane >= d) x += y;
+            }
+            if (lane == 63) s_part[wave] = x;
+            __syncthreads();
+            uint32_t at = x - cnt;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) at += w < wave ? s_part[w] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < kOwnTab / 256u; ++j)
+                if (mv[j] != kEmpty) s_key[at++] = mv[j];
+            const uint32_t U = (u + 63u) & ~63u, nblk = U >> 6;
+            if (tid < U - u) s_key[u + tid] = kEmpty;                       // (pads the last block: sorts behind every seed)
+            __syncthreads();
+            STAMP(2, 3);
+            for (uint32_t b = wave; b < nblk; b += 4u) s_key[b * 64u + lane] = wave_sort64(s_key[b * 64u + lane], lane);
+            __syncthreads();
+            STAMP(2, 4);
+            for (uint32_t i = tid; i < U; i += 256u) {
+                const uint32_t me = s_key[i];
+                uint32_t rank = 0;
+                // (four blocks side by side: their seven dependent reads each overlap; plain scalars -- arrays of pointers ended up in scratch memory)
+                for (uint32_t b = 0; b < nblk; b += 4u) {
+                    const uint32_t *b0 = s_key + b * 64u, *b1 = s_key + min(b + 1u, nblk - 1u) * 64u;
+                    const uint32_t *b2 = s_key + min(b + 2u, nblk - 1u) * 64u, *b3 = s_key + min(b + 3u, nblk - 1u) * 64u;
+                    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+                    for (uint32_t st = 32; st > 0; st >>= 1) {
+                        p0 += b0[p0 + st - 1u] < me ? st : 0u;
+                        p1 += b1[p1 + st - 1u] < me ? st : 0u;
+                        p2 += b2[p2 + st - 1u] < me ? st : 0u;
+                        p3 += b3[p3 + st - 1u] < me ? st : 0u;
+                    }
+                    p0 += b0[p0] < me ? 1u : 0u;
+                    p1 += b1[p1] < me ? 1u : 0u;
+                    p2 += b2[p2] < me ? 1u : 0u;
+                    p3 += b3[p3] < me ? 1u : 0u;
+                    rank += p0 + (b + 1u < nblk ? p1 : 0u) + (b + 2u < nblk ? p2 : 0u) + (b + 3u < nblk ? p3 : 0u);
+                }
+                if (me != kEmpty) s_tab[rank] = me;                         // (the set is dead: its place holds the ascending array)
+            }
+            __syncthreads();
+        }
+        STAMP(2, 5);
+        // ---- this tile's candidates of contig k ------------------------------------------------------
+        if (mine) {
+            if (u == 0) {                                                   // :209-210
+                if (code != 0) p.out_pred[c] = 0;
+                if (ps_in != 0) p.out_ps[c] = 0;
+            } else if (code >= 4) {
+                if (over) {
+                    const OwnArgs a = {recs, p.seed_ent, p.read_tag, p.cand_pos, p.cand_off, p.cand_svread, p.cand_refread, p.mark_read, p.c2rec,
+                                       p.out_ps, p.status, p.out_pred, c_lo, c_hi};
+                    finalize_candidate_walk(a, c, code, ps_in);
+                } else if ((code & ~3u) == kNeedNearest) {                   // :106-111, the position already here
+                    p.out_pred[c] = code & 3;
+                    p.out_ps[c] = nearest_ps(s_tab, u, c_pos);
+                } else {
+                    finalize_candidate(p, c, code, ps_in, k, true, s_tab, u, 0u);
+                }
+            }
+        }
+        STAMP(2, 6);
+        __syncthreads();                                                    // s_tab / s_key are reused
+    }
+}
+
 // plan time: ctg_start[c] = 1 for the first candidate of every non-empty contig
 __global__ void plan_mark_starts(const uint32_t *ctg_off, uint32_t K, uint8_t *ctg_start)
 {
@@ -1625,6 +1922,7 @@ int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
     hipLaunchKernelGGL(plan_mark_starts, dim3((K + 255) / 256), dim3(256), 0, stream, ctx->d_ctg_off, K,
                        (uint8_t *)ctx->ws_start.ptr);
     HIP_TRY(ctx, hipGetLastError());
+    ctx->ef_seeds_stale = false;                               // (the saved kernel arguments describe the previous workspace)
     ctx->plan_off.assign(pr->cand_ctg_off, pr->cand_ctg_off + K + 1);
     ctx->plan_C = C;
     ctx->plan_stream = stream;
@@ -1815,12 +2113,23 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
         ctx->ev_used += 6;
     }
     const uint32_t blocks = (pr->n_cands + kCandPerBlock - 1) / kCandPerBlock;
+    // two launches where the problem is small (round 6): ef_finalize_own builds every tile's seed set itself, no ef_seed_sort
+    // (the diagnostic bits that select a variant of ef_seed_sort / ef_finalize select the three launches with it)
+    const uint32_t three = DUET_DBG_EF_OWN_OFF | DUET_DBG_EF_FIN_TPB2 | DUET_DBG_EF_FIN_TPB4 | DUET_DBG_EF_NO_SEED_HASH;
+    const bool own = p.n_small && !(ctx->dbg & three) && (blocks <= kOwnMaxTiles || (ctx->dbg & DUET_DBG_EF_OWN_ALL));
+    if (prof) ctx->ev_kmask.push_back(own ? 0x5 : 0x7);
     if (((uintptr_t)pr->mark_read & 15) == 0)
         hipExtLaunchKernelGGL(ef_classify<true>, dim3(blocks), dim3(kCandPerBlock), 0, stream, ev[0], ev[1], 0, p);
     else
         hipExtLaunchKernelGGL(ef_classify<false>, dim3(blocks), dim3(kCandPerBlock), 0, stream, ev[0], ev[1], 0, p);
-    hipExtLaunchKernelGGL(ef_seed_sort, dim3(pr->n_contigs), dim3(kSortThreads), 0, stream, ev[2], ev[3], 0, p);
-    {
+    if (own) {
+        hipExtLaunchKernelGGL(ef_finalize_own, dim3(blocks), dim3(256), 0, stream, ev[4], ev[5], 0, p);
+        ctx->ef_last_params.assign((const unsigned char *)&p, (const unsigned char *)&p + sizeof(p));
+        ctx->ef_last_stream = stream;
+        ctx->ef_seeds_stale = true;
+    } else {
+        ctx->ef_seeds_stale = false;
+        hipExtLaunchKernelGGL(ef_seed_sort, dim3(pr->n_contigs), dim3(kSortThreads), 0, stream, ev[2], ev[3], 0, p);
         // Tiles per workgroup: the per-workgroup costs (launch, the tile's contigs, the seeds into LDS) once per 512 / 1024
         // candidates where there are enough of them to fill the chip anyway -- measured (tools/gpu/r4_fin.sh), 1 / 2 / 4 tiles:
         // 1e5 candidates 6.3 / 8.5 / 11.2 us, 2e6 20.6 / 18.4 / 18.8 us, 2e7 127 / 91 / 75 us
@@ -1965,8 +2274,10 @@ int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats)
     const int nk = ctx->ev_mode == 2 ? DUET_N_KERNELS : 1;
     for (size_t r = 0; r < runs; ++r) {
         hipEvent_t *ev = &ctx->ev_pool[6 * r];
+        const unsigned mask = r < ctx->ev_kmask.size() ? ctx->ev_kmask[r] : 0x7u;      // (a kernel that did not run has no events: 0 us)
         HIP_TRY(ctx, hipEventSynchronize(ev[2 * nk - 1]));
         for (int i = 0; i < nk; ++i) {
+            if (!((mask >> i) & 1u)) continue;
             float ms = 0;
             HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
             acc[i] += ms;
@@ -1979,6 +2290,7 @@ int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats)
         for (int i = 0; i < DUET_N_KERNELS; ++i) stats->kernel_ms[i] = (float)(acc[i] / runs);
         stats->total_ms = (float)(tot / runs);
     }
+    ctx->ev_kmask.clear();
     stats->n_profiled_runs = (uint32_t)runs;
     ctx->ev_used = 0;
     return DUET_OK;
@@ -1989,6 +2301,8 @@ int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t 
     if (!ctx) return fail(nullptr, DUET_ERR_INVALID, "null context");
     if (contig + 1 >= ctx->plan_off.size()) return fail(ctx, DUET_ERR_INVALID, "contig out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc_m = duet_ef_materialise_seeds(ctx);
+    if (rc_m) return rc_m;
     HIP_TRY(ctx, hipDeviceSynchronize());
     uint32_t n = 0;
     HIP_TRY(ctx, hipMemcpy(&n, ctx->d_n_one + contig, 4, hipMemcpyDeviceToHost));
@@ -2000,6 +2314,19 @@ int duet_ef_get_seed_ps(duet_ctx *ctx, uint32_t contig, uint32_t *out, uint32_t 
 }
 
 }  // extern "C"
+
+// the ascending seed arrays (onebuf, n_one) of the last run, when that run was the two-launch one: ef_seed_sort on its seed entries
+int duet_ef_materialise_seeds(duet_ctx *ctx)
+{
+    if (!ctx->ef_seeds_stale || ctx->ef_last_params.size() != sizeof(Params)) return DUET_OK;
+    Params p;
+    memcpy(&p, ctx->ef_last_params.data(), sizeof(p));
+    hipLaunchKernelGGL(ef_seed_sort, dim3(p.K), dim3(kSortThreads), 0, ctx->ef_last_stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->ef_last_stream));
+    ctx->ef_seeds_stale = false;
+    return DUET_OK;
+}
 
 int duet_ef_validate(duet_ctx *ctx, const duet_ef_problem *pr) { return validate(ctx, pr, (const void *)1, (const void *)1); }
 
@@ -2052,6 +2379,7 @@ int duet_ef_run_host(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pred
     HIP_TRY(ctx, hipMemcpyAsync(out_ps, ctx->h_out[1].ptr, (size_t)C * 4, hipMemcpyDeviceToHost, s));
     if ((rc = duet_ef_check(ctx, s))) return rc;
     if (stats) {
+        if ((rc = duet_ef_materialise_seeds(ctx))) return rc;
         std::vector<uint32_t> n_one(pr->n_contigs);
         HIP_TRY(ctx, hipMemcpy(n_one.data(), ctx->d_n_one, sizeof(uint32_t) * pr->n_contigs, hipMemcpyDeviceToHost));
         uint32_t tot = 0;

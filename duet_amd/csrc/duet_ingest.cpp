@@ -4,6 +4,9 @@
 // mirrors upstream's exceptions) takes over.
 
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -174,6 +177,55 @@ struct NameTable {
     }
 };
 
+// A whole file in memory that nobody has touched before the readers do: malloc, not a vector (whose resize would write every page
+// from ONE thread first -- 30 ms per 100 MB), filled by `threads` readers with pread, each first-touching its own stretch.
+struct RawBuf {
+    char *p = nullptr;
+    size_t n = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { free(p); p = nullptr; n = 0; }
+};
+
+bool read_file_parallel(const char *path, RawBuf &buf, int threads)
+{
+    buf.clear();
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); return false; }
+    const size_t sz = (size_t)sb.st_size;
+    if (sz == 0) { close(fd); return true; }
+    buf.p = (char *)malloc(sz);
+    if (!buf.p) { close(fd); return false; }
+    buf.n = sz;
+    int T = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+    if (sz < (8u << 20)) T = 1;
+    std::vector<char> ok((size_t)T, 1);
+    auto work = [&](int t) {
+        size_t at = sz * (size_t)t / (size_t)T;
+        const size_t hi = sz * (size_t)(t + 1) / (size_t)T;
+        while (at < hi) {
+            const ssize_t got = pread(fd, buf.p + at, hi - at, (off_t)at);
+            if (got <= 0) { ok[(size_t)t] = 0; return; }
+            at += (size_t)got;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    close(fd);
+    for (char c : ok)
+        if (!c) { buf.clear(); return false; }
+    return true;
+}
+
 bool read_file(const char *path, std::vector<char> &buf)
 {
     FILE *f = fopen(path, "rb");
@@ -198,7 +250,7 @@ struct duet_ingest {
     std::vector<uint8_t> bam_has_aln;             // per contig: its BAM printed at least one alignment line (:30-33)
     std::string err;
     // VCF
-    std::vector<char> vcf;
+    RawBuf vcf;
     std::string vcf_path;                          // what `vcf` holds (duet_ingest_vcf_precount reads it first, parse reuses it)
     std::vector<uint8_t> skip;                     // per contig: its records are another rank's (duet_ingest_set_owned); empty = none
     std::vector<Span> contig_lines;               // first tokens containing '##contig=<ID='
@@ -752,6 +804,60 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     return DUET_INGEST_OK;
 }
 
+// Several contigs' BAMs at once (round 6).  A contig's tag table, tag words and "has alignments" flag are its own, so whole
+// contigs go to the workers -- the largest files first, a shared counter hands them out -- instead of one contig after the other with
+// the workers meeting at every stage of each (inflate, records, then ONE thread filling that contig's name table in file order: with
+// 24 contigs that serial part was what the BAM side cost).  With fewer contigs than workers every contig keeps `threads / n`
+// workers of its own.  SVIM-mode extraction appends to shared arrays in contig order: it takes the contigs one by one as before.
+// Returns the status of the first contig (in the caller's order) that failed, with that contig's message.
+int duet_ingest_add_bams(duet_ingest *g, int n, const int *contigs, const char *const *paths, int threads)
+{
+    if (!g || n < 0 || (n && (!contigs || !paths))) return DUET_INGEST_INVALID;
+    if (threads < 1) threads = 1;
+    if (n <= 1 || threads == 1 || g->extract) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = duet_ingest_add_bam(g, contigs[i], paths[i], threads);
+            if (rc) return rc;
+        }
+        return DUET_INGEST_OK;
+    }
+    for (int i = 0; i < n; ++i)
+        if (contigs[i] < 0 || contigs[i] >= (int)g->contigs.size() || !paths[i]) return DUET_INGEST_INVALID;
+    std::vector<int> order((size_t)n);
+    std::vector<long long> bytes((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        order[(size_t)i] = i;
+        struct stat sb;
+        if (stat(paths[i], &sb) == 0) bytes[(size_t)i] = (long long)sb.st_size;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bytes[(size_t)a] > bytes[(size_t)b]; });
+    const int outer = n < threads ? n : threads, inner = threads / outer > 1 ? threads / outer : 1;
+    std::vector<int> rcs((size_t)n, DUET_INGEST_OK);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int j = next.fetch_add(1);
+            if (j >= n) return;
+            const int i = order[(size_t)j];
+            rcs[(size_t)i] = duet_ingest_add_bam(g, contigs[i], paths[i], inner);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < outer; ++t) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
+    for (int i = 0; i < n; ++i)
+        if (rcs[(size_t)i]) {
+            // (failing contigs may have written the message side by side: the first one's again, alone)
+            g->tables[(size_t)contigs[i]] = NameTable();
+            g->tags[(size_t)contigs[i]].clear();
+            return duet_ingest_add_bam(g, contigs[i], paths[i], threads);
+        }
+    return DUET_INGEST_OK;
+}
+
 namespace {
 
 struct Rec { Span tok[10]; };
@@ -820,35 +926,91 @@ int vcf_begin(duet_ingest *g, const char *path, int threads, VcfStage &st)
     g->threads = threads > 0 ? threads : 1;
     if (g->alias) return decline("contig list names a contig twice");
     if (g->vcf_path != path || g->vcf.empty()) {
-        if (!read_file(path, g->vcf)) { st.err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+        if (!read_file_parallel(path, g->vcf, threads)) { st.err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
         g->vcf_path = path;
     }
     const char *d = g->vcf.data();
     const size_t n = g->vcf.size();
-    if (n && memchr(d, 0, n)) return decline("NUL byte in the VCF");
-    lap("read+ascii");
+    lap("read");
     const int K = (int)g->contigs.size();
     int T = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
     if (n < (1u << 20)) T = 1;
 
     // ---- lines (universal newlines: \n, \r, \r\n) ------------------------------------------------
+    // Every worker scans its stretch of the file once: NUL bytes, carriage returns, and the places of the '\n' (round 6: the read,
+    // these checks and the line index were ONE thread's 140 ms per 4e6 marks, the largest serial piece of the ingest).  A file
+    // with a '\r' anywhere takes the serial scan below (universal newlines cut lines in three ways).
     std::vector<size_t> line_lo, line_hi;
     {
-        const bool has_cr = n && memchr(d, '\r', n);
-        size_t p = 0;
-        while (p < n) {
-            size_t e;
-            if (!has_cr) {
-                const char *q = (const char *)memchr(d + p, '\n', n - p);
-                e = q ? (size_t)(q - d) : n;
-            } else {
-                e = p;
-                while (e < n && d[e] != '\n' && d[e] != '\r') ++e;
+        std::vector<std::vector<size_t>> nl((size_t)T);
+        std::vector<char> has_nul((size_t)T, 0), has_cr_t((size_t)T, 0);
+        auto scan = [&](int t) {
+            const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+            if (lo >= hi) return;
+            if (memchr(d + lo, 0, hi - lo)) { has_nul[(size_t)t] = 1; return; }
+            if (memchr(d + lo, '\r', hi - lo)) { has_cr_t[(size_t)t] = 1; return; }
+            std::vector<size_t> &v = nl[(size_t)t];
+            v.reserve((hi - lo) / 256 + 16);
+            size_t p = lo;
+            while (p < hi) {
+                const char *q = (const char *)memchr(d + p, '\n', hi - p);
+                if (!q) break;
+                v.push_back((size_t)(q - d));
+                p = (size_t)(q - d) + 1;
             }
-            line_lo.push_back(p);
-            line_hi.push_back(e);
-            p = e + 1;
-            if (has_cr && e < n && d[e] == '\r' && p < n && d[p] == '\n') ++p;
+        };
+        {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; ++t) pool.emplace_back(scan, t);
+            scan(0);
+            for (auto &th : pool) th.join();
+        }
+        for (char c : has_nul)
+            if (c) return decline("NUL byte in the VCF");
+        bool has_cr = false;
+        for (char c : has_cr_t) has_cr = has_cr || c;
+        if (!has_cr) {
+            size_t total = 0;
+            std::vector<size_t> base((size_t)T + 1, 0);
+            for (int t = 0; t < T; ++t) { base[(size_t)t] = total; total += nl[(size_t)t].size(); }
+            // (the last line may lack its newline: the last newline over all stretches says)
+            size_t last_nl = (size_t)-1;
+            for (int t = T - 1; t >= 0 && last_nl == (size_t)-1; --t)
+                if (!nl[(size_t)t].empty()) last_nl = nl[(size_t)t].back();
+            const bool open_tail = n && (last_nl == (size_t)-1 || last_nl + 1 < n);
+            const size_t L0 = total + (open_tail ? 1 : 0);
+            line_lo.resize(L0);
+            line_hi.resize(L0);
+            auto fill = [&](int t) {
+                const std::vector<size_t> &v = nl[(size_t)t];
+                size_t at = base[(size_t)t];
+                // the line that ends at v[i] starts behind the newline before it (the previous stretch's last one for i = 0)
+                size_t prev = (size_t)-1;
+                for (int u = t - 1; u >= 0 && prev == (size_t)-1; --u)
+                    if (!nl[(size_t)u].empty()) prev = nl[(size_t)u].back();
+                for (size_t i = 0; i < v.size(); ++i, ++at) {
+                    line_lo[at] = prev + 1;            // ((size_t)-1 + 1 == 0: the file's first line)
+                    line_hi[at] = v[i];
+                    prev = v[i];
+                }
+            };
+            {
+                std::vector<std::thread> pool;
+                for (int t = 1; t < T; ++t) pool.emplace_back(fill, t);
+                fill(0);
+                for (auto &th : pool) th.join();
+            }
+            if (open_tail) { line_lo[total] = last_nl + 1; line_hi[total] = n; }
+        } else {
+            size_t p = 0;
+            while (p < n) {
+                size_t e = p;
+                while (e < n && d[e] != '\n' && d[e] != '\r') ++e;
+                line_lo.push_back(p);
+                line_hi.push_back(e);
+                p = e + 1;
+                if (e < n && d[e] == '\r' && p < n && d[p] == '\n') ++p;
+            }
         }
     }
     const size_t L = line_lo.size();
@@ -1344,7 +1506,7 @@ int duet_ingest_vcf_precount(duet_ingest *g, const char *path, uint64_t *n_recor
 {
     if (!g || !path || !n_records || !n_bytes) return DUET_INGEST_INVALID;
     if (g->vcf_path != path || g->vcf.empty()) {
-        if (!read_file(path, g->vcf)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
+        if (!read_file_parallel(path, g->vcf, g->threads)) { g->err = std::string("cannot read ") + path; return DUET_INGEST_IO; }
         g->vcf_path = path;
     }
     const char *d = g->vcf.data();

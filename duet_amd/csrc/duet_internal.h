@@ -55,7 +55,13 @@ struct duet_ctx {
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};
     // profiling events: 6 per run
     std::vector<hipEvent_t> ev_pool;
+    std::vector<uint8_t> ev_kmask;         // per profiled run: the kernels that ran (bit i = kernel i; the two-launch E/F has no ef_seed_sort)
     size_t ev_used = 0;
+    // the two-launch E/F (ef_finalize_own) leaves no ascending seed arrays behind: what duet_ef_get_seed_ps / duet_ef_stats need is
+    // made on demand by ef_seed_sort from the same seed entries, with the last run's kernel arguments on the last run's stream
+    std::vector<unsigned char> ef_last_params;
+    hipStream_t ef_last_stream = nullptr;
+    bool ef_seeds_stale = false;
     bool pending_check = false;
 };
 
@@ -84,6 +90,8 @@ int duet_ef_plan_on_device_prepare(duet_ctx *ctx, uint32_t K, uint32_t c_max, hi
 int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint32_t c_max, const uint32_t *d_n_cands,
                                   const uint32_t *d_ctg_off /* or null ... */, const uint16_t *d_cand_contig /* ... then the candidates' contig column */,
                                   uint8_t *out_pred, uint32_t *out_ps, hipStream_t stream, bool planned);
+
+int duet_ef_materialise_seeds(duet_ctx *ctx);
 
 // argument checks of an E/F problem (host or device arrays alike: pointers and counts only)
 int duet_ef_validate(duet_ctx *ctx, const duet_ef_problem *pr);

@@ -60,6 +60,7 @@ def load():
         lib.duet_ingest_error.restype = ctypes.c_char_p
         lib.duet_ingest_error.argtypes = [ctypes.c_void_p]
         lib.duet_ingest_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        lib.duet_ingest_add_bams.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
         lib.duet_ingest_parse_vcf.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         lib.duet_ingest_parse_vcf_begin.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         lib.duet_ingest_parse_vcf_finish.argtypes = [ctypes.c_void_p]
@@ -175,7 +176,7 @@ class NativeIngest(object):
             t_bam = max(1, int(thread) - t_vcf)
         first_half = threading.Thread(target=lib.duet_ingest_parse_vcf_begin, args=(h, vcf_path.encode(), t_vcf))
         first_half.start()
-        with_bam = []
+        with_bam, paths = [], []
         bam_ok = True
         try:
             for k, c in enumerate(chrom_list):
@@ -183,11 +184,15 @@ class NativeIngest(object):
                     continue
                 for cand in (sam_home + 'chr' + c + '.bam', sam_home + c + '.bam'):
                     if os.path.exists(cand):
-                        bam_ok = lib.duet_ingest_add_bam(h, k, cand.encode(), t_bam) == OK
                         with_bam.append(k)
+                        paths.append(cand.encode())
                         break
-                if not bam_ok:
-                    break
+            if with_bam:
+                # every contig has a tag dict of its own (sv_phasing_fn.py:15-29): the contigs go to the workers whole
+                # (duet_ingest_add_bams), not one after the other
+                ks = (ctypes.c_int * len(with_bam))(*with_bam)
+                ps = (ctypes.c_char_p * len(paths))(*paths)
+                bam_ok = lib.duet_ingest_add_bams(h, len(with_bam), ks, ps, t_bam) == OK
         finally:
             first_half.join()                       # (also on an exception: nobody else owns the handle it works on)
         if not bam_ok:

@@ -147,6 +147,10 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 #define DUET_DBG_EF_WALK_R4 0x200000u    /* E/F: ef_classify's lane walk with round 4's loop body (35 vector instructions per mark) instead of round 5's shorter one */
 #define DUET_DBG_EF_FP_DECIDE 0x400000u  /* E/F: ef_classify takes every class-0 / class-1 decision through the binary64 expressions (rounds 1-4) instead of the
                                             integer form with the binary64 fallback */
+#define DUET_DBG_EF_OWN_OFF 0x800000u     /* E/F: three launches (ef_classify, ef_seed_sort, ef_finalize) at every size; default up to 1024 tiles of 256 candidates
+                                          * and 64 contigs: two -- every finalize tile builds its contig's seed set itself (ef_finalize_own) */
+#define DUET_DBG_EF_OWN_ALL 0x1000000u    /* ... the two launches at every size (up to 64 contigs) */
+#define DUET_DBG_EF_OWN_SMALLTAB 0x2000000u /* ... and their seed set in LDS holds 8 distinct seeds (default 2048): contigs with more take the array-free walk */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */

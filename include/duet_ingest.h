@@ -47,6 +47,10 @@ const char *duet_ingest_error(const duet_ingest *ing);
 
 /* Tag dict of contig k from a BAM file (built-in BGZF/BAM reader, `threads` inflate workers). */
 int duet_ingest_add_bam(duet_ingest *ing, int contig, const char *bam_path, int threads);
+/* The same for n contigs in one call, `threads` workers in all (src/duet/sv_phasing_fn.py:15-29 is a loop over independent contigs:
+ * every contig has a dict of its own): whole contigs are dealt to the workers, the largest files first; with fewer contigs than
+ * workers each contig keeps threads / n of them.  Returns the status of the first contig in the caller's order that failed. */
+int duet_ingest_add_bams(duet_ingest *ing, int n, const int *contigs, const char *const *bam_paths, int threads);
 
 /* 1 when the BAM added for contig k held at least one alignment (the reference logs '  signatures extracted from k'
  * then, '  no signature from k' otherwise: src/duet/sv_phasing_fn.py:30-33), 0 when it held none or none was added. */

@@ -429,3 +429,50 @@ def test_idempotent_and_linear_in_contigs(ctx):
     C = soa1.n_cands
     assert np.array_equal(p2[:C], p1) and np.array_equal(p2[C:], p1)
     assert np.array_equal(s2[:C], s1) and np.array_equal(s2[C:], s1)
+
+
+OWN_OFF, OWN_ALL, OWN_SMALLTAB = 0x800000, 0x1000000, 0x2000000     # include/duet_ef.h: DUET_DBG_EF_OWN_OFF / _ALL / _SMALLTAB
+
+
+def test_two_launches_three_launches_and_the_array_free_walk_agree(ctx):
+    """Round 6: up to 1024 tiles and 64 contigs step E/F is TWO launches -- every finalize tile builds its contig's seed set itself
+    (ef_finalize_own: hash set + ordered blocks in LDS) -- beyond that the three of rounds 1-5.  Every case through: the default,
+    the three launches forced, the two launches forced (also on the large case), and the two launches with a seed set of 8 entries
+    (contigs with more distinct seeds answer "is this PS a seed" / "which seed is nearest" by walking the contig's seed entries);
+    the seed arrays the ABI hands out (made on demand after a two-launch run) are the same in all of them."""
+    cases = [soa_fuzz.random_soa(6100 + s, n_contigs=1 + s % 5, sorted_pos=bool(s % 3)) for s in range(6)]
+    cases.append(soa_fuzz.random_soa(6200, n_contigs=40, cands_per_contig=(0, 400), reads_per_contig=(5, 300), n_ps=(1, 9)))     # tiles over many contigs
+    cases.append(soa_fuzz.random_soa(6201, n_contigs=64, cands_per_contig=(0, 40), reads_per_contig=(5, 30)))                     # K = 64: the last two-launch K
+    cases.append(soa_fuzz.random_soa(6202, n_contigs=65, cands_per_contig=(0, 40), reads_per_contig=(5, 30)))                     # K = 65: three launches
+    for n_ps in (3, 500, 2300, 6000):                                      # 2300 / 6000 distinct seeds: beyond the set in LDS by themselves
+        cases.append(soa_fuzz.random_soa(6300 + n_ps, n_contigs=2, cands_per_contig=(9000, 14000), reads_per_contig=(4000, 6000),
+                                         n_ps=(n_ps, n_ps), ps_spread=3000000, deg=(1, 6), empty_contig_rate=0, no_seed_contig_rate=0,
+                                         sorted_pos=False))
+    cases.append(soa_fuzz.random_soa(6400, n_contigs=2, cands_per_contig=(2000, 3000), reads_per_contig=(60, 90), n_ps=(9, 14), deg=(4, 30),
+                                     empty_contig_rate=0, no_seed_contig_rate=0))                  # >= 3 voter groups: the marks-based vote
+    cases.append(soa_fuzz.random_soa(6401, n_contigs=2, cands_per_contig=(1500, 2500), reads_per_contig=(30, 60), n_ps=(2, 2), deg=(4, 16),
+                                     empty_contig_rate=0, no_seed_contig_rate=0))                  # the summary pool, exhausted
+    cases.append(soa_fuzz.random_soa(6402, n_contigs=3, allow_divzero=True, empty_contig_rate=0, no_seed_contig_rate=0))
+    cases.append(engine.soa_from_synth(H.case_contigs('config2', 1)))
+    cases.append(engine.soa_from_synth(synth.bench_genome(4000000, 5)))   # 24 contigs, 4e5 candidates = 1563 tiles: three launches by default
+    for i, soa in enumerate(cases):
+        supp = 0 if i == len(cases) - 3 else 2
+        seeds = None
+        for dbg in (0, OWN_OFF, OWN_ALL, OWN_ALL | OWN_SMALLTAB):
+            ctx.set_debug(dbg)
+            try:
+                rc, want_pred, want_ps = c_oracle.ef(soa, 50, supp)
+                if rc != 0:
+                    with pytest.raises(ZeroDivisionError):
+                        ctx.run_host(soa, 50, supp)
+                    continue
+                check_against_c_oracle(ctx, soa, 50, supp)
+                if soa.n_contigs <= 8:
+                    got = [ctx.seed_ps(k).copy() for k in range(soa.n_contigs)]
+                    if seeds is None:
+                        seeds = got
+                    assert all(np.array_equal(a, b) for a, b in zip(got, seeds)), (i, dbg)
+                if supp == 2 and soa.n_cands < 200000:
+                    check_against_c_oracle(ctx, soa, 0, 0)
+            finally:
+                ctx.set_debug(0)

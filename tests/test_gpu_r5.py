@@ -51,6 +51,23 @@ empty = soa_fuzz.random_soa(1, n_contigs=1, empty_contig_rate=1)
 assert empty.n_cands == 0
 out = g.ef_allgather(empty, 50, 2, np.zeros(0, np.uint32), 2, 100)
 assert out.shape == (1, comm.block_bytes(100, 2)) and not out.any()
+# round 6: what RCCL itself says about the communicator, and the rank-stamped pattern through it
+info = g.info()
+assert info["rank"] == 0 and info["world"] == 1 and info["rccl_ranks"] == 1 and info["rccl_rank"] == 0 and info["rccl_device"] == 0, info
+g.selftest(4096)
+# a rank whose own part fails (a null array with a non-zero count) still contributes a block -- status word with the top bit -- and
+# then reports its own error (ADVICE round 5: it used to be dereferenced before any check)
+bad = soa_fuzz.random_soa(7001, n_contigs=2)
+prob, keep = _lib.problem_from_arrays(bad, 50, 2)
+prob.cand_pos = None
+import ctypes
+nm = bad.n_cands + 5
+outb = np.empty((1, comm.block_bytes(nm, 0)), dtype=np.uint8)
+rc = ctx.lib.duet_comm_ef_allgather(g.handle, ctypes.byref(prob), None, 0, nm, outb.ctypes.data_as(ctypes.c_void_p))
+assert rc == _lib.DUET_ERR_INVALID and "null array" in ctx.last_error(), (rc, ctx.last_error())
+rbb = dist.record_bytes(nm)
+st = int(outb[0, rbb:rbb + 4].view(np.uint32)[0])
+assert st == (0x80000000 | (-_lib.DUET_ERR_INVALID)) and not outb[0, :rbb].any(), hex(st)
 g.close()
 ctx.close()
 print("EF GATHER OK")

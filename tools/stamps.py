@@ -10,6 +10,8 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libduet_ef_stamps.
 from duet_amd.devmem import DeviceProblem
 
 ctx = _lib.Context(0)
+if '3k' in sys.argv:
+    ctx.set_debug(0x800000)        # DUET_DBG_EF_OWN_OFF: the three launches of rounds 1-5
 lib = _lib.load()
 lib.duet_dbg_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 which = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
@@ -45,7 +47,7 @@ st = buf[:3 * 65536 * 8].reshape(3, 65536, 8).astype(np.int64)
 t0 = st[0][st[0][:, 0] > 0][:, 0].min()
 names = [['start', 'offsets', 'staged', 'consumed', 'loop_end', 'decided', 'end'],
          ['start', 'gathered', 'sorted', 'end', 'recs', 'counted', 'written', 'runs'],
-         ['start', 'meta', 'staged']]
+         ['start', 'meta', 'staged'] if '3k' in sys.argv else ['start', 'cleared', 'inserted', 'compacted', 'sorted64', 'ranked', 'end']]
 for k in range(3):
     blk = st[k][st[k][:, 0] > 0]
     nb = len(blk)

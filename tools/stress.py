@@ -27,8 +27,9 @@ for i in range(n_ef):
     rc, wp, ws = c_oracle.ef(soa, sl, sr)
     if rc:
         continue
-    # (E/F paths in turn: default; ef_finalize with two / four tiles per workgroup; the seed sort without its hash set)
-    ctx.set_debug([0, 0x20, 0x80, 0x40][i % 4])
+    # (E/F paths in turn: default = two launches, every finalize tile with its own seed set; that with a seed set of 8 entries -- the
+    # array-free walk; three launches; ef_finalize with two / four tiles per workgroup; the seed sort without its hash set)
+    ctx.set_debug([0, 0x3000000, 0x800000, 0x20, 0x80, 0x40][i % 6])
     p, s = ctx.run_host(soa, sl, sr)
     ctx.set_debug(0)
     if not (np.array_equal(p, wp) and np.array_equal(s, ws)):
