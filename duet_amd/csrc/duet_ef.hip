@@ -208,7 +208,8 @@ struct Params {
     const uint8_t *ctg_start;         // [C]   1 where a candidate is the first of its contig
     const uint32_t *blk_ctg;          // [B]   contig of candidate 256*b
     // workspace (per run)
-    uint64_t *blk_rec;                // [B][4] per classify block: {entry count, entry 0, entry 1, entry 2}
+    uint64_t *blk_rec;                // [B][8] per classify block, one 64-byte line: {entry count, entries 0 .. 6} (entries 3 .. also in seed_ent:
+                                      //        ef_seed_sort reads the first half, ef_finalize_own the line -- no dependent trip for a tile of up to seven)
     uint64_t *seed_ent;               // [B*256] entries 3.. of a block: (candidate << 32 | seed PS)
     uint32_t *onebuf;                 // [C+K] per contig at ctg_off[k]+k: {n, ascending distinct seed PS...}
     uint32_t one_cap;                 // C + K
@@ -460,6 +461,13 @@ __device__ __forceinline__ void consume_heavy(CandState &st, const uint64_t *s_t
     }
 }
 
+// a tile's 64-byte record: [b] = its first half {count, entries 0 .. 2}, second(b) = entries 3 .. 6
+struct TileRecs {
+    const ulonglong4 *p;
+    __device__ __forceinline__ ulonglong4 operator[](uint32_t b) const { return p[2 * (size_t)b]; }
+    __device__ __forceinline__ ulonglong4 second(uint32_t b) const { return p[2 * (size_t)b + 1]; }
+};
+
 struct TileShared {
     uint32_t seed[kCandPerBlock];
     uint32_t wcnt[kCandPerBlock / 64], wlast[kCandPerBlock / 64], wclean[kCandPerBlock / 64];
@@ -585,10 +593,10 @@ __device__ __forceinline__ void seeds_tile(const Params &p, TileShared &sh, uint
         // entries in a single round trip); the rest go to the tile's overflow slots
         const uint32_t at = before + (uint32_t)__popcll(mask & (upto >> 1));
         const uint64_t e = ((uint64_t)c << 32) | seed;
-        if (at < 3) p.blk_rec[(size_t)tile * 4 + 1 + at] = e;
-        else p.seed_ent[(size_t)tile * kCandPerBlock + at] = e;
+        if (at < 7) p.blk_rec[(size_t)tile * 8 + 1 + at] = e;
+        if (at >= 3) p.seed_ent[(size_t)tile * kCandPerBlock + at] = e;
     }
-    if (tid == 0) p.blk_rec[(size_t)tile * 4] = total;
+    if (tid == 0) p.blk_rec[(size_t)tile * 8] = total;
 }
 
 // ---- staging pieces: 4 * kStageIt marks per thread and pass, kStageIt x (16-byte index load -> 4 tag gathers) ----
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(kSortThreads) void ef_seed_sort(const Params p)
     auto entry = [&](uint32_t b, uint32_t j, const ulonglong4 &rec) -> uint64_t {
         return j == 0 ? rec.y : (j == 1 ? rec.z : (j == 2 ? rec.w : p.seed_ent[(size_t)b * kCandPerBlock + j]));
     };
-    const ulonglong4 *recs = reinterpret_cast<const ulonglong4 *>(p.blk_rec);
+    const TileRecs recs{reinterpret_cast<const ulonglong4 *>(p.blk_rec)};
     // records of my first tile and of the tile before it (whose last entry, if it belongs to this contig,
     // absorbs an equal first entry): both loads are independent -> one round trip
     ulonglong4 rec0 = {0, 0, 0, 0}, recp = {0, 0, 0, 0};
@@ -1274,8 +1282,10 @@ __device__ __forceinline__ void for_each_tag(const Params &p, uint32_t b, uint32
     }
 }
 
-// multi-PS vote straight from the marks (:85-105): only for candidates without a group summary
-__device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *one, uint32_t n_one, Vote &v, uint32_t &ps)
+// multi-PS vote straight from the marks (:85-105): only for candidates without a group summary.  mem(ps): is this PS a seed of
+// the contig (:91)
+template <class Mem>
+__device__ __forceinline__ void class2_from_marks_m(const Params &p, uint32_t c, Mem mem, Vote &v, uint32_t &ps)
 {
     const uint32_t b = p.cand_off[c], e = p.cand_off[c + 1];
     uint32_t best = 0;
@@ -1287,7 +1297,7 @@ __device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *o
         if (t == kUntagged || tag_pc(t) > kPcMax) return;
         const uint32_t g = tag_ps(t);
         if (g == done_ps || (g == ps && best)) return;
-        if (!is_member(one, n_one, g)) return;                 // :91
+        if (!mem(g)) return;                                   // :91
         // size and sums of g's group over the whole list; a later occurrence of an already
         // evaluated group reproduces the same n and cannot beat it (strict '>', :101)
         uint32_t n = 0, n1 = 0, n2 = 0;
@@ -1306,6 +1316,10 @@ __device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *o
             v.hap0 = v.allhap - n1 - n2;                       // only with a winner (:105)
         }
     });
+}
+__device__ void class2_from_marks(const Params &p, uint32_t c, const uint32_t *one, uint32_t n_one, Vote &v, uint32_t &ps)
+{
+    class2_from_marks_m(p, c, [&](uint32_t g) { return is_member(one, n_one, g); }, v, ps);
 }
 
 // one candidate's part of ef_finalize (everything after the tile's seed array is staged)
@@ -1520,14 +1534,14 @@ __global__ __launch_bounds__(256) void ef_finalize(const Params p)
 // More than kOwnKeys distinct seeds in a contig (an unsorted VCF over thousands of phase sets): the tile answers its few
 // questions -- is this PS a seed, which seed is nearest -- by walking the contig's entries where they lie.  The ascending array
 // the ABI can hand out (duet_ef_get_seed_ps, duet_ef_stats.n_seed_ps) is made on demand by ef_seed_sort from the same entries.
-constexpr uint32_t kOwnMaxTiles = 1024;
-constexpr uint32_t kOwnTab = 4096;                 // hash-set slots (open addressing)
-constexpr uint32_t kOwnKeys = 2048;                // distinct seeds ordered in LDS
+constexpr uint32_t kOwnMaxTiles = 2048;            // (measured, tools/own_sweep.py: ahead up to ~1,600 tiles on the 24-contig genome, level at 3,100, behind beyond)
+constexpr uint32_t kOwnTab = 2048;                 // hash-set slots (open addressing; the hash takes the product's top 11 bits)
+constexpr uint32_t kOwnKeys = 1024;                // distinct seeds kept in LDS
 
 // what the array-free walk needs of the kernel's arguments, by value: the walk is a rare path behind a real call, and a call that
 // took the 600-byte argument block by reference would make EVERY launch copy that block to scratch memory first
 struct OwnArgs {
-    const ulonglong4 *recs;
+    TileRecs recs;
     const uint64_t *seed_ent, *read_tag;
     const uint32_t *cand_pos, *cand_off, *cand_svread, *cand_refread, *mark_read, *c2rec;
     uint32_t *out_ps, *status;
@@ -1537,7 +1551,7 @@ struct OwnArgs {
 
 // f(ps) for every seed entry of contig [c_lo, c_hi), tiles dealt out with a stride
 template <class F>
-__device__ __forceinline__ void own_each_entry(const ulonglong4 *recs, const uint64_t *seed_ent, uint32_t c_lo, uint32_t c_hi, uint32_t first,
+__device__ __forceinline__ void own_each_entry(TileRecs recs, const uint64_t *seed_ent, uint32_t c_lo, uint32_t c_hi, uint32_t first,
                                                uint32_t stride, F f)
 {
     const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
@@ -1646,12 +1660,164 @@ __device__ __noinline__ void finalize_candidate_walk(OwnArgs a, uint32_t c, uint
     a.out_ps[c] = own_nearest_walk(a, c_pos);
 }
 
+// A workgroup barrier that waits for the wavefront's LDS traffic only.  __syncthreads() is a fence as well: it drains the global
+// loads in flight (s_waitcnt vmcnt(0)) in front of s_barrier -- here that would put the summaries' round trip, issued early so that it
+// runs beside the seed set's phases, in front of the first of them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// maximum of one value per lane over the wavefront (row rotations, then the two row broadcasts: wave_sum's pattern)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// (rare path of ef_finalize_own: candidates out of position order) the hash set's values, ascending, into s_one[0 .. u): compacted,
+// every wavefront orders blocks of 64 in its registers, a value's place is the sum of its lower bounds in all blocks (its own
+// included: the values are distinct) -- ef_seed_sort's scheme.  Every thread of the workgroup calls it.
+__device__ __noinline__ void own_sort_set(const uint32_t *s_tab, uint32_t *s_key, uint32_t *s_one, uint32_t *s_part, uint32_t u)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t mv[kOwnTab / 256u], cnt = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kOwnTab / 256u; ++j) {
+        mv[j] = s_tab[tid + 256u * j];
+        cnt += mv[j] != kEmpty ? 1u : 0u;
+    }
+    uint32_t x = cnt;                                               // inclusive running count inside the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) s_part[wave] = x;
+    __syncthreads();
+    uint32_t at = x - cnt;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) at += w < wave ? s_part[w] : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < kOwnTab / 256u; ++j)
+        if (mv[j] != kEmpty) s_key[at++] = mv[j];
+    const uint32_t U = (u + 63u) & ~63u, nblk = U >> 6;
+    if (tid < U - u) s_key[u + tid] = kEmpty;                       // (pads the last block: sorts behind every seed)
+    __syncthreads();
+    for (uint32_t b = wave; b < nblk; b += 4u) s_key[b * 64u + lane] = wave_sort64(s_key[b * 64u + lane], lane);
+    __syncthreads();
+    for (uint32_t i = tid; i < U; i += 256u) {
+        const uint32_t me = s_key[i];
+        uint32_t rank = 0;
+        // (four blocks side by side: their seven dependent reads each overlap)
+        for (uint32_t b = 0; b < nblk; b += 4u) {
+            const uint32_t *b0 = s_key + b * 64u, *b1 = s_key + min(b + 1u, nblk - 1u) * 64u;
+            const uint32_t *b2 = s_key + min(b + 2u, nblk - 1u) * 64u, *b3 = s_key + min(b + 3u, nblk - 1u) * 64u;
+            uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+            for (uint32_t st = 32; st > 0; st >>= 1) {
+                p0 += b0[p0 + st - 1u] < me ? st : 0u;
+                p1 += b1[p1 + st - 1u] < me ? st : 0u;
+                p2 += b2[p2 + st - 1u] < me ? st : 0u;
+                p3 += b3[p3 + st - 1u] < me ? st : 0u;
+            }
+            p0 += b0[p0] < me ? 1u : 0u;
+            p1 += b1[p1] < me ? 1u : 0u;
+            p2 += b2[p2] < me ? 1u : 0u;
+            p3 += b3[p3] < me ? 1u : 0u;
+            rank += p0 + (b + 1u < nblk ? p1 : 0u) + (b + 2u < nblk ? p2 : 0u) + (b + 3u < nblk ? p3 : 0u);
+        }
+        if (me != kEmpty) s_one[rank] = me;
+    }
+    __syncthreads();
+}
+
+// (rare path of ef_finalize_own) the multi-PS vote of a candidate without a group summary, straight from its marks (:85-105,
+// class2_from_marks); "is this PS a seed" (:91) from the hash set in LDS
+__device__ __noinline__ void own_vote_from_marks(const uint32_t *mark_read, const uint64_t *read_tag, uint32_t mb, uint32_t me_,
+                                                 const uint32_t *s_tab, Vote *vo, uint32_t *pso)
+{
+    auto each = [&](auto f) {                                      // (eight marks' two dependent loads at a time, as for_each_tag)
+        for (uint32_t m0 = mb; m0 < me_; m0 += 8) {
+            uint32_t r[8];
+            uint64_t t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = mark_read[m0 + j < me_ ? m0 + j : mb];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = read_tag[r[j] == kEmpty ? 0u : r[j]];       // (read_tag always has >= 1 readable word)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (m0 + j < me_) f(r[j] == kEmpty ? kUntagged : t[j]);
+        }
+    };
+    auto member = [&](uint32_t key) -> bool {
+        uint32_t h = (key * 2654435761u) >> (32u - 11u);
+        for (;;) {
+            const uint32_t v = s_tab[h];
+            if (v == key) return true;
+            if (v == kEmpty) return false;
+            h = (h + 1u) & (kOwnTab - 1u);
+        }
+    };
+    Vote v = {0, 0, 0, 0, 0, 0};
+    uint32_t ps = 0, best = 0, done_ps = kEmpty;
+    each([&](uint64_t t) {
+        if (t != kUntagged && tag_pc(t) <= kPcMax) ++v.allhap;
+    });
+    each([&](uint64_t t) {
+        if (t == kUntagged || tag_pc(t) > kPcMax) return;
+        const uint32_t g = tag_ps(t);
+        if (g == done_ps || (g == ps && best)) return;
+        if (!member(g)) return;                                    // :91
+        uint32_t n = 0, n1 = 0, n2 = 0;
+        uint64_t s1 = 0, s2 = 0;
+        each([&](uint64_t u) {
+            if (u == kUntagged || tag_pc(u) > kPcMax || tag_ps(u) != g) return;
+            ++n;
+            const uint32_t hap = tag_hap(u);
+            if (hap == 1) { ++n1; s1 += tag_pc(u); }
+            else if (hap == 2) { ++n2; s2 += tag_pc(u); }
+        });
+        done_ps = g;
+        if (n > best) {                                            // strict: the first-seen group wins ties (:101)
+            best = n; ps = g;
+            v.hap1 = n1; v.hap2 = n2; v.t1 = s1; v.t2 = s2;
+            v.hap0 = v.allhap - n1 - n2;                           // only with a winner (:105)
+        }
+    });
+    *vo = v;
+    *pso = ps;
+}
+
+// ef_finalize_own's hash set, the probe sequence of `key` from slot h on: 1 when the key is new to the set, 0 when it is there already
+// (or the table is full).  ONE copy of this loop behind a call: inlined at the fourteen places that may need it, it was 2,000 of the
+// hot phase's 2,100 instructions.
+__device__ __noinline__ uint32_t own_insert_slow(uint32_t *s_tab, uint32_t key, uint32_t h)
+{
+    for (uint32_t probes = 0; probes < kOwnTab; ++probes) {
+        const uint32_t old = atomicCAS(&s_tab[h], kEmpty, key);
+        if (old == kEmpty) return 1u;
+        if (old == key) return 0u;
+        h = (h + 1u) & (kOwnTab - 1u);
+    }
+    return 0u;
+}
+
+constexpr uint32_t kOwnWin = 64;                   // seeds strictly inside the tile's range of asking positions that are kept as a list
+
 __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
 {
-    __shared__ uint32_t s_tab[kOwnTab];                        // the hash set; afterwards the ascending array
-    __shared__ uint32_t s_key[kOwnKeys];                       // the distinct seeds, compacted, then in sorted blocks of 64
-    __shared__ uint32_t s_part[256 / 64];
-    __shared__ uint32_t s_ndist, s_over;
+    __shared__ uint32_t s_tab[kOwnTab];                        // the hash set of the contig's seeds
+    __shared__ uint32_t s_key[kOwnKeys];                       // (rare path) the distinct seeds, compacted, then in sorted blocks of 64
+    __shared__ uint32_t s_one[kOwnKeys];                       // (rare path) ... ascending
+    __shared__ uint32_t s_win[kOwnWin];
+    __shared__ uint32_t s_mm[4][2];                            // per wavefront: ~min and max + 1 of the asking positions
+    __shared__ uint32_t s_red[4][3];                           // per wavefront: left seed + 1, ~right seed, seeds new to the set
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_nwin;
+    __shared__ __align__(8) uint32_t s_c2[kC2Quota * kC2Words];      // the tile's own group-summary slots
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     STAMP(2, 0);
     if (blockIdx.x == 0 && tid == 0) p.status[1] = 0;          // the summary pool's counter, for the next run's ef_classify
@@ -1665,137 +1831,238 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
         if (p.ctg_small[mid] <= c0) lo = mid; else hi = mid;
     }
     const uint32_t keys_cap = (p.dbg & DUET_DBG_EF_OWN_SMALLTAB) ? 8u : kOwnKeys;
-    const ulonglong4 *recs = reinterpret_cast<const ulonglong4 *>(p.blk_rec);
-    // ONE round trip in front of everything: the candidate's code, PS and position (a candidate that needs the nearest seed
-    // would fetch its position one trip later), and -- below -- up to four tiles' seed records of the first contig
-    const uint8_t code = live ? p.out_pred[c] : 0;
+    const uint32_t win_cap = (p.dbg & DUET_DBG_EF_OWN_SMALLTAB) ? 2u : kOwnWin;
+    const TileRecs recs{reinterpret_cast<const ulonglong4 *>(p.blk_rec)};
+    // ONE round trip in front of everything: the candidate's code, PS and position (a candidate that needs the nearest seed would
+    // fetch its position one trip later) and up to four tiles' seed records of the tile's first contig
+    const uint32_t code = live ? (uint32_t)p.out_pred[c] : 0u;
     const uint32_t ps_in = live ? p.out_ps[c] : 0;
     const uint32_t c_pos = live ? p.cand_pos[c] : 0;
+    uint32_t k_first = lo;
+    while (k_first < p.n_small && p.ctg_small[k_first] == p.ctg_small[k_first + 1]) ++k_first;       // (the tile's first contig with candidates)
+    constexpr uint32_t kPre = 2;                               // records per thread that leave with the first trip: 512 tiles of a contig
+    ulonglong4 rec[kPre] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, ext[kPre] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // a tile's count + entries 0 .. 2; entries 3 .. 6
+    auto load_recs = [&](uint32_t b_lo, uint32_t b_hi) {
+#pragma unroll
+        for (uint32_t i = 0; i < kPre; ++i) {
+            const uint32_t b = b_lo + tid + 256u * i;
+            rec[i].x = 0;
+            if (b <= b_hi) { rec[i] = recs[b]; ext[i] = recs.second(b); }
+        }
+    };
+    if (k_first < p.n_small) load_recs(p.ctg_small[k_first] / kCandPerBlock, (p.ctg_small[k_first + 1] - 1) / kCandPerBlock);
+    // What a multi-PS candidate needs (:85-105, :148-155) would be a SECOND, dependent trip -- its group summary sits at a slot that
+    // only its PS word names.  The tile's own kC2Quota summary slots (3.5 KB: the candidates of this very tile put theirs there) and
+    // every candidate's own columns leave with the first trip instead, whether or not anybody will look at them; only a summary
+    // in the shared pool (a tile with more than 64 multi-PS candidates) is fetched once the slot is known.
+    const uint32_t c_o0 = live ? p.cand_off[c] : 0u, c_o1 = live ? p.cand_off[c + 1] : 0u;
+    const uint32_t c_svread = live ? p.cand_svread[c] : 0u, c_refread = live ? p.cand_refread[c] : 0u;
+    {
+        constexpr uint32_t kPairs = kC2Quota * kC2Words / 2;                // 448 eight-byte pieces
+        const uint2 *src = reinterpret_cast<const uint2 *>(p.c2rec + (size_t)blockIdx.x * kC2Quota * kC2Words);
+        uint2 *dst = reinterpret_cast<uint2 *>(s_c2);
+        const uint2 a0 = src[tid], a1 = src[tid + 256u < kPairs ? tid + 256u : 0u];
+        dst[tid] = a0;
+        if (tid + 256u < kPairs) dst[tid + 256u] = a1;
+    }
     for (uint32_t k = lo; k < p.n_small && p.ctg_small[k] <= last; ++k) {
         const uint32_t c_lo = p.ctg_small[k], c_hi = p.ctg_small[k + 1];
         if (c_lo == c_hi) continue;
-        // ---- the contig's distinct seeds ---------------------------------------------------------
         const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
-        ulonglong4 rec[4];
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            const uint32_t b = b_lo + tid + 256u * i;
-            rec[i] = recs[b <= b_hi ? b : b_lo];               // (loads in flight while the table is cleared)
-        }
+        if (k != k_first) load_recs(b_lo, b_hi);               // (in flight while the table is cleared)
 #pragma unroll
         for (uint32_t i = 0; i < kOwnTab / 256u; ++i) s_tab[tid + 256u * i] = kEmpty;
-        if (tid == 0) { s_ndist = 0; s_over = 0; }
-        __syncthreads();
+        if (tid == 0) s_nwin = 0;
+        // the range of positions for which this tile will ask "which seed is nearest" (:106-111): candidates of this contig that
+        // need the nearest seed outright, or may (a multi-PS candidate without a winner)
+        const bool mine = live && c >= c_lo && c < c_hi;
+        const bool asks = mine && code >= 4u && !(code & kDivZero);
+        {
+            const uint32_t mn = wave_max_u32(asks ? ~c_pos : 0u), mx = wave_max_u32(asks ? c_pos + 1u : 0u);     // (a position is below 2^32 - 1)
+            if (lane == 0) { s_mm[wave][0] = mn; s_mm[wave][1] = mx; }
+        }
+        lds_barrier();
         STAMP(2, 1);
-        auto insert = [&](uint64_t e) {
-            const uint32_t cc = (uint32_t)(e >> 32), key = (uint32_t)e;        // (a PS is at most 2^32 - 2: kEmpty is free)
-            if (cc < c_lo || cc >= c_hi) return;
-            uint32_t h = (key * 2654435761u) >> 20;
-            for (uint32_t probes = 0; probes < kOwnTab; ++probes) {
-                const uint32_t old = atomicCAS(&s_tab[h], kEmpty, key);
-                if (old == kEmpty) {
-                    if (atomicAdd(&s_ndist, 1u) >= keys_cap) s_over = 1;          // (whether this happens depends on the SET only)
-                    break;
-                }
-                if (old == key) break;
-                h = (h + 1u) & (kOwnTab - 1u);
+        // ---- every entry of the contig: into the hash set (is this PS a seed, :91), and -- in the same sweep, from the registers
+        // it sits in -- what the tile needs to answer "which seed is nearest" for positions in [pmin, pmax]: the largest seed
+        // <= pmin, the smallest seed >= pmax, and the seeds strictly inside (with position-ordered candidates a handful; repeats
+        // from neighbouring tiles do not hurt a minimum).
+        uint32_t pmin, pmax;
+        {
+            const uint32_t a0 = max(max(s_mm[0][0], s_mm[1][0]), max(s_mm[2][0], s_mm[3][0]));
+            const uint32_t a1 = max(max(s_mm[0][1], s_mm[1][1]), max(s_mm[2][1], s_mm[3][1]));
+            pmin = a1 ? ~a0 : 0u;                                           // (nobody asks: any range serves)
+            pmax = a1 ? a1 - 1u : 0u;
+        }
+        uint32_t fresh = 0, leftp = 0, rinv = 0;
+        static_assert(kOwnTab == 1u << 11, "the hash takes 11 bits");
+        auto slot_of = [](uint32_t key) -> uint32_t { return (key * 2654435761u) >> (32u - 11u); };
+        auto is_new = [&](uint32_t key) {                                   // a seed new to the set: counted, and looked at once
+            ++fresh;
+            if (key <= pmin) leftp = max(leftp, key + 1u);
+            if (key >= pmax) rinv = max(rinv, ~key);
+            if (key > pmin && key < pmax) {
+                const uint32_t at = atomicAdd(&s_nwin, 1u);
+                if (at < kOwnWin) s_win[at] = key;
             }
         };
-        auto tile = [&](uint32_t b, const ulonglong4 &r) {
+        auto insert = [&](uint64_t e) {
+            const uint32_t cc = (uint32_t)(e >> 32), key = (uint32_t)e;        // (a PS is at most 2^32 - 2: kEmpty is free)
+            if (cc >= c_lo && cc < c_hi && own_insert_slow(s_tab, key, slot_of(key))) is_new(key);
+        };
+        // The thread's up to 2 x 7 entries in four groups -- a tile's first three, its next four --, each group only when some lane
+        // of the wavefront has one (most tiles have two or three entries, most wavefronts no second tile): a group's first probes
+        // leave together, what comes back is looked at without a branch per entry (the branch per entry cost this phase 1,800
+        // instructions and 2 us: selects instead; only a collision and a seed inside the window are rare enough to branch for).
+        auto group = [&](const uint64_t (&e)[4], uint32_t first, uint32_t n_in, uint32_t cnt) {
+            uint32_t key[4], old[4];
+            bool ok[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t cc = (uint32_t)(e[j] >> 32);
+                key[j] = (uint32_t)e[j];                                    // (a PS is at most 2^32 - 2: kEmpty is free)
+                ok[j] = j < n_in && first + j < cnt && cc >= c_lo && cc < c_hi;
+                old[j] = kEmpty;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (ok[j]) old[j] = atomicCAS(&s_tab[slot_of(key[j])], kEmpty, key[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                bool nw = ok[j] && old[j] == kEmpty;
+                if (ok[j] && old[j] != kEmpty && old[j] != key[j])          // (a collision: the probe sequence, behind a call)
+                    nw = own_insert_slow(s_tab, key[j], (slot_of(key[j]) + 1u) & (kOwnTab - 1u)) != 0u;
+                fresh += nw ? 1u : 0u;
+                leftp = max(leftp, (nw && key[j] <= pmin) ? key[j] + 1u : 0u);
+                rinv = max(rinv, (nw && key[j] >= pmax) ? ~key[j] : 0u);
+                if (nw && key[j] > pmin && key[j] < pmax) {
+                    const uint32_t at = atomicAdd(&s_nwin, 1u);
+                    if (at < kOwnWin) s_win[at] = key[j];
+                }
+            }
+        };
+#pragma unroll
+        for (uint32_t i = 0; i < kPre; ++i) {
+            const uint32_t cnt = b_lo + tid + 256u * i <= b_hi ? (uint32_t)rec[i].x : 0u;
+            if (__any(cnt > 0u)) {
+                const uint64_t e[4] = {rec[i].y, rec[i].z, rec[i].w, 0ull};
+                group(e, 0u, 3u, cnt);
+            }
+            if (__any(cnt > 3u)) {
+                const uint64_t e[4] = {ext[i].x, ext[i].y, ext[i].z, ext[i].w};
+                group(e, 3u, 4u, cnt);
+            }
+        }
+        // (what is rare: a tile with more than seven entries -- the rest from its overflow slots --, a contig of more than 512 tiles)
+#pragma unroll 1
+        for (uint32_t i = 0; i < kPre; ++i) {
+            const uint32_t b = b_lo + tid + 256u * i;
+            const uint32_t cnt = b <= b_hi ? (uint32_t)rec[i].x : 0u;
+            for (uint32_t j = 7; j < cnt; ++j) insert(p.seed_ent[(size_t)b * kCandPerBlock + j]);
+        }
+        for (uint32_t b = b_lo + tid + 256u * kPre; b <= b_hi; b += 256u) {
+            const ulonglong4 r = recs[b];
             const uint32_t cnt = (uint32_t)r.x;
             if (cnt > 0) insert(r.y);
             if (cnt > 1) insert(r.z);
             if (cnt > 2) insert(r.w);
             for (uint32_t j = 3; j < cnt; ++j) insert(p.seed_ent[(size_t)b * kCandPerBlock + j]);
-        };
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            const uint32_t b = b_lo + tid + 256u * i;
-            if (b <= b_hi) tile(b, rec[i]);
         }
-        for (uint32_t b = b_lo + tid + 1024u; b <= b_hi; b += 256u) tile(b, recs[b]);      // (more than 1024 tiles: DUET_DBG_EF_OWN_ALL only)
-        __syncthreads();
+        {
+            const uint32_t l = wave_max_u32(leftp), r = wave_max_u32(rinv), o = wave_sum(fresh);
+            if (lane == 0) { s_red[wave][0] = l; s_red[wave][1] = r; s_red[wave][2] = o; }
+        }
+        lds_barrier();
         STAMP(2, 2);
-        const uint32_t u = s_ndist;
-        const bool over = s_over != 0 || u > keys_cap;
-        const bool mine = live && c >= c_lo && c < c_hi;
-        if (!over && u != 0) {
-            // compact the set -- sixteen slots per thread, 256 apart (neighbouring lanes read neighbouring words; the order of a set is
-            // free) --, order the values: every wavefront orders blocks of 64 in its registers, a value's place is the sum of its
-            // lower bounds in all blocks (its own included: the values are distinct)
-            uint32_t mv[kOwnTab / 256u], cnt = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < kOwnTab / 256u; ++j) {
-                mv[j] = s_tab[tid + 256u * j];
-                cnt += mv[j] != kEmpty ? 1u : 0u;
-            }
-            uint32_t x = cnt;                                               // inclusive running count inside the wavefront
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if ((int)lane >= d) x += y;
-            }
-            if (lane == 63) s_part[wave] = x;
-            __syncthreads();
-            uint32_t at = x - cnt;
-#pragma unroll
-            for (uint32_t w = 0; w < 4; ++w) at += w < wave ? s_part[w] : 0u;
-#pragma unroll
-            for (uint32_t j = 0; j < kOwnTab / 256u; ++j)
-                if (mv[j] != kEmpty) s_key[at++] = mv[j];
-            const uint32_t U = (u + 63u) & ~63u, nblk = U >> 6;
-            if (tid < U - u) s_key[u + tid] = kEmpty;                       // (pads the last block: sorts behind every seed)
-            __syncthreads();
-            STAMP(2, 3);
-            for (uint32_t b = wave; b < nblk; b += 4u) s_key[b * 64u + lane] = wave_sort64(s_key[b * 64u + lane], lane);
-            __syncthreads();
-            STAMP(2, 4);
-            for (uint32_t i = tid; i < U; i += 256u) {
-                const uint32_t me = s_key[i];
-                uint32_t rank = 0;
-                // (four blocks side by side: their seven dependent reads each overlap; plain scalars -- arrays of pointers ended up in scratch memory)
-                for (uint32_t b = 0; b < nblk; b += 4u) {
-                    const uint32_t *b0 = s_key + b * 64u, *b1 = s_key + min(b + 1u, nblk - 1u) * 64u;
-                    const uint32_t *b2 = s_key + min(b + 2u, nblk - 1u) * 64u, *b3 = s_key + min(b + 3u, nblk - 1u) * 64u;
-                    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll
-                    for (uint32_t st = 32; st > 0; st >>= 1) {
-                        p0 += b0[p0 + st - 1u] < me ? st : 0u;
-                        p1 += b1[p1 + st - 1u] < me ? st : 0u;
-                        p2 += b2[p2 + st - 1u] < me ? st : 0u;
-                        p3 += b3[p3 + st - 1u] < me ? st : 0u;
-                    }
-                    p0 += b0[p0] < me ? 1u : 0u;
-                    p1 += b1[p1] < me ? 1u : 0u;
-                    p2 += b2[p2] < me ? 1u : 0u;
-                    p3 += b3[p3] < me ? 1u : 0u;
-                    rank += p0 + (b + 1u < nblk ? p1 : 0u) + (b + 2u < nblk ? p2 : 0u) + (b + 3u < nblk ? p3 : 0u);
-                }
-                if (me != kEmpty) s_tab[rank] = me;                         // (the set is dead: its place holds the ascending array)
-            }
-            __syncthreads();
-        }
+        const uint32_t u = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];                   // distinct seeds (a full table loses some: over)
+        const uint32_t Lp = max(max(s_red[0][0], s_red[1][0]), max(s_red[2][0], s_red[3][0]));       // left seed + 1, 0: none
+        const uint32_t Ri = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));       // ~right seed, 0: none
+        const uint32_t n_win = s_nwin;
+        const bool over = u > keys_cap;                                     // (a full table: u == kOwnTab > keys_cap)
+        const bool sorted = !over && n_win > win_cap;                       // candidates out of position order: the whole set, ascending
+        if (sorted) own_sort_set(s_tab, s_key, s_one, s_part, u);      // (a call: rare, and its registers are not the hot path's)
         STAMP(2, 5);
         // ---- this tile's candidates of contig k ------------------------------------------------------
+        // :107-111 -- ties go to the larger seed
+        auto nearest = [&](uint32_t pos) -> uint32_t {
+            if (sorted) return nearest_ps(s_one, u, pos);
+            uint32_t best = 0;
+            int64_t bd = -1;
+            auto look = [&](uint32_t v) {
+                const int64_t d = llabs((int64_t)pos - (int64_t)v);
+                if (bd < 0 || d < bd || (d == bd && v > best)) { bd = d; best = v; }
+            };
+            if (Lp) look(Lp - 1u);
+            if (Ri) look(~Ri);
+            for (uint32_t i = 0; i < n_win; ++i) look(s_win[i]);
+            return best;
+        };
+        auto member = [&](uint32_t key) -> bool {                           // (the table has empty slots: u <= keys_cap < kOwnTab)
+            uint32_t h = (key * 2654435761u) >> (32u - 11u);
+            for (;;) {
+                const uint32_t v = s_tab[h];
+                if (v == key) return true;
+                if (v == kEmpty) return false;
+                h = (h + 1u) & (kOwnTab - 1u);
+            }
+        };
         if (mine) {
             if (u == 0) {                                                   // :209-210
                 if (code != 0) p.out_pred[c] = 0;
                 if (ps_in != 0) p.out_ps[c] = 0;
-            } else if (code >= 4) {
-                if (over) {
+            } else if (code >= 4u) {
+                if (code & kDivZero) {                                      // :123 would raise
+                    atomicOr(&p.status[0], 1u);
+                    p.out_pred[c] = 0;
+                    p.out_ps[c] = 0;
+                } else if (over) {
                     const OwnArgs a = {recs, p.seed_ent, p.read_tag, p.cand_pos, p.cand_off, p.cand_svread, p.cand_refread, p.mark_read, p.c2rec,
                                        p.out_ps, p.status, p.out_pred, c_lo, c_hi};
                     finalize_candidate_walk(a, c, code, ps_in);
-                } else if ((code & ~3u) == kNeedNearest) {                   // :106-111, the position already here
-                    p.out_pred[c] = code & 3;
-                    p.out_ps[c] = nearest_ps(s_tab, u, c_pos);
-                } else {
-                    finalize_candidate(p, c, code, ps_in, k, true, s_tab, u, 0u);
+                } else if (code & kClass2Slow) {                            // no group summary: the vote from the marks (:85-105)
+                    Vote v;
+                    uint32_t ps;
+                    const uint32_t mb = p.cand_off[c], me_ = p.cand_off[c + 1];
+                    own_vote_from_marks(p.mark_read, p.read_tag, mb, me_, s_tab, &v, &ps);
+                    if (v.hap1 == 0 && v.hap2 == 0) ps = nearest(c_pos);    // :106
+                    p.out_pred[c] = (uint8_t)decide(2, v, me_ - mb, p.cand_svread[c], p.cand_refread[c]);
+                    p.out_ps[c] = ps;
+                } else if (code & kClass2) {                                // :85-105, :148-155 from the summary that is already here
+                    uint32_t w[kC2Words];
+                    const uint32_t own0 = blockIdx.x * kC2Quota;
+                    if (ps_in >= own0 && ps_in < own0 + kC2Quota) {
+#pragma unroll
+                        for (int i = 0; i < kC2Words; ++i) w[i] = s_c2[(ps_in - own0) * kC2Words + i];
+                    } else {                                                // (a slot of the shared pool)
+                        const uint32_t *rec2 = p.c2rec + (size_t)ps_in * kC2Words;
+#pragma unroll
+                        for (int i = 0; i < kC2Words; ++i) w[i] = rec2[i];
+                    }
+                    Vote v = {0, 0, 0, 0, 0, 0};
+                    uint32_t ps = 0, best = 0;
+                    v.allhap = w[0];
+                    const uint32_t ng = w[1];
+#pragma unroll
+                    for (int g = 0; g < kC2Groups; ++g) {
+                        if ((uint32_t)g < ng && w[2 + 6 * g + 1] > best && member(w[2 + 6 * g])) {
+                            best = w[2 + 6 * g + 1];
+                            ps = w[2 + 6 * g];
+                            v.hap1 = w[2 + 6 * g + 2]; v.hap2 = w[2 + 6 * g + 3];
+                            v.t1 = w[2 + 6 * g + 4]; v.t2 = w[2 + 6 * g + 5];
+                            v.hap0 = v.allhap - v.hap1 - v.hap2;           // only with a winner (:105)
+                        }
+                    }
+                    if (v.hap1 == 0 && v.hap2 == 0) ps = nearest(c_pos);    // :106
+                    p.out_pred[c] = (uint8_t)decide(2, v, c_o1 - c_o0, c_svread, c_refread);
+                    p.out_ps[c] = ps;
+                } else {                                                    // kNeedNearest
+                    p.out_pred[c] = (uint8_t)(code & 3u);
+                    p.out_ps[c] = nearest(c_pos);
                 }
             }
         }
         STAMP(2, 6);
-        __syncthreads();                                                    // s_tab / s_key are reused
+        __syncthreads();                                                    // the set is reused
     }
 }
 
@@ -1872,7 +2139,7 @@ int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
         memcmp(ctx->plan_off.data(), pr->cand_ctg_off, sizeof(uint32_t) * (K + 1)) == 0)
         return DUET_OK;
     const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
-    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
+    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 16 + (size_t)B * 16;      // (... 64-byte tile records, 64-byte aligned)
     const size_t want[6] = {small_words * 4, C, (size_t)B * kCandPerBlock * 8, ((size_t)C + K + 1) * 4, ((size_t)C + K + 1) * 4,
                             c2_slots(B, C) * kC2Words * 4};
     DevBuf *bufs[6] = {&ctx->ws_small, &ctx->ws_start, &ctx->ws_ent, &ctx->ws_one, &ctx->ws_tmp, &ctx->ws_c2};
@@ -1901,7 +2168,7 @@ int ensure_plan(duet_ctx *ctx, const duet_ef_problem *pr, hipStream_t stream)
     ctx->d_n_one = w;              w += K;
     ctx->d_status = w;             w += 8;
     ctx->d_blk_ctg = w;            w += B;
-    w += ((uintptr_t)w & 31) ? (32 - ((uintptr_t)w & 31)) / 4 : 0;        // 32-byte aligned tile records
+    w += ((uintptr_t)w & 63) ? (64 - ((uintptr_t)w & 63)) / 4 : 0;        // 32-byte aligned tile records
     ctx->d_blk_cnt = w;            // B records of 4 x u64
     // staging: ctg_off, then the contig of the first candidate of every 256-candidate block
     uint32_t *h_off = ctx->plan_stage, *h_blk = ctx->plan_stage + (K + 1);
@@ -2160,7 +2427,7 @@ int duet_ef_plan_on_device_prepare(duet_ctx *ctx, uint32_t K, uint32_t c_max, hi
 {
     const uint32_t C = c_max;
     const uint32_t B = (C + kCandPerBlock - 1) / kCandPerBlock;
-    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 8 + (size_t)B * 8;
+    const size_t small_words = (size_t)(K + 1) + K + 8 + (size_t)B + 16 + (size_t)B * 16;      // (... 64-byte tile records, 64-byte aligned)
     const size_t want[6] = {small_words * 4, C, (size_t)B * kCandPerBlock * 8, ((size_t)C + K + 1) * 4, ((size_t)C + K + 1) * 4,
                             c2_slots(B, C) * kC2Words * 4};
     DevBuf *bufs[6] = {&ctx->ws_small, &ctx->ws_start, &ctx->ws_ent, &ctx->ws_one, &ctx->ws_tmp, &ctx->ws_c2};
@@ -2177,7 +2444,7 @@ int duet_ef_plan_on_device_prepare(duet_ctx *ctx, uint32_t K, uint32_t c_max, hi
     ctx->d_n_one = w;              w += K;
     ctx->d_status = w;             w += 8;
     ctx->d_blk_ctg = w;            w += B;
-    w += ((uintptr_t)w & 31) ? (32 - ((uintptr_t)w & 31)) / 4 : 0;
+    w += ((uintptr_t)w & 63) ? (64 - ((uintptr_t)w & 63)) / 4 : 0;
     ctx->d_blk_cnt = w;
     ctx->plan_off.clear();                                     // the cached host-side plan no longer describes the workspace
     ctx->plan_C = 0;

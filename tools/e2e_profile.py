@@ -7,10 +7,12 @@ from duet_amd.native import NativeIngest
 from duet_amd.read_file import init_chrom_list
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+M = int(float(sys.argv[2])) if len(sys.argv) > 2 else 0           # marks: 0 = BASELINE configs[1]; else the 24-contig genome of that size
 home = tempfile.mkdtemp(prefix='duet_e2e_')
 try:
-    c = synth.bench_contig('1', 200000, 100000, 1)
-    synth.write_workdir(home, [c], dialect='cutesv', seed=1, write_sam=False)
+    contigs = [synth.bench_contig('1', 200000, 100000, 1)] if not M else synth.bench_genome(M, 3)
+    synth.write_workdir(home, contigs, dialect='cutesv', seed=1, write_sam=False)
+    del contigs
     ctx = engine.default_context(0)
     vcf, out = home + '/sv_calling/variants.vcf', home + '/phased_sv.vcf'
     for rep in range(4):

@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
-"""GPU-side diagnostic: end to end (caller VCF + haplotagged BAM on disk -> phased_sv.vcf) of config 2 per host thread count,
-with the native ingest's own lap times (DUET_INGEST_TIMING)."""
+"""GPU-side diagnostic: end to end (caller VCF + haplotagged BAM on disk -> phased_sv.vcf) per host thread count, with the native
+ingest's own lap times (DUET_INGEST_TIMING).
+
+    python3 tools/e2e_time.py [marks=0] [threads,threads,...]     marks 0: BASELINE configs[1]; else the 24-contig genome of that size
+                                                                  (2e7: BASELINE configs[2] as text, what VERDICT round 5 item 5 asks for)"""
 import os, shutil, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['DUET_INGEST_TIMING'] = '1'
 from duet_amd import synth
 from duet_amd.sv_phasing import sv_phasing
 
+M = int(float(sys.argv[1])) if len(sys.argv) > 1 else 0
+TS = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 32]
+if os.environ.get('DUET_E2E_QUIET') == '1':
+    del os.environ['DUET_INGEST_TIMING']
 home = tempfile.mkdtemp(prefix='duet_e2e_')
 try:
-    c = synth.bench_contig('1', 200000, 100000, 1)
-    synth.write_workdir(home, [c], dialect='cutesv', seed=1, write_sam=False)
+    contigs = [synth.bench_contig('1', 200000, 100000, 1)] if not M else synth.bench_genome(M, 3)
+    synth.write_workdir(home, contigs, dialect='cutesv', seed=1, write_sam=False)
+    del contigs
     sv_phasing(home, 50, 2, 4, False)
-    for T in (1, 2, 4, 8, 16, 32):
+    import hashlib
+    print('marks %s, phased_sv.vcf sha256 %s' % (M or 'config2', hashlib.sha256(open(home + '/phased_sv.vcf', 'rb').read()).hexdigest()))
+    for T in TS:
         best = 1e9
         for _ in range(3):
             sys.stderr.write('--- threads %d\n' % T)

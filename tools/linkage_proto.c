@@ -15,6 +15,15 @@ static inline uint64_t absdiff(uint64_t a, uint64_t b) { return a > b ? a - b : 
 #define QCAP (1ull << 41)
 #define QONE (1ull << 26)
 static uint64_t q0[NMAX][NMAX], S[NMAX][NMAX];
+/* round 6: what a nearest neighbour KEPT across rounds would save -- per size class: [0] rounds, [1] sum over
+ * rounds of clusters alive (= iterations of the lane-per-cluster scan: every lane walks all of them), [2] sum of merges, [3] sum of
+ * clusters that would have to look again (the merged ones, and those whose kept neighbour was in a merge), [4] rounds in which NO
+ * cluster has to look again */
+uint64_t nn_stats[5][8];
+/* ... and what cross-group sums restricted to one threshold-graph component would save (item 1b) -- per class: [0] partitions with open
+ * rows, [1] pairs of open rows (what the sums' pass evaluates, before the same-group pairs are taken out), [2] of them inside one component */
+uint64_t comp_stats[5][8];
+static int nn_cls;
 typedef unsigned __int128 u128;
 static void seq(uint32_t n, int mergeable, uint32_t *root)
 {
@@ -35,7 +44,9 @@ static void seq(uint32_t n, int mergeable, uint32_t *root)
 }
 static int rnn(uint32_t n, int mergeable, uint32_t *root, uint64_t *sum_alive)
 {
-    uint32_t size[NMAX], nn[NMAX], alive[NMAX], rep[NMAX];
+    uint32_t size[NMAX], nn[NMAX], alive[NMAX], rep[NMAX], nn_prev[NMAX], touched[NMAX];
+    int have_prev = 0;
+    for (uint32_t i = 0; i < n; ++i) touched[i] = 0;
     for (uint32_t i = 0; i < n; ++i) { root[i] = i; size[i] = 1; alive[i] = 1; for (uint32_t j = 0; j < n; ++j) S[i][j] = q0[i][j]; }
     if (!mergeable) return 0;
     /* identical marks */
@@ -51,8 +62,16 @@ static int rnn(uint32_t n, int mergeable, uint32_t *root, uint64_t *sum_alive)
                     if (nn[a] == NMAX || S[a][k] * bn < bs * size[k]) { bs = S[a][k]; bn = size[k]; nn[a] = k; } }
                 if (nn[a] != NMAX && bs > QONE * bn * size[a]) nn[a] = NMAX;      /* beyond the threshold */
             }
+            {   /* instrumentation: who would have had to look again this round */
+                uint32_t dirty = 0;
+                if (have_prev) for (uint32_t a = 0; a < n; ++a) if (alive[a] && (touched[a] || (nn_prev[a] != NMAX && (touched[nn_prev[a]] || !alive[nn_prev[a]])))) ++dirty;
+                if (!have_prev) dirty = na;
+                nn_stats[nn_cls][0]++; nn_stats[nn_cls][1] += na; nn_stats[nn_cls][3] += dirty; if (dirty == 0) nn_stats[nn_cls][4]++;
+                for (uint32_t a = 0; a < n; ++a) { nn_prev[a] = nn[a]; touched[a] = 0; }
+                have_prev = 1;
+            }
             for (uint32_t a = 0; a < n; ++a) rep[a] = a;
-            for (uint32_t a = 0; a < n; ++a) if (alive[a] && nn[a] != NMAX && nn[a] > a && nn[nn[a]] == a) rep[nn[a]] = a;
+            for (uint32_t a = 0; a < n; ++a) if (alive[a] && nn[a] != NMAX && nn[a] > a && nn[nn[a]] == a) { rep[nn[a]] = a; touched[a] = 1; touched[nn[a]] = 1; nn_stats[nn_cls][2]++; }
         }
         first = 0;
         int merged = 0;
@@ -98,6 +117,19 @@ int int_proto(uint32_t M, const uint16_t *contig, const uint8_t *type, const uin
                 q0[i][j] = d == 0.0 ? 0 : (uint64_t)t;
             } }
         uint32_t r0[NMAX], r1[NMAX]; uint64_t sa = 0;
+        nn_cls = cls;
+        if (mergeable) {   /* components of {q <= threshold}; a component is settled when it is a clique */
+            uint32_t comp[NMAX];
+            for (uint32_t i = 0; i < n; ++i) comp[i] = i;
+            for (int ch = 1; ch;) { ch = 0;
+                for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j < n; ++j)
+                    if (q0[i][j] <= QONE && comp[j] < comp[i]) { comp[i] = comp[j]; ch = 1; } }
+            uint32_t open_n = 0, csize[NMAX] = {0}, cedges[NMAX] = {0};
+            for (uint32_t i = 0; i < n; ++i) { csize[comp[i]]++; for (uint32_t j = i + 1; j < n; ++j) if (comp[i] == comp[j] && q0[i][j] <= QONE) cedges[comp[i]]++; }
+            uint64_t same = 0;
+            for (uint32_t c = 0; c < n; ++c) if (csize[c] && cedges[c] != csize[c] * (csize[c] - 1) / 2) { open_n += csize[c]; same += (uint64_t)csize[c] * (csize[c] - 1) / 2; }
+            if (open_n) { comp_stats[cls][0]++; comp_stats[cls][1] += (uint64_t)open_n * (open_n - 1) / 2; comp_stats[cls][2] += same; }
+        }
         seq(n, mergeable, r0);
         int rr = rnn(n, mergeable, r1, &sa);
         if (memcmp(r0, r1, 4 * n)) st[1]++;

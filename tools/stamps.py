@@ -47,7 +47,7 @@ st = buf[:3 * 65536 * 8].reshape(3, 65536, 8).astype(np.int64)
 t0 = st[0][st[0][:, 0] > 0][:, 0].min()
 names = [['start', 'offsets', 'staged', 'consumed', 'loop_end', 'decided', 'end'],
          ['start', 'gathered', 'sorted', 'end', 'recs', 'counted', 'written', 'runs'],
-         ['start', 'meta', 'staged'] if '3k' in sys.argv else ['start', 'cleared', 'inserted', 'compacted', 'sorted64', 'ranked', 'end']]
+         ['start', 'meta', 'staged'] if '3k' in sys.argv else ['start', 'cleared', 'inserted', 'swept', 'sorted64', 'ranked', 'end']]
 for k in range(3):
     blk = st[k][st[k][:, 0] > 0]
     nb = len(blk)
