@@ -1807,8 +1807,12 @@ __device__ __noinline__ uint32_t own_insert_slow(uint32_t *s_tab, uint32_t key, 
 
 constexpr uint32_t kOwnWin = 64;                   // seeds strictly inside the tile's range of asking positions that are kept as a list
 
+// DYN: the device-planned run of the fused clustered + phased pipeline -- the candidate count and the contig offsets exist on the
+// device only (the grid strides over the real tiles; the offsets, K + 1 <= 65 words, come into LDS once per workgroup)
+template <bool DYN>
 __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
 {
+    __shared__ uint32_t s_coff[kSmallK + 1];
     __shared__ uint32_t s_tab[kOwnTab];                        // the hash set of the contig's seeds
     __shared__ uint32_t s_key[kOwnKeys];                       // (rare path) the distinct seeds, compacted, then in sorted blocks of 64
     __shared__ uint32_t s_one[kOwnKeys];                       // (rare path) ... ascending
@@ -1821,14 +1825,22 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     STAMP(2, 0);
     if (blockIdx.x == 0 && tid == 0) p.status[1] = 0;          // the summary pool's counter, for the next run's ef_classify
-    const uint32_t n_cands = p.C;
-    const uint32_t c0 = blockIdx.x * 256u, c = c0 + tid;
+    const uint32_t n_cands = DYN ? *p.dyn_c : p.C;
+    const uint32_t nK = DYN ? p.K : p.n_small;
+    if (DYN) {
+        if (tid <= nK) s_coff[tid] = p.ctg_off[tid];
+        __syncthreads();
+    }
+    // contig k's first candidate: out of the kernel arguments (host-planned: scalar loads, no memory) or out of LDS
+    auto coff = [&](uint32_t kk) -> uint32_t { return DYN ? s_coff[kk] : p.ctg_small[kk]; };
+  for (uint32_t tile = blockIdx.x; (uint64_t)tile * 256u < n_cands; tile += gridDim.x) {
+    const uint32_t c0 = tile * 256u, c = c0 + tid;
     const bool live = c < n_cands;
     const uint32_t last = min(c0 + 255u, n_cands - 1);
-    uint32_t lo = 0, hi = p.n_small;                           // the last k with ctg_small[k] <= c0 (scalar unit, no memory)
+    uint32_t lo = 0, hi = nK;                                  // the last k with coff(k) <= c0
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (p.ctg_small[mid] <= c0) lo = mid; else hi = mid;
+        if (coff(mid) <= c0) lo = mid; else hi = mid;
     }
     const uint32_t keys_cap = (p.dbg & DUET_DBG_EF_OWN_SMALLTAB) ? 8u : kOwnKeys;
     const uint32_t win_cap = (p.dbg & DUET_DBG_EF_OWN_SMALLTAB) ? 2u : kOwnWin;
@@ -1839,7 +1851,7 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
     const uint32_t ps_in = live ? p.out_ps[c] : 0;
     const uint32_t c_pos = live ? p.cand_pos[c] : 0;
     uint32_t k_first = lo;
-    while (k_first < p.n_small && p.ctg_small[k_first] == p.ctg_small[k_first + 1]) ++k_first;       // (the tile's first contig with candidates)
+    while (k_first < nK && coff(k_first) == coff(k_first + 1)) ++k_first;       // (the tile's first contig with candidates)
     constexpr uint32_t kPre = 2;                               // records per thread that leave with the first trip: 512 tiles of a contig
     ulonglong4 rec[kPre] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, ext[kPre] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // a tile's count + entries 0 .. 2; entries 3 .. 6
     auto load_recs = [&](uint32_t b_lo, uint32_t b_hi) {
@@ -1850,7 +1862,7 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
             if (b <= b_hi) { rec[i] = recs[b]; ext[i] = recs.second(b); }
         }
     };
-    if (k_first < p.n_small) load_recs(p.ctg_small[k_first] / kCandPerBlock, (p.ctg_small[k_first + 1] - 1) / kCandPerBlock);
+    if (k_first < nK) load_recs(coff(k_first) / kCandPerBlock, (coff(k_first + 1) - 1) / kCandPerBlock);
     // What a multi-PS candidate needs (:85-105, :148-155) would be a SECOND, dependent trip -- its group summary sits at a slot that
     // only its PS word names.  The tile's own kC2Quota summary slots (3.5 KB: the candidates of this very tile put theirs there) and
     // every candidate's own columns leave with the first trip instead, whether or not anybody will look at them; only a summary
@@ -1859,14 +1871,14 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
     const uint32_t c_svread = live ? p.cand_svread[c] : 0u, c_refread = live ? p.cand_refread[c] : 0u;
     {
         constexpr uint32_t kPairs = kC2Quota * kC2Words / 2;                // 448 eight-byte pieces
-        const uint2 *src = reinterpret_cast<const uint2 *>(p.c2rec + (size_t)blockIdx.x * kC2Quota * kC2Words);
+        const uint2 *src = reinterpret_cast<const uint2 *>(p.c2rec + (size_t)tile * kC2Quota * kC2Words);
         uint2 *dst = reinterpret_cast<uint2 *>(s_c2);
         const uint2 a0 = src[tid], a1 = src[tid + 256u < kPairs ? tid + 256u : 0u];
         dst[tid] = a0;
         if (tid + 256u < kPairs) dst[tid + 256u] = a1;
     }
-    for (uint32_t k = lo; k < p.n_small && p.ctg_small[k] <= last; ++k) {
-        const uint32_t c_lo = p.ctg_small[k], c_hi = p.ctg_small[k + 1];
+    for (uint32_t k = lo; k < nK && coff(k) <= last; ++k) {
+        const uint32_t c_lo = coff(k), c_hi = coff(k + 1);
         if (c_lo == c_hi) continue;
         const uint32_t b_lo = c_lo / kCandPerBlock, b_hi = (c_hi - 1) / kCandPerBlock;
         if (k != k_first) load_recs(b_lo, b_hi);               // (in flight while the table is cleared)
@@ -1953,20 +1965,50 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
                 group(e, 3u, 4u, cnt);
             }
         }
-        // (what is rare: a tile with more than seven entries -- the rest from its overflow slots --, a contig of more than 512 tiles)
+        // A tile with more than seven entries -- candidates of a sparse type in stage A0's type-major order: a tile of 256 of them
+        // spans a quarter of the contig and carries a hundred phase sets -- has the rest in its overflow slots: the WAVEFRONT takes
+        // them, 64 entries per trip side by side (one lane walking them alone was a chain of a hundred dependent loads in EVERY
+        // workgroup, 35 of the kernel's 45 us on those candidates).
+        auto overflow = [&](uint32_t b, uint32_t cnt, uint32_t from) {
+            // (a few entries more: the lane itself, four loads in flight at a time -- many lanes do that side by side; a wavefront
+            // that took its lanes' tiles one after the other made a 782-tile genome's step 83 us where this takes 28)
+            constexpr uint32_t kLong = 24;
+            if (cnt > from && cnt <= kLong) {
+                const uint64_t *ov = p.seed_ent + (size_t)b * kCandPerBlock;
+#pragma unroll 1
+                for (uint32_t j = from; j < cnt; j += 4) {
+                    uint64_t e[4];
+#pragma unroll
+                    for (uint32_t t = 0; t < 4; ++t) e[t] = ov[min(j + t, cnt - 1u)];
+#pragma unroll
+                    for (uint32_t t = 0; t < 4; ++t)
+                        if (j + t < cnt) insert(e[t]);
+                }
+            }
+            unsigned long long todo = __ballot(cnt > kLong);
+            while (todo) {
+                const uint32_t h = (uint32_t)__ffsll((long long)todo) - 1u;
+                todo &= todo - 1ull;
+                const uint32_t b_h = (uint32_t)__builtin_amdgcn_readlane((int)b, h), cnt_h = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h);
+                const uint64_t *ov = p.seed_ent + (size_t)b_h * kCandPerBlock;
+                for (uint32_t j = from + lane; j < cnt_h; j += 64u) insert(ov[j]);
+            }
+        };
 #pragma unroll 1
         for (uint32_t i = 0; i < kPre; ++i) {
             const uint32_t b = b_lo + tid + 256u * i;
-            const uint32_t cnt = b <= b_hi ? (uint32_t)rec[i].x : 0u;
-            for (uint32_t j = 7; j < cnt; ++j) insert(p.seed_ent[(size_t)b * kCandPerBlock + j]);
+            overflow(b, b <= b_hi ? (uint32_t)rec[i].x : 0u, 7u);
         }
-        for (uint32_t b = b_lo + tid + 256u * kPre; b <= b_hi; b += 256u) {
-            const ulonglong4 r = recs[b];
+        // (a contig of more than 512 tiles: the others' records one more trip later)
+        for (uint32_t b0 = b_lo + 256u * kPre; b0 <= b_hi; b0 += 256u) {
+            const uint32_t b = b0 + tid;
+            ulonglong4 r = {0, 0, 0, 0};
+            if (b <= b_hi) r = recs[b];
             const uint32_t cnt = (uint32_t)r.x;
             if (cnt > 0) insert(r.y);
             if (cnt > 1) insert(r.z);
             if (cnt > 2) insert(r.w);
-            for (uint32_t j = 3; j < cnt; ++j) insert(p.seed_ent[(size_t)b * kCandPerBlock + j]);
+            overflow(b, cnt, 3u);
         }
         {
             const uint32_t l = wave_max_u32(leftp), r = wave_max_u32(rinv), o = wave_sum(fresh);
@@ -2029,7 +2071,7 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
                     p.out_ps[c] = ps;
                 } else if (code & kClass2) {                                // :85-105, :148-155 from the summary that is already here
                     uint32_t w[kC2Words];
-                    const uint32_t own0 = blockIdx.x * kC2Quota;
+                    const uint32_t own0 = tile * kC2Quota;
                     if (ps_in >= own0 && ps_in < own0 + kC2Quota) {
 #pragma unroll
                         for (int i = 0; i < kC2Words; ++i) w[i] = s_c2[(ps_in - own0) * kC2Words + i];
@@ -2064,6 +2106,8 @@ __global__ __launch_bounds__(256) void ef_finalize_own(const Params p)
         STAMP(2, 6);
         __syncthreads();                                                    // the set is reused
     }
+    if (!DYN) break;
+  }
 }
 
 // plan time: ctg_start[c] = 1 for the first candidate of every non-empty contig
@@ -2390,7 +2434,7 @@ int duet_ef_run_device(duet_ctx *ctx, const duet_ef_problem *pr, uint8_t *out_pr
     else
         hipExtLaunchKernelGGL(ef_classify<false>, dim3(blocks), dim3(kCandPerBlock), 0, stream, ev[0], ev[1], 0, p);
     if (own) {
-        hipExtLaunchKernelGGL(ef_finalize_own, dim3(blocks), dim3(256), 0, stream, ev[4], ev[5], 0, p);
+        hipExtLaunchKernelGGL(ef_finalize_own<false>, dim3(blocks), dim3(256), 0, stream, ev[4], ev[5], 0, p);
         ctx->ef_last_params.assign((const unsigned char *)&p, (const unsigned char *)&p + sizeof(p));
         ctx->ef_last_stream = stream;
         ctx->ef_seeds_stale = true;
@@ -2502,12 +2546,22 @@ int duet_ef_run_planned_on_device(duet_ctx *ctx, const duet_ef_problem *pr, uint
         hipLaunchKernelGGL((ef_classify<true, true>), dim3(G), dim3(kCandPerBlock), 0, stream, p);
     else
         hipLaunchKernelGGL((ef_classify<false, true>), dim3(G), dim3(kCandPerBlock), 0, stream, p);
+    // The own-set finalize (ef_finalize_own) is NOT taken here by default: stage A0 hands its candidates over by type, then position,
+    // and a tile of a sparse type (DUP, INV: a percent of the candidates each) spans a quarter of the contig and carries a hundred
+    // seed entries that EVERY tile then reads -- measured on configs[1]'s marks: 35.6 us against 34.3 for E/F alone, 270.9 against
+    // 269.1 us for the pipeline (in position order the same candidates take 23.4 against 28.8).  DUET_DBG_EF_OWN_ALL takes it
+    // (tests/test_gpu_fused.py runs the pipeline both ways).
+    const uint32_t three = DUET_DBG_EF_OWN_OFF | DUET_DBG_EF_FIN_TPB2 | DUET_DBG_EF_FIN_TPB4 | DUET_DBG_EF_NO_SEED_HASH;
+    if (K <= (uint32_t)kSmallK && !(ctx->dbg & three) && (ctx->dbg & DUET_DBG_EF_OWN_ALL)) {
+        hipLaunchKernelGGL(ef_finalize_own<true>, dim3(G), dim3(256), 0, stream, p);
+    } else {
     hipLaunchKernelGGL(ef_seed_sort, dim3(K), dim3(kSortThreads), 0, stream, p);
     // (two tiles per workgroup where the bound says millions of candidates: the per-workgroup round trips once per 512)
     if (d_cand_contig && (C >= 8000000u || (ctx->dbg & DUET_DBG_EF_FIN_TPB2)))
         hipLaunchKernelGGL((ef_finalize<true, 2>), dim3(G), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(ef_finalize<true>, dim3(G), dim3(256), 0, stream, p);
+    }
     HIP_TRY(ctx, hipGetLastError());
     ctx->pending_check = true;
     return DUET_OK;

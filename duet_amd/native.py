@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libduet_ingest.so')
 
 OK, UNSUPPORTED = 0, 1
 
-EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam',
+EXPORTS = ('duet_ingest_create', 'duet_ingest_destroy', 'duet_ingest_error', 'duet_ingest_add_bam', 'duet_ingest_add_bams',
            'duet_ingest_parse_vcf', 'duet_ingest_parse_vcf_begin', 'duet_ingest_parse_vcf_finish', 'duet_ingest_get_arrays',
            'duet_ingest_emit', 'duet_ingest_free', 'duet_ingest_header',
            'duet_ingest_get_rows', 'duet_ingest_set_extraction', 'duet_ingest_get_marks', 'duet_ingest_bam_has_alignments',

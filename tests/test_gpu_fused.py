@@ -71,7 +71,8 @@ def fused_case(contigs, seed, waits, contig_ids=None, extra=0):
     # ef_finalize takes two tiles per workgroup from a bound of 8 M candidates on: the last run of a small case forces that
     # (DUET_DBG_EF_FIN_TPB2 = 0x20), and the wave-cooperative walk of ef_classify on every candidate (0x80000)
     for it, wait in enumerate(waits):
-        ctx.set_debug((0x40000 if it % 2 else 0) | (0x20 | 0x80000 if it == len(waits) - 1 and len(waits) > 2 else 0))
+        # (... and, every other time from the second on, the own-set finalize in the device-planned E/F tail: DUET_DBG_EF_OWN_ALL, round 6)
+        ctx.set_debug((0x40000 if it % 2 else 0) | (0x20 | 0x80000 if it == len(waits) - 1 and len(waits) > 2 else 0) | (0x1000000 if it % 2 == 1 else 0))
         ds.run_fused(ctx, wait=wait)
         got = ds.fetch()
         assert ds.n_found == len(want_cl['cand_pos'])
