@@ -640,10 +640,12 @@ int duet_ingest_add_bam(duet_ingest *g, int contig, const char *path, int thread
     if (NR) g->bam_has_aln[contig] = 1;
     auto rec_end = [&](size_t i) { return at[i] + 4 + (size_t)u32(at[i]); };
     std::vector<BamRec> recs;
-    const bool batch = !g->extract && NR >= 4096 && threads > 1;
+    // (also with ONE worker -- a contig of its own in duet_ingest_add_bams: the records examined first, the name table then filled with
+    // the slot of the record eight ahead already asked for; the record-by-record path missed the cache once per read name)
+    const bool batch = !g->extract && NR >= 4096;
     if (batch) {
         recs.resize(NR);
-        const int T = threads > 32 ? 32 : threads;
+        const int T = threads > 32 ? 32 : (threads < 1 ? 1 : threads);
         auto work = [&](int t) {
             for (size_t i = NR * t / T, hi = NR * (t + 1) / T; i < hi; ++i) parse_bam_record(b, at[i], rec_end(i), recs[i]);
         };
@@ -1563,6 +1565,14 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
     if (!g || !g->parsed || !o) return DUET_INGEST_INVALID;
     const size_t C = g->cand_pos.size();
     if (!g->rows_ready) {
+        const bool timing = getenv("DUET_INGEST_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[duet_ingest] rows %-9s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
         // (round 6: the three passes over the candidates' spans -- lengths, offsets, copies -- by `threads` workers each; at 2e6
         // candidates they were 120 ms of a 640 ms run on one thread, the pool's zero-fill included)
         const int T = (int)std::min<size_t>((size_t)std::max(1, g->threads), std::max<size_t>(1, C / 4096));
@@ -1586,6 +1596,7 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
             part_mp[(size_t)t] = mp;
         });
         for (int t = 0; t < T; ++t) part[(size_t)t + 1] += part[(size_t)t];
+        lap("lengths");
         const size_t total = part[(size_t)T];
         if (total >= 0xFFFFFFF0ull) return unsupported(g, "candidate texts exceed 4 GiB");
         g->pool.clear();
@@ -1601,6 +1612,13 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
             size_t a = part[(size_t)t];
             char *pool = g->pool_raw.get();
             for (size_t c = lo; c < hi; ++c) {
+                // (the texts lie where the caller VCF's lines lie: four cache misses per candidate unless they are asked for ahead)
+                if (c + 16 < hi) {
+                    __builtin_prefetch(g->c_chrom[c + 16].p);
+                    __builtin_prefetch(g->c_ref[c + 16].p);
+                    __builtin_prefetch(g->c_alt[c + 16].p);
+                    __builtin_prefetch(g->c_type[c + 16].p);
+                }
                 const Span *f[4] = {&g->c_chrom[c], &g->c_ref[c], &g->c_alt[c], &g->c_type[c]};
                 for (int i = 0; i < 4; ++i) {
                     g->str_off[4 * c + i] = (uint32_t)a;
@@ -1609,6 +1627,7 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
                 }
             }
         });
+        lap("copies");
         g->str_off[4 * C] = (uint32_t)at;
         g->max_pos = mp;
         // rank of each CHROM text among the distinct ones, in byte order (what Python's string compare does at :229).
@@ -1616,12 +1635,23 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
         auto same = [](const Span &x, const Span &y) { return x.n == y.n && memcmp(x.p, y.p, x.n) == 0; };
         std::vector<std::string> texts;
         {
+            // (by the workers: every candidate's CHROM text is a cache miss in the caller VCF's buffer -- one thread walking two
+            // million of them twice was 100 ms of a 520 ms run)
+            std::vector<std::vector<std::string>> local((size_t)T);
+            run([&](int t) {
+                const size_t lo = C * (size_t)t / T, hi = C * (size_t)(t + 1) / T;
+                std::unordered_map<std::string, int> seen;
+                for (size_t c = lo; c < hi; ++c) {
+                    if (c + 16 < hi) __builtin_prefetch(g->c_chrom[c + 16].p);
+                    if (c > lo && same(g->c_chrom[c], g->c_chrom[c - 1])) continue;
+                    std::string x(g->c_chrom[c].p, g->c_chrom[c].n);
+                    if (seen.emplace(x, 1).second) local[(size_t)t].push_back(std::move(x));
+                }
+            });
             std::unordered_map<std::string, int> seen;
-            for (size_t c = 0; c < C; ++c) {
-                if (c && same(g->c_chrom[c], g->c_chrom[c - 1])) continue;
-                std::string t(g->c_chrom[c].p, g->c_chrom[c].n);
-                if (seen.emplace(t, 1).second) texts.push_back(std::move(t));
-            }
+            for (auto &v : local)
+                for (auto &x : v)
+                    if (seen.emplace(x, 1).second) texts.push_back(std::move(x));
         }
         std::sort(texts.begin(), texts.end(), [](const std::string &x, const std::string &y) {
             const int c = memcmp(x.data(), y.data(), std::min(x.size(), y.size()));
@@ -1631,11 +1661,17 @@ int duet_ingest_get_rows(duet_ingest *g, duet_ingest_rows *o)
         std::unordered_map<std::string, uint16_t> rank;
         for (size_t i = 0; i < texts.size(); ++i) rank.emplace(texts[i], (uint16_t)i);
         g->chrom_rank.resize(C);
-        for (size_t c = 0; c < C; ++c)
-            g->chrom_rank[c] = (c && same(g->c_chrom[c], g->c_chrom[c - 1])) ? g->chrom_rank[c - 1]
-                                                                             : rank[std::string(g->c_chrom[c].p, g->c_chrom[c].n)];
+        run([&](int t) {
+            const size_t lo = C * (size_t)t / T, hi = C * (size_t)(t + 1) / T;
+            for (size_t c = lo; c < hi; ++c) {
+                if (c + 16 < hi) __builtin_prefetch(g->c_chrom[c + 16].p);
+                g->chrom_rank[c] = (c > lo && same(g->c_chrom[c], g->c_chrom[c - 1])) ? g->chrom_rank[c - 1]
+                                                                                      : rank.find(std::string(g->c_chrom[c].p, g->c_chrom[c].n))->second;
+            }
+        });
         g->n_chrom_texts = (uint32_t)texts.size();
         g->rows_ready = true;
+        lap("ranks");
     }
     o->n_cands = (uint32_t)C;
     o->pool = g->pool_raw ? g->pool_raw.get() : g->pool.data();

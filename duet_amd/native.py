@@ -336,6 +336,15 @@ class NativeIngest(object):
             self.lib.duet_ingest_destroy(self.handle)
             self.handle = None
 
+    def close_in_background(self):
+        """Hand the native object to a thread that frees it (round 6: at configs[2]'s size the name tables, the tag words and the
+        565 MB VCF buffer take 75 ms to give back -- nothing the caller waits for: the rows are already out).  The thread is not a
+        daemon: the interpreter's exit waits for it."""
+        if self.handle:
+            import threading
+            h, self.handle, self.soa = self.handle, None, None
+            threading.Thread(target=self.lib.duet_ingest_destroy, args=(h,)).start()
+
     def __del__(self):
         try:
             self.close()

@@ -81,8 +81,10 @@ def _native(home, svlen_thres, suppread_thres, thread, include_all_ctgs, caller_
             pred, ps = engine.run_ef(ing.soa, svlen_thres, suppread_thres, ctx=ctx)
             body = ing.emit_rows(pred, ps)
         logging.info('write phased callset into .vcf file')
-    finally:
+    except BaseException:
         ing.close()
+        raise
+    ing.close_in_background()                       # (the rows are out: freeing the ingest's memory needs nobody's attention)
     with open(out_vcf, 'ab') as out:
         out.write(body)
     return True

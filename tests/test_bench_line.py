@@ -41,6 +41,11 @@ def test_single_gpu_line_is_small_and_complete():
     assert 'traffic_per_kernel_bytes' not in text
     # the clustered+phased reading of the metric stays on the line, with its own roofline and counter traffic
     assert back['value_clustered_and_phased'] > 0 and back['roofline_clustered_and_phased']['traffic'] > 0
+    # round 6: what `value` is stays on the line; the roofline's launch time in both readings when the record has them
+    full['value_is'] = bench.VALUE_IS
+    full['roofline'].update({'launch_ms_in_run': 0.008, 'launch_ms_profiles': 0.0097, 'frac_in_run': 0.24})
+    back = json.loads(json.dumps(bench.compact_line(full, None)))
+    assert back['value_is'].startswith('phased_only') and back['roofline']['launch_ms_profiles'] == 0.0097 and back['roofline']['frac_in_run'] == 0.24
 
 
 def test_multi_gpu_line_is_small():
@@ -65,6 +70,11 @@ def test_multi_gpu_line_is_small():
     assert len(text) < bench.LINE_BUDGET
     back = json.loads(text)
     assert back['topology']['distinct_devices'] == world and len(back['topology']['devices']) == world
+    # round 6: what RCCL itself says about the communicator travels to the line's top level
+    full['topology']['rccl_ranks_seen'] = world
+    full['topology']['comm_selftest'] = 'ok'
+    back2 = json.loads(json.dumps(bench.compact_line(full, None)))
+    assert back2['rccl_ranks_seen'] == world and back2['topology']['rccl_ranks_seen'] == world
     assert len(back['per_rank']['marks']) == world
 
 
