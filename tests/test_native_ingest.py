@@ -139,6 +139,38 @@ def test_many_records_parallel_bam_path(tmp_path):
         assert ing is not None and ing.handle is None and 'PC/PS out of range' in ing.why, (t, ing.why)
 
 
+def test_whole_contigs_dealt_to_the_workers(tmp_path):
+    """Round 6, duet_ingest_add_bams: several contigs' BAMs in one call, whole contigs dealt to the workers (largest file first; each
+    contig alone takes the batched record path of the test above) -- the same arrays as contig after contig with one thread and as the
+    Python ingest (sv_phasing_fn.py:15-29 builds one dict per contig: nothing crosses contigs); a contig whose BAM declines makes the
+    call decline with THAT contig's reason, whatever the others did meanwhile."""
+    import re
+    from duet_amd import bamio, synth
+    home = str(tmp_path / 'w')
+    contigs = [synth.bench_contig(l, 5000 + 900 * i, 300 + 40 * i, 11 + i, length=3000000) for i, l in enumerate(('1', '2', '3', '7', 'X'))]
+    synth.write_workdir(home, contigs, dialect='cutesv', seed=2, write_sam=True)
+    vcf, sams = home + '/sv_calling/variants.vcf', home + '/snp_phasing/'
+    one = native.NativeIngest.load(vcf, sams, CHROMS, 1)
+    many = native.NativeIngest.load(vcf, sams, CHROMS, 8)
+    few = native.NativeIngest.load(vcf, sams, CHROMS, 3)           # (fewer workers than contigs)
+    assert one.handle is not None and many.handle is not None and few.handle is not None
+    tab, soa = F.generate_callinfo(vcf, F.read_hap_bam(sams, 4, False), False)
+    for field, _ in engine.EfSoA.FIELDS:
+        assert np.array_equal(getattr(one.soa, field), getattr(many.soa, field)), field
+        assert np.array_equal(getattr(one.soa, field), getattr(few.soa, field)), field
+        assert np.array_equal(getattr(many.soa, field), getattr(soa, field)), field
+    assert one.log_lines(CHROMS) == many.log_lines(CHROMS)
+    for ing in (one, many, few):
+        ing.close()
+    lines = synth.sam_lines(contigs[3])
+    k = next(i for i, l in enumerate(lines) if i > 3000 and 'PC:i:' in l)
+    lines[k] = re.sub(r'PC:i:\d+', 'PC:i:-7', lines[k])
+    bamio.write_bam_from_sam_lines(sams + 'chr7.bam', [('chr7', 3000000)], lines)
+    for t in (1, 3, 8):
+        ing = native.NativeIngest.load(vcf, sams, CHROMS, t)
+        assert ing is not None and ing.handle is None and 'PC/PS out of range' in ing.why, (t, ing.why)
+
+
 def test_python_int_forms_accepted(tmp_path):
     home = _tiny_case(tmp_path, [REC.replace('\t100\t', '\t+1_00\t').replace('RE=5', 'RE=0_5')], SAM)
     ing = native.NativeIngest.load(home + '/sv_calling/variants.vcf', home + '/snp_phasing/', CHROMS, 1)
