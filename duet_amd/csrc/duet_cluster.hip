@@ -126,6 +126,9 @@ struct ClParams {
     uint32_t *order, *cand_off, *cand_pos, *cand_span;
     uint16_t *cand_contig;
     uint8_t *cand_type;
+    // a fork without an event (cl_gate): the kernel in front of which the side stream forks off writes the run's epoch here as it starts
+    uint32_t *fork_flag;
+    uint32_t fork_epoch;
 };
 
 __device__ __forceinline__ uint64_t centre_of(uint32_t pos, uint32_t span) { return (uint64_t)pos + (span >> 1); }
@@ -560,6 +563,9 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
     static_assert(!APPLY || (kBoxThreads == kScanThreads && kBoxHalo == 128), "the scan's thread layout; a partition ends within the halo");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, tile = blockIdx.x;
     const uint32_t t0 = tile * kScanTile, shard = tile / p.tps;
+    // (small inputs: the side stream's chain of the > 64-mark partitions starts BESIDE this kernel -- everything in front of it on the
+    // stream is done when any of its workgroups runs: the first one says so, cl_gate on the side stream is waiting for it)
+    if (!APPLY && p.fork_flag && tile == 0 && tid == 0) __hip_atomic_store(p.fork_flag, p.fork_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t p_lo = 0, np = 0;
     if (tid < kClasses) s_cnt[tid] = 0;
     if (tid < (kScanTile + kBoxHalo + 31) / 32) s_dbit[tid] = 0;
@@ -2361,6 +2367,27 @@ __global__ __launch_bounds__(64) void cl_link_one(const ClParams p, const uint32
 // bpermutes, no memory), loads the record and the depth bin it selects, and writes its candidate -- neighbouring lanes write
 // neighbouring candidates, and a partition of ten clusters costs what one of one does (round 3: one thread per partition
 // walking its clusters four at a time, 76 us at 2e7 marks).
+// A fork without an event (round 6).  hipEventRecord on the main stream + hipStreamWaitEvent on the side stream cost the MAIN stream
+// 7-14 us each time (the record's barrier packet sits in front of its next kernel: timelines of rounds 4-6).  Instead the main stream
+// runs a one-lane kernel that writes the run's epoch to a device word, and the side stream -- whose launches were queued long before --
+// starts with a one-lane kernel that waits for that word.  The main stream never waits for the side stream here (the JOIN stays an
+// event), so a side queue that the device schedules late only starts late: nothing can deadlock; the wait is bounded all the same
+// (2 s, then the kernel traps: a loud failure, not a hang).  Kernel boundaries on both queues do the cache maintenance around it.
+__global__ void cl_signal(uint32_t *flag, uint32_t epoch)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void cl_gate(const uint32_t *flag, uint32_t epoch)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    // (epochs only grow; a later run's value serves as well: its main stream is behind this run's)
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 200000000ull) __builtin_trap();
+    }
+}
+
 __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) p.cand_off[0] = 0;
@@ -2758,9 +2785,18 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // alone and read their rows through the sort permutation themselves (or where the record sort left them), so their launch
     // starts beside cl_box, not after it (1.0 M marks: the chain ended 30-40 us after everything else when it started behind
     // cl_box) -- except where cl_box itself numbers the partitions (large inputs: the chain is far from critical there).
-    auto launch_big = [&]() -> int {
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+    // (small inputs only: at 2e7 marks the forks' gaps are 15 of 2,100 us, and a side chain that starts 7 us earlier takes compute units
+    // from the first tier's first launch -- measured: 2,187 against 2,127 us)
+    const bool gate_forks = small && !(ctx->dbg & DUET_DBG_CLUSTER_EVENT_FORKS);
+    const uint32_t epoch = ++ctx->cl_epoch;
+    auto launch_big = [&](bool next_kernel_signals) -> int {
+        if (gate_forks) {
+            if (!next_kernel_signals) hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, st, ctx->cl_flags + 0, epoch);
+            hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, ctx->cl_side[0], (const uint32_t *)(ctx->cl_flags + 0), epoch);
+        } else {
+            HIP_TRY(ctx, hipEventRecord(ctx->cl_fork, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[0], ctx->cl_fork, 0));
+        }
         ClParams pb = p;
         pb.gather_rows = rec_mode ? 0u : 1u;                     // (rec_mode: the sorted rows are there already)
         const uint32_t gb = std::min(4096u, std::max(256u, (M / 64u + 63u) / 64u));      // (partitions <= marks; 64 of them per wavefront and step)
@@ -2768,10 +2804,18 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         const uint32_t gl = std::min(gb, 1024u);
         if (cap100) hipLaunchKernelGGL((cl_link_one<64, 2, 100>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
         else hipLaunchKernelGGL((cl_link_one<64, 2, 128>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+        // the join the same way on small inputs: the side stream says when it is through, a gate on the main stream waits for it (the
+        // side stream's launches are queued in front of that gate, so even one shared hardware queue would run them first)
+        if (gate_forks) hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[0], ctx->cl_flags + 4, epoch);
+        else HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
         return DUET_OK;
     };
-    if (!box_applies && (rc = launch_big())) return rc;
+    // (small inputs: cl_box itself signals as it starts -- a signal kernel of its own was 5.9 us on the main stream)
+    p.fork_flag = (!box_applies && gate_forks) ? ctx->cl_flags + 0 : nullptr;
+    p.fork_epoch = epoch;
+    // (the side stream's launches are queued BEHIND cl_box's: were the two streams ever to share a hardware queue, a gate in front of the
+    // kernel that opens it would never see it start; an event fork goes in front, as in rounds 1-5)
+    if (!box_applies && !gate_forks && (rc = launch_big(false))) return rc;
     const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
     if (box_applies)
@@ -2780,7 +2824,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         hipLaunchKernelGGL((cl_box<true, false>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts, (const uint8_t *)nullptr, (const PartSum *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     else
         hipLaunchKernelGGL((cl_box<false, false>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts, (const uint8_t *)nullptr, (const PartSum *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-    if (box_applies && (rc = launch_big())) return rc;
+    if ((box_applies || gate_forks) && (rc = launch_big(!box_applies && gate_forks))) return rc;
     if (!tiers) {
         // one launch for the classes of up to 64 marks, nothing handed on
         hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
@@ -2793,8 +2837,13 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         // tier's many small workgroups and takes as long for a piece as it does alone for everything.)
         hipLaunchKernelGGL((cl_tight_one<64, 1, kK64>), dim3(grid), dim3(64), 0, st, p, lists + 3 * (size_t)M, (const uint32_t *)(cnts + 3 * kShards), over + 3 * kShards);
         // (what this class hands on -- the most of all classes -- has its second tier beside the other classes' first one)
-        HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], st));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[1], ctx->cl_join[1], 0));
+        if (gate_forks) {
+            hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, st, ctx->cl_flags + 8, epoch);
+            hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, ctx->cl_side[1], (const uint32_t *)(ctx->cl_flags + 8), epoch);
+        } else {
+            HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], st));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[1], ctx->cl_join[1], 0));
+        }
         hipLaunchKernelGGL((cl_tier2_one<64, 1, 64>), dim3(std::min(grid, 4096u)), dim3(64), 0, ctx->cl_side[1], p, (const uint32_t *)(lists + 3 * (size_t)M), (const uint32_t *)(over + 3 * kShards));
         HIP_TRY(ctx, hipEventRecord(ctx->cl_join[2], ctx->cl_side[1]));
         hipLaunchKernelGGL((cl_tight_one<32, 1, kK32>), dim3(grid), dim3(64), 0, st, p, lists + 2 * (size_t)M, (const uint32_t *)(cnts + 2 * kShards), over + 2 * kShards);
@@ -2804,7 +2853,8 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // what they handed on
     if (tiers) hipLaunchKernelGGL(cl_tier2_all, dim3(std::min(gridw, 2048u)), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)over, small ? 1u : 0u);
     if (!small) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[2], 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
+    if (gate_forks) hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), epoch);
+    else HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
     p.cbase = cbase;

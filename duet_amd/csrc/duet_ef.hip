@@ -2304,6 +2304,8 @@ duet_ctx *duet_ctx_create(int device_id)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->plan_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->rx_dtot, 8 * 2048 * sizeof(uint32_t));        // kDtotCopies x 256 (key sort) / x 2048 (record sort)
     if (e == hipSuccess) e = hipMemset(ctx->rx_dtot, 0, 8 * 2048 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->cl_flags, 64);
+    if (e == hipSuccess) e = hipMemset(ctx->cl_flags, 0, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_untagged, 64);
     if (e == hipSuccess) e = hipMemset(ctx->d_untagged, 0xFF, 64);                                  // the tag word of a mark without a tag
     if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -2336,6 +2338,7 @@ void duet_ctx_destroy(duet_ctx *ctx)
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->rx_dtot) (void)hipFree(ctx->rx_dtot);
     if (ctx->d_untagged) (void)hipFree(ctx->d_untagged);
+    if (ctx->cl_flags) (void)hipFree(ctx->cl_flags);
     for (int i = 0; i < 3; ++i) {
         if (ctx->cl_side[i]) (void)hipStreamDestroy(ctx->cl_side[i]);
         if (ctx->cl_join[i]) (void)hipEventDestroy(ctx->cl_join[i]);

@@ -53,6 +53,8 @@ struct duet_ctx {
     void *sv_depth_off_at = nullptr;                       // fused SVIM-mode pipeline: contig offsets, adapted columns, gathered marks
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};
+    uint32_t *cl_flags = nullptr;                             // [16] device words: what the side streams' gate kernels wait for (stage A0's forks, round 6)
+    uint32_t cl_epoch = 0;                                    // ... the value the current run's forks write there
     // profiling events: 6 per run
     std::vector<hipEvent_t> ev_pool;
     std::vector<uint8_t> ev_kmask;         // per profiled run: the kernels that ran (bit i = kernel i; the two-launch E/F has no ef_seed_sort)

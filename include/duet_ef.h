@@ -151,6 +151,8 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
                                           * and 64 contigs: two -- every finalize tile builds its contig's seed set itself (ef_finalize_own) */
 #define DUET_DBG_EF_OWN_ALL 0x1000000u    /* ... the two launches at every size (up to 64 contigs) */
 #define DUET_DBG_EF_OWN_SMALLTAB 0x2000000u /* ... and their seed set in LDS holds 8 distinct seeds (default 2048): contigs with more take the array-free walk */
+#define DUET_DBG_CLUSTER_EVENT_FORKS 0x4000000u /* A0: the side streams fork off behind hipEventRecord / hipStreamWaitEvent (rounds 1-5) instead of a signal kernel on the
+                                          * main stream and a gate kernel on the side stream (round 6) */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */
