@@ -217,6 +217,9 @@ typedef struct duet_cluster_result {
     uint32_t *n_cands;
 } duet_cluster_result;
 
+/* (Up to 4 M marks the stage's side-stream chains fork off and join through one-lane signal / gate kernels and a per-call epoch word
+ * of the context, not through events -- an event record cost the main stream 7-14 us each.  Such a call cannot be captured into a
+ * hipGraph: set DUET_DBG_CLUSTER_EVENT_FORKS with duet_ctx_set_debug for that; it also applies to duet_svim_phase_device.) */
 DUET_API int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res,
                             void *stream);
 DUET_API int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res);

@@ -37,7 +37,9 @@ def check(ctx, marks, **kw):
                        (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800), (True, 0x4000), (False, 0x8000),
                        (True, 0x10000), (False, 0x10200), (True, 0x14000), (False, 0x4200), (True, 0x10800),
                        (True, 0x20000), (False, 0x20200), (True, 0x21200),
-                       (True, 0x40000), (False, 0x40000), (True, 0x40100), (True, 0x40800), (True, 0x44000), (True, 0x41000), (True, 0x42000), (True, 0x60000)):
+                       (True, 0x40000), (False, 0x40000), (True, 0x40100), (True, 0x40800), (True, 0x44000), (True, 0x41000), (True, 0x42000), (True, 0x60000),
+                       # DUET_DBG_CLUSTER_EVENT_FORKS = 0x4000000 (round 6): the side streams behind events instead of signal / gate kernels
+                       (True, 0x4000000), (False, 0x4040000), (True, 0x4002000)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)
