@@ -129,6 +129,10 @@ struct ClParams {
     // a fork without an event (cl_gate): the kernel in front of which the side stream forks off writes the run's epoch here as it starts
     uint32_t *fork_flag;
     uint32_t fork_epoch;
+    // small inputs, the partitions of 33..64 marks on four wavefronts each (cl_wide_list on the side stream): cl_fast_all says when it
+    // starts (cl_box is through then) and takes the classes of fast_classes only
+    uint32_t *box_done_flag;
+    uint32_t fast_classes;
 };
 
 __device__ __forceinline__ uint64_t centre_of(uint32_t pos, uint32_t span) { return (uint64_t)pos + (span >> 1); }
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(kBoxThreads) void cl_box(const ClParams p, const ui
                 p.pc[p_lo + j] = 1;
             } else {
                 cls = size_class(n);
-                if (cls == 4) cls = -1;                      // (cl_tight_big finds them itself: its launch starts before this kernel is done)
+                if (cls == 4) cls = -1;                      // (cl_tight_big / cl_find_big finds them itself: its launch starts before this kernel is done)
             }
         }
         // append the others to their class lists (wave-aggregated)
@@ -1019,24 +1023,39 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
                 const uint32_t tmax = (!(nn_ & 1u) && k >= half) ? half - 1 : half;
                 const uint32_t ek32 = pk[r] + spk[r], ck32 = pk[r] + (spk[r] >> 1);
                 const uint64_t ek = (uint64_t)pk[r] + spk[r], ck = centre_of(pk[r], spk[r]);
-                for (uint32_t t = 1; t <= tmax; ++t) {
-                    uint32_t j = k + t;
-                    j = j >= nn_ ? j - nn_ : j;
-                    const uint32_t pj = X.pos[sub][j], spj = X.span[sub][j];
-                    uint32_t m;
-                    if (!wide) {
-                        m = min(min(absdiff_u32(pk[r], pj), absdiff_u32(ek32, pj + spj)), absdiff_u32(ck32, pj + (spj >> 1)));
-                    } else {
-                        const uint64_t ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
-                        const uint64_t m2 = ek > ej ? ek - ej : ej - ek, m3 = ck > cj ? ck - cj : cj - ck;
-                        const uint64_t mm = m2 < m3 ? m2 : m3;
-                        m = absdiff_u32(pk[r], pj);
-                        m = mm < (uint64_t)m ? (uint32_t)mm : m;
+                // (four columns at a time, their rows' loads side by side: a column that waited for its (pos, span) and then for the other
+                // row's reciprocal was two dependent LDS trips -- 3.2 us of a unit's 16 at 1.0 M marks)
+                for (uint32_t t0 = 1; t0 <= tmax; t0 += 4) {
+                    uint32_t jj[4], pj4[4], spj4[4];
+                    double ij4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint32_t j = k + min(t0 + u, tmax);
+                        j = j >= nn_ ? j - nn_ : j;
+                        jj[u] = j;
+                        pj4[u] = X.pos[sub][j];
+                        spj4[u] = X.span[sub][j];
+                        ij4[u] = X.inv[sub][j];
                     }
-                    const uint32_t sdif = absdiff_u32(spk[r], spj);
-                    const double inv = spk[r] > spj ? ik : X.inv[sub][j];        // 1 / the larger span (the same number when they are equal)
-                    const double dp = (double)m * p.invn, ds = (double)sdif * inv;
-                    S[at(k, j)] = quantise(dp + ds, p.scale);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (t0 + u > tmax) continue;
+                        const uint32_t pj = pj4[u], spj = spj4[u];
+                        uint32_t m;
+                        if (!wide) {
+                            m = min(min(absdiff_u32(pk[r], pj), absdiff_u32(ek32, pj + spj)), absdiff_u32(ck32, pj + (spj >> 1)));
+                        } else {
+                            const uint64_t ej = (uint64_t)pj + spj, cj = centre_of(pj, spj);
+                            const uint64_t m2 = ek > ej ? ek - ej : ej - ek, m3 = ck > cj ? ck - cj : cj - ck;
+                            const uint64_t mm = m2 < m3 ? m2 : m3;
+                            m = absdiff_u32(pk[r], pj);
+                            m = mm < (uint64_t)m ? (uint32_t)mm : m;
+                        }
+                        const uint32_t sdif = absdiff_u32(spk[r], spj);
+                        const double inv = spk[r] > spj ? ik : ij4[u];            // 1 / the larger span (the same number when they are equal)
+                        const double dp = (double)m * p.invn, ds = (double)sdif * inv;
+                        S[at(k, jj[u])] = quantise(dp + ds, p.scale);
+                    }
                 }
             }
         }
@@ -1070,25 +1089,41 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
             if (alive[r]) X.rep[sub][me] = (uint8_t)(dies[r] ? into[r] : me);
         }
         __syncthreads();
+        // one pass of LDS adds (round 6; the tight groups' step below has the argument): every entry {x, s} with s a cluster that goes adds
+        // itself to {x's cluster, s's cluster} -- the lane of x does it, of two clusters that both go the smaller one's; entries that
+        // receive have two clusters that stay for indices, entries that give one that goes.  (Rounds 3-5: one merge after the other, each
+        // a dependent read-add-write with a barrier behind it -- as many steps as clusters go in the round.)
         uint32_t nd_max = nd;
 #pragma unroll
         for (int d = 32; d >= GROUP && d > 0; d >>= 1) nd_max = max(nd_max, (uint32_t)__shfl_xor((int)nd_max, d, 64));
-        for (uint32_t t = 0; t < nd_max; ++t) {
-            const bool on = t < nd;
-            const uint32_t dst = X.mdst[sub][on ? t : 0u], src = X.msrc[sub][on ? t : 0u];
-            const int rb_d = rowbase(dst), rb_s = rowbase(src);
+        for (uint32_t t = 0; t < nd_max; t += 4) {
+            const uint32_t d4 = *reinterpret_cast<const uint32_t *>(&X.mdst[sub][t]), s4 = *reinterpret_cast<const uint32_t *>(&X.msrc[sub][t]);
+            double v[4][R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t me = sl + r * GROUP;
-                const bool mine = on && alive[r] && me != dst && me != src;
-                const int i_d = me < dst ? rb_me[r] + (int)dst : rb_d + (int)me;
-                const int i_s = me < src ? rb_me[r] + (int)src : rb_s + (int)me;
-                const double v = S[mine ? i_d : NT + 1] + S[mine ? i_s : NT + 1];
-                S[mine ? i_d : NT + 1] = v;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t dst = (d4 >> (8 * u)) & 0xFFu, src = (s4 >> (8 * u)) & 0xFFu;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t me = sl + r * GROUP;
+                    const uint32_t mine_c = dies[r] ? into[r] : me;              // my cluster after the round
+                    const bool give = t + u < nd && alive[r] && me != src && mine_c != dst && !(dies[r] && me > src);
+                    v[u][r] = S[give ? at(me, src) : NT + 1];
+                }
             }
-            if (on && sl == 0) X.size[sub][dst] = (uint8_t)((uint32_t)X.size[sub][dst] + (uint32_t)X.size[sub][src]);
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t dst = (d4 >> (8 * u)) & 0xFFu, src = (s4 >> (8 * u)) & 0xFFu;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t me = sl + r * GROUP;
+                    const uint32_t mine_c = dies[r] ? into[r] : me;
+                    const bool on = t + u < nd && alive[r];
+                    if (on && me != src && mine_c != dst && !(dies[r] && me > src)) unsafeAtomicAdd(&S[at(mine_c, dst)], v[u][r]);
+                    if (on && me == dst) X.size[sub][dst] = (uint8_t)((uint32_t)X.size[sub][dst] + (uint32_t)X.size[sub][src]);
+                }
+            }
         }
+        __syncthreads();
         // every row follows its cluster; the clusters that are left, ascending, with their sizes
         BitSet<NW> after = live;
         for (int i = 0; i < NW; ++i) after.w[i] &= ~dead.w[i];
@@ -1125,16 +1160,42 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
 #pragma unroll
         for (int r = 0; r < R; ++r) { g1[r].clear(); g2[r].clear(); }
         constexpr double kHalf = (double)(kQOne / 2), kQuarter = (double)(kQOne / 4);
-        for (uint32_t k = 0; k < n_all; ++k) {
-            const int rb_k = rowbase(k);
+        // (32 columns at a time, the bits of a mask word collected in one register, four entries' loads side by side)
+        for (uint32_t k0 = 0; k0 < n_all; k0 += 32) {
+            uint32_t a1[R], a2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a1[r] = a2[r] = 0;
+            const uint32_t k1 = min(n_all, k0 + 32u);
+            for (uint32_t k = k0; k < k1; k += 4) {
+                double sv[4][R];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t kk = k + u;
+                    const int rb_k = rowbase(kk);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t me = sl + r * GROUP;
+                        int idx = me < kk ? rb_me[r] + (int)kk : rb_k + (int)me;
+                        idx = (me == kk || kk >= nn_ || !alive[r]) ? NT : idx;
+                        sv[u][r] = S[idx];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        a1[r] |= (sv[u][r] <= kHalf ? 1u : 0u) << (k + u - k0);
+                        a2[r] |= (sv[u][r] <= kQuarter ? 1u : 0u) << (k + u - k0);
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const uint32_t me = sl + r * GROUP;
-                int idx = me < k ? rb_me[r] + (int)k : rb_k + (int)me;
-                idx = (me == k || k >= nn_ || !alive[r]) ? NT : idx;
-                const double sv = S[idx];
-                g1[r].set_if(sv <= kHalf, k);
-                g2[r].set_if(sv <= kQuarter, k);
+                for (int i = 0; i < NW; ++i) {
+                    const bool here = NW == 1 || (k0 >> 6) == (uint32_t)i;
+                    g1[r].w[i] |= here ? (uint64_t)a1[r] << (k0 & 63u) : 0ull;
+                    g2[r].w[i] |= here ? (uint64_t)a2[r] << (k0 & 63u) : 0ull;
+                }
             }
         }
         bool dies[R];
@@ -1180,65 +1241,47 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
         }
         const BitSet<NW> dead = group_ballot<GROUP, R, NW>(dies, sub);
         if (__ballot(dead.any())) {
-            // the groups' sums.  Group after group (all lanes of a partition walk the same list of heads and members):
-            // every row outside the group adds up its entries to the group's members and leaves the sum at the group's head --
-            // {i, head} = sum over j in the group of {i, j}.  A row of an EARLIER group finds at {i, j} what j collected
-            // for i's group, so after the last group {head_g, head_h} holds every member pair of g x h.  One pass over a row's
-            // entries instead of one dependent read-add-write per dying row.
-            bool head[R];
-            BitSet<NW> mine[R];
+            // the groups' sums in ONE pass of LDS adds (round 6): every unordered pair {i, j} of rows whose groups differ adds its entry to its
+            // groups' entry {head(i), head(j)} -- unless it IS that entry.  An entry that receives has two heads for indices, an entry
+            // that gives has a row that goes: nobody reads what somebody else writes, no barrier inside, and the adds are sums of integers
+            // below 2^53 in binary64 (exact, any order).  The pairs are dealt as in the pair pass above.  (Rounds 3-5 went group after
+            // group: per group a walk over its members with two barriers -- 5.9 us per unit of cl_fast_all at 1.0 M marks, the largest
+            // single item of its 16.)
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t me = sl + r * GROUP;
-                mine[r] = ok1[r] ? g1[r] : g2[r];
-                head[r] = alive[r] && into[r] == me && (ok1[r] || ok2[r]) && mine[r].count() > 1u;
-                if (head[r])
-                    for (int i = 0; i < NW; ++i) s_mask[me][i] = mine[r].w[i];
                 if (alive[r]) X.rep[sub][me] = (uint8_t)into[r];
             }
-            BitSet<NW> heads = group_ballot<GROUP, R, NW>(head, sub);
-            if (sl == 0) S[NT + 1] = 0.0;
             __syncthreads();
-            uint32_t nh_max = heads.count();
-#pragma unroll
-            for (int d = 32; d >= GROUP && d > 0; d >>= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d, 64));
-            for (uint32_t t = 0; t < nh_max; ++t) {
-                const bool on = heads.any();
-                const uint32_t h = on ? heads.pop_first() : 0u;
-                BitSet<NW> mem;
-                for (int i = 0; i < NW; ++i) mem.w[i] = on ? s_mask[h][i] : 0ull;
-                double acc[R];
-                bool out[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    acc[r] = 0.0;
-                    out[r] = alive[r] && on && !mem.test(sl + r * GROUP);
-                }
-                const uint32_t cnt = mem.count();
-                uint32_t cnt_max = cnt;
-#pragma unroll
-                for (int d = 32; d >= GROUP && d > 0; d >>= 1) cnt_max = max(cnt_max, (uint32_t)__shfl_xor((int)cnt_max, d, 64));
-                for (uint32_t c = 0; c < cnt_max; ++c) {
-                    const bool more = mem.any();
-                    const uint32_t j = more ? mem.pop_first() : 0u;
-                    const int rb_j = rowbase(j);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t me = sl + r * GROUP;
-                        const int idx = me < j ? rb_me[r] + (int)j : rb_j + (int)me;
-                        acc[r] += S[(more && out[r]) ? idx : NT + 1];
-                    }
-                }
-                __syncthreads();                             // (every lane has read before anybody writes a head's column)
+            {
+                const uint32_t half = nn_ >> 1;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t me = sl + r * GROUP;
-                    if (out[r]) S[me < h ? rb_me[r] + (int)h : rowbase(h) + (int)me] = acc[r];
+                    if (alive[r]) {
+                        const uint32_t A = into[r];
+                        const uint32_t tmax = (!(nn_ & 1u) && me >= half) ? half - 1 : half;
+                        for (uint32_t t0 = 1; t0 <= tmax; t0 += 4) {
+                            uint32_t jj[4], B4[4];
+                            double v4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                uint32_t j = me + min(t0 + u, tmax);
+                                j = j >= nn_ ? j - nn_ : j;
+                                jj[u] = j;
+                                B4[u] = X.rep[sub][j];
+                                v4[u] = S[at(me, j)];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (t0 + u <= tmax && A != B4[u] && !(A == me && B4[u] == jj[u])) unsafeAtomicAdd(&S[at(A, B4[u])], v4[u]);
+                        }
+                        if (into[r] == me) X.size[sub][me] = (uint8_t)(ok1[r] ? g1[r].count() : (ok2[r] ? g2[r].count() : 1u));
+                    }
                 }
-                if (on && sl == 0) X.size[sub][h] = (uint8_t)cnt;
-                __syncthreads();
             }
+            __syncthreads();
             // every row follows its group; the clusters that are left, ascending, with their sizes
             BitSet<NW> after = live;
             for (int i = 0; i < NW; ++i) after.w[i] &= ~dead.w[i];
@@ -2252,15 +2295,21 @@ __global__ __launch_bounds__(64, 6) void cl_tight_all(const ClParams p, uint32_t
 // Small inputs (one launch's worth of partitions: the chip is not full and a partition's own chain of dependent steps is what
 // takes the time): the threshold graph and, in the same wavefront, the full-triangle linkage for what it does not settle --
 // one launch, nothing handed on.  Measured at 1.0 M marks: 86 us against 70 + 60 us for the two tiers above.
-constexpr size_t kFastSmemBytes = cmax(cmax(sizeof(FastSmem<64, 1>), sizeof(FastSmem<32, 1>)), cmax(sizeof(FastSmem<16, 1>), sizeof(FastSmem<8, 1>)));
-constexpr size_t kLinkSmemBytes = cmax(cmax(sizeof(LinkSmem<64, 1, 64>), sizeof(LinkSmem<32, 1, 32>)), cmax(sizeof(LinkSmem<16, 1, 16>), sizeof(LinkSmem<8, 1, 8>)));
+constexpr size_t kFastSmemBytes32 = cmax(sizeof(FastSmem<32, 1>), cmax(sizeof(FastSmem<16, 1>), sizeof(FastSmem<8, 1>)));
+constexpr size_t kLinkSmemBytes32 = cmax(sizeof(LinkSmem<32, 1, 32>), cmax(sizeof(LinkSmem<16, 1, 16>), sizeof(LinkSmem<8, 1, 8>)));
+constexpr size_t kFastSmemBytes = cmax(sizeof(FastSmem<64, 1>), kFastSmemBytes32);
+constexpr size_t kLinkSmemBytes = cmax(sizeof(LinkSmem<64, 1, 64>), kLinkSmemBytes32);
 
+// C64: the class of 33..64 marks is this launch's too (else the four-wavefront units of cl_wide_list have it: the launch holds the scratch of
+// 32 rows, 10 KB instead of 19, and all its workgroups are resident at once at 1.0 M marks)
+template <bool C64>
 __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32_t *lists, const uint32_t *cnts /* [kClasses][kShards] */)
 {
     CL_STAMP_INIT(4);
-    __shared__ __align__(16) unsigned char smem[kFastSmemBytes];
-    __shared__ __align__(16) unsigned char smem_link[kLinkSmemBytes];
+    __shared__ __align__(16) unsigned char smem[C64 ? kFastSmemBytes : kFastSmemBytes32];
+    __shared__ __align__(16) unsigned char smem_link[C64 ? kLinkSmemBytes : kLinkSmemBytes32];
     __shared__ uint32_t s_pref[kShards + 1];               // the running sums of ONE class's shard counters at a time
+    if (p.box_done_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(p.box_done_flag, p.fork_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     // the classes' totals (one wavefront: a lane per shard)
     uint32_t tot[4];
 #pragma unroll
@@ -2268,7 +2317,7 @@ __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32
         uint32_t x = cnts[c * kShards + (threadIdx.x & 63u)];
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d, 64);
-        tot[c] = x;
+        tot[c] = (((p.fast_classes >> c) & 1u) && (C64 || c < 3)) ? x : 0u;
     }
     const size_t M = p.M;
     const uint32_t span = p.tps * kScanTile;
@@ -2283,8 +2332,9 @@ __global__ __launch_bounds__(64) void cl_fast_all(const ClParams p, const uint32
             loaded = c;
         }
         const WorkList l{lists + (size_t)c * M, s_pref, span, 0u};
-        if (c == 3) fast_unit<64, 1, 64, kFastThenLink>(p, l, vb, smem, smem_link);
-        else if (c == 2) fast_unit<32, 1, 32, kFastThenLink>(p, l, (vb - b3) * 2, smem, smem_link);
+        if (c == 3) {
+            if constexpr (C64) fast_unit<64, 1, 64, kFastThenLink>(p, l, vb, smem, smem_link);
+        } else if (c == 2) fast_unit<32, 1, 32, kFastThenLink>(p, l, (vb - b3) * 2, smem, smem_link);
         else if (c == 1) fast_unit<16, 1, 16, kFastThenLink>(p, l, (vb - b2) * 4, smem, smem_link);
         else fast_unit<8, 1, 8, kFastThenLink>(p, l, (vb - b1) * 8, smem, smem_link);
     }
@@ -2361,6 +2411,431 @@ __global__ __launch_bounds__(64) void cl_link_one(const ClParams p, const uint32
         fast_unit<GROUP, R, NCAP, kLinkOnly>(p, list, base, smem, smem_link);
 }
 
+// ---------------------------------------------------------------------------------------------
+// agglomeration, small inputs: one partition on FOUR (EIGHT) wavefronts (round 6)
+// ---------------------------------------------------------------------------------------------
+//
+// On a small input the chip is not full and a launch lasts as long as its longest partition: a 64-mark partition on one wavefront is a
+// chain of 70 us (cl_fast_all), a 100-mark one 90 us (cl_tight_big + cl_link_one) -- pair pass, group sums and a dozen rounds, each a run
+// of dependent LDS trips (profiles/history/r05_agglomeration_chain_logs_config2.txt).  Here NCAP x 4 threads take ONE partition, four
+// lanes per row, and every phase is a handful of loads that leave together:
+//   * the sums live in a FULL symmetric matrix (row stride NCAP + 2): a lane's sixteen columns of its row are eight 16-byte loads side
+//     by side, with the columns' sizes in one more -- no index arithmetic, no dependent trips (the first version of this kernel kept
+//     link_unit's triangle and walked columns one at a time: 4 dependent trips per column, 85 us per 64-mark partition);
+//   * a CONTRACTION -- disjoint groups of clusters become one cluster each, rep[c] = the group's head -- is two passes of LDS atomics
+//     (sums of integers below 2^53 in binary64: exact, order-free): every row adds its entries at dying columns to the heads' columns,
+//     then every dying row adds its entries at surviving columns to its head's row.  Targets are never sources within a pass;
+//   * the tight groups of link_unit (components of {q <= threshold / 2} or {/ 4} that are cliques: nodes of the merge tree, its
+//     comment has the argument) are one contraction; every round of mutual nearest neighbours is another, with groups of one or two;
+//   * nearest neighbours: a row's four lanes scan their sixteen columns each and meet by shuffles (smaller mean, ties to the smaller
+//     index: what one lane walking the columns in order finds).
+// Exact sums of integers: any evaluation that merges provably-first groups arrives at the oracle's clusters (oracle/cluster_oracle.c,
+// rule 4 and the comment above link_unit).  Four barriers per round.
+template <int NCAP>
+struct WideSmem {
+    static constexpr int NW = NCAP > 64 ? 2 : 1, LD = NCAP + 2;
+    double S[NCAP * LD];                                     // S[a * LD + b]: the sum over the member pairs of clusters a and b (symmetric; the diagonal is never read)
+    double inv[NCAP];
+    uint2 ps[NCAP];
+    uint32_t mk[NCAP], rd[NCAP];
+    uint64_t m1[NCAP][NW], m2[NCAP][NW];                     // neighbourhoods at threshold / 2 and / 4; m1 later: the clusters' rows, at their heads
+    unsigned long long sum[NCAP][2];
+    uint64_t pass[2][NW], heads[NW], amask[2][NW];           // amask: the clusters that stay, as the step decides it
+    uint32_t deaths, na[2];
+    uint16_t acl[2][NCAP];                                   // the clusters that are left, ascending: id | size << 8 (a step reads one list and writes the other)
+    uint8_t size[NCAP];                                      // by cluster id (what a cluster that is gone leaves here is never read)
+    uint8_t rep[NCAP];                                       // this step: the cluster a cluster goes into (itself: it stays)
+    uint8_t nn[NCAP], root[NCAP];
+};
+
+template <int NW>
+__device__ __forceinline__ BitSet<NW> bits_load(const uint64_t (&m)[NW])
+{
+    BitSet<NW> b;
+    for (int i = 0; i < NW; ++i) b.w[i] = m[i];
+    return b;
+}
+
+// part: a partition of up to NCAP rows, on NCAP * 4 threads; gather: its rows come through the sort permutation (no cl_box before this launch)
+template <int NCAP>
+__device__ __forceinline__ void wide_unit(const ClParams &p, uint32_t part, bool gather, WideSmem<NCAP> &X)
+{
+    constexpr int NW = WideSmem<NCAP>::NW, LD = WideSmem<NCAP>::LD, LPR = 4, CH = NCAP / LPR, T = NCAP * LPR;
+    static_assert(CH % 16 == 0, "a lane takes its columns sixteen at a time");
+    const uint32_t tid = threadIdx.x, row0 = tid / LPR, q0 = tid % LPR;
+    const uint32_t s = p.part_start[part], n = p.part_start[part + 1] - s;
+    auto shfl64 = [](uint64_t v, int d) -> uint64_t {
+        return ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
+    };
+    double *S = X.S;
+    CL_STAMP(0x40);
+    __syncthreads();                                         // (the unit before this one is through with the scratch)
+    if (tid < (uint32_t)NCAP) {
+        uint32_t pk = 0, sp = 0, rdv = 0, mkv = 0;
+        if (tid < n) {
+            if (gather) {
+                mkv = mark_at(p, s + tid);
+                const uint3 r3 = load_rec(p, mkv);
+                pk = r3.x; sp = r3.y; rdv = r3.z;
+            } else {
+                const uint4 r4 = p.srec[s + tid];
+                pk = r4.x; sp = r4.y; rdv = r4.z; mkv = r4.w & p.idx_mask;
+            }
+        }
+        X.ps[tid] = make_uint2(pk, sp);
+        X.rd[tid] = rdv;
+        X.mk[tid] = mkv;
+        X.inv[tid] = sp ? 1.0 / (double)sp : 0.0;
+        X.size[tid] = 1;
+        X.acl[0][tid] = (uint16_t)(tid | 0x100u);
+        X.rep[tid] = (uint8_t)tid;
+        X.root[tid] = (uint8_t)tid;
+    }
+    if (tid == 0) {
+        X.deaths = 0;
+        X.na[0] = n;
+        for (int l = 0; l < 2; ++l)
+            for (int i = 0; i < NW; ++i) { X.pass[l][i] = 0; X.amask[l][i] = 0; }
+    }
+    __syncthreads();
+    CL_STAMP(0x41);
+    const bool live = row0 < n;
+    // every unordered pair once (link_unit's scheme), a row's columns dealt to its lanes; 64-bit ends and centres throughout
+    if (live) {
+        const uint32_t half = n >> 1, tmax = (!(n & 1u) && row0 >= half) ? half - 1u : half;
+        const uint2 me = X.ps[row0];
+        const double ik = X.inv[row0];
+        const uint64_t ek = (uint64_t)me.x + me.y, ck = centre_of(me.x, me.y);
+        for (uint32_t t = 1u + q0; t <= tmax; t += LPR) {
+            uint32_t j = row0 + t;
+            j = j >= n ? j - n : j;
+            const uint2 o = X.ps[j];
+            const double ij = X.inv[j];
+            const uint64_t ej = (uint64_t)o.x + o.y, cj = centre_of(o.x, o.y);
+            const uint64_t m2 = ek > ej ? ek - ej : ej - ek, m3 = ck > cj ? ck - cj : cj - ck;
+            const uint64_t mm = m2 < m3 ? m2 : m3;
+            uint32_t m = absdiff_u32(me.x, o.x);
+            m = mm < (uint64_t)m ? (uint32_t)mm : m;
+            const uint32_t sdif = absdiff_u32(me.y, o.y);
+            const double inv = me.y > o.y ? ik : ij;                             // 1 / the larger span
+            const double dp = (double)m * p.invn, ds = (double)sdif * inv;
+            const double v = quantise(dp + ds, p.scale);
+            S[row0 * LD + j] = v;
+            S[j * LD + row0] = v;
+        }
+    }
+    __syncthreads();
+    CL_STAMP(0x42);
+    uint32_t L = 0, seen = 0;
+    // A step works on the clusters that are left (list L, na of them): as many lanes per cluster as the threads allow (four when all
+    // NCAP are there, up to 64), a cluster's columns -- the list again -- dealt to its lanes one by one.  What a step costs falls with
+    // the square of what is left.
+    // Once kSolo clusters or fewer are left the first wavefront goes on ALONE (four lanes per cluster and more): what is left of a round is its
+    // chain of dependent LDS trips, and without the other wavefronts its barriers are no more than waits for the wave's own LDS traffic
+    // (3 us per round with the barriers, whatever is left)
+    constexpr uint32_t kSolo = 16;
+    uint32_t na = n, lg = 0, row = 0, q = 0, chd = 0, te = T;
+    bool has = false, solo = false;
+    auto sync = [&]() {
+        if (solo) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __syncthreads();
+        }
+    };
+    auto deal = [&]() {
+        na = X.na[L];
+        lg = min(6u, 31u - (uint32_t)__clz((int)(te / max(na, 1u))));
+        const uint32_t ri = tid >> lg;
+        q = tid & ((1u << lg) - 1u);
+        has = ri < na;
+        row = has ? (uint32_t)X.acl[L][ri] & 0xFFu : 0u;
+        chd = (na + (1u << lg) - 1u) >> lg;
+    };
+    // the contraction that X.rep describes (sizes and X.amask[L ^ 1] say what the clusters that stay look like afterwards)
+    auto contract = [&]() {
+        const uint16_t *acl = X.acl[L];
+        if (has) {
+            for (uint32_t u0 = 0; u0 < chd; u0 += 4) {
+                uint32_t col[4], h[4];
+                double v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t ci = q + ((u0 + k) << lg);
+                    col[k] = ci < na ? (uint32_t)acl[ci] & 0xFFu : row;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { h[k] = X.rep[col[k]]; v[k] = S[row * LD + col[k]]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (h[k] != col[k] && q + ((u0 + k) << lg) < na) unsafeAtomicAdd(&S[row * LD + h[k]], v[k]);
+            }
+            if (q == 0 && X.rep[row] == row) {
+                const BitSet<NW> stay = bits_load<NW>(X.amask[L ^ 1u]);
+                X.acl[L ^ 1u][stay.count_below(row)] = (uint16_t)(row | ((uint32_t)X.size[row] << 8));
+            }
+        }
+        if (tid == 0) X.na[L ^ 1u] = bits_load<NW>(X.amask[L ^ 1u]).count();
+        for (uint32_t r = tid; r < n; r += te) X.root[r] = X.rep[X.root[r]];
+        sync();
+        const uint32_t head = has ? X.rep[row] : row;
+        if (head != row) {
+            for (uint32_t u0 = 0; u0 < chd; u0 += 4) {
+                uint32_t col[4], h[4];
+                double v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t ci = q + ((u0 + k) << lg);
+                    col[k] = ci < na ? (uint32_t)acl[ci] & 0xFFu : row;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { h[k] = X.rep[col[k]]; v[k] = S[row * LD + col[k]]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (h[k] == col[k] && q + ((u0 + k) << lg) < na) unsafeAtomicAdd(&S[head * LD + col[k]], v[k]);     // (col = row: its head is not itself)
+            }
+        }
+        sync();
+        L ^= 1u;
+    };
+    if (p.mergeable) {
+        // tight groups (link_unit): neighbourhoods at the two levels; every row is there, four lanes each, sixteen columns at a time
+        constexpr double kHalf = (double)(kQOne / 2), kQuarter = (double)(kQOne / 4);
+        BitSet<NW> g1, g2;
+        g1.clear();
+        g2.clear();
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < CH; c += 16) {
+                const uint32_t c0 = q0 * CH + c;
+                if (c0 >= n) continue;
+                double2 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2 *>(&S[row0 * LD + c0 + 2 * k]);
+                uint32_t b1 = 0, b2 = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t j = c0 + k;
+                    const double sv = (k & 1) ? v[k >> 1].y : v[k >> 1].x;
+                    const bool in = j < n && j != row0;
+                    b1 |= (in && sv <= kHalf) ? 1u << k : 0u;
+                    b2 |= (in && sv <= kQuarter) ? 1u << k : 0u;
+                }
+                for (int i = 0; i < NW; ++i) {
+                    g1.w[i] |= (NW == 1 || (c0 >> 6) == (uint32_t)i) ? (uint64_t)b1 << (c0 & 63u) : 0ull;
+                    g2.w[i] |= (NW == 1 || (c0 >> 6) == (uint32_t)i) ? (uint64_t)b2 << (c0 & 63u) : 0ull;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < LPR; d <<= 1) {
+            for (int i = 0; i < NW; ++i) {
+                g1.w[i] |= shfl64(g1.w[i], d);
+                g2.w[i] |= shfl64(g2.w[i], d);
+            }
+        }
+        g1.set_if(live, row0);
+        g2.set_if(live, row0);
+        if (live && q0 == 0) {
+            for (int i = 0; i < NW; ++i) { X.m1[row0][i] = g1.w[i]; X.m2[row0][i] = g2.w[i]; }
+        }
+        __syncthreads();
+        bool ok1 = false, ok2 = false;
+        if (live) {
+            ok1 = bits_load<NW>(X.m1[g1.first()]).equals(g1);
+            ok2 = bits_load<NW>(X.m2[g2.first()]).equals(g2);
+            if (q0 == 0) {
+                if (ok1) atomicOr((unsigned long long *)&X.pass[0][NW == 1 ? 0 : (row0 >> 6)], 1ull << (row0 & 63u));
+                if (ok2) atomicOr((unsigned long long *)&X.pass[1][NW == 1 ? 0 : (row0 >> 6)], 1ull << (row0 & 63u));
+            }
+        }
+        __syncthreads();
+        if (live) {
+            // a row's component is a clique <=> the row and all its neighbours have the neighbourhood of their smallest member
+            const BitSet<NW> p1 = bits_load<NW>(X.pass[0]), p2 = bits_load<NW>(X.pass[1]);
+            for (int i = 0; i < NW; ++i) {
+                ok1 = ok1 && (g1.w[i] & ~p1.w[i]) == 0ull;
+                ok2 = ok2 && (g2.w[i] & ~p2.w[i]) == 0ull;
+            }
+            const uint32_t f = ok1 ? g1.first() : (ok2 ? g2.first() : row0);
+            if (q0 == 0) {
+                X.rep[row0] = (uint8_t)f;
+                if (f == row0) {
+                    X.size[row0] = (uint8_t)(ok1 ? g1.count() : (ok2 ? g2.count() : 1u));
+                    atomicOr((unsigned long long *)&X.amask[1][NW == 1 ? 0 : (row0 >> 6)], 1ull << (row0 & 63u));
+                } else {
+                    atomicAdd(&X.deaths, 1u);
+                }
+            }
+        }
+        __syncthreads();
+        seen = X.deaths;
+        CL_STAMP(0x43);
+        if (seen) {
+            deal();
+            contract();
+        }
+        CL_STAMP(0x44);
+    }
+    // rounds of mutual nearest neighbours
+    for (uint32_t round = 0; round < 2u * NCAP && p.mergeable; ++round) {
+        CL_STAMP(0x45);
+        if (!solo && X.na[L] <= kSolo) {
+            if (tid >= 64u) break;                                               // (the other wavefronts wait in front of the emission)
+            solo = true;
+            te = 64u;
+        }
+        deal();
+        if (na < 2u) break;
+        const uint16_t *acl = X.acl[L];
+        double bs = kNothing, bn = 1.0;
+        uint32_t bk = 0xFFu;
+        if (has) {
+            for (uint32_t u0 = 0; u0 < chd; u0 += 4) {
+                uint32_t e[4];
+                double v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t ci = q + ((u0 + k) << lg);
+                    e[k] = ci < na ? (uint32_t)acl[ci] : row;                    // (beyond the list: the cluster itself, which is skipped)
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = S[row * LD + (e[k] & 0xFFu)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t j = e[k] & 0xFFu;
+                    const double sv = (j != row && v[k] <= kFar) ? v[k] : kNothing;
+                    const double nk = (double)(e[k] >> 8);
+                    const bool better = sv * bn < bs * nk;
+                    bs = better ? sv : bs;
+                    bn = better ? nk : bn;
+                    bk = better ? j : bk;
+                }
+            }
+        }
+        CL_STAMP(0x48);
+        for (uint32_t d = 1; d < (1u << lg); d <<= 1) {
+            const double os = __shfl_xor(bs, (int)d, 64), on = __shfl_xor(bn, (int)d, 64);
+            const uint32_t ok = (uint32_t)__shfl_xor((int)bk, (int)d, 64);
+            const double l = os * bn, r = bs * on;
+            const bool take = l < r || (l == r && ok < bk);
+            bs = take ? os : bs;
+            bn = take ? on : bn;
+            bk = take ? ok : bk;
+        }
+        CL_STAMP(0x49);
+        if (has && q == 0) {
+            const bool within = bs <= (double)kQOne * (bn * (double)X.size[row]);
+            X.nn[row] = (uint8_t)(within ? bk : 0xFFu);
+        }
+        if (tid == 0)
+            for (int i = 0; i < NW; ++i) X.amask[L ^ 1u][i] = 0;
+        sync();
+        CL_STAMP(0x4A);
+        // mutual nearest neighbours merge, the larger index into the smaller
+        if (has && q == 0) {
+            const uint32_t k = X.nn[row];
+            const uint32_t pm = (k != 0xFFu && X.nn[k] == row) ? k : 0xFFu;
+            const bool dies = pm < row;                                           // (0xFF is not below any row)
+            X.rep[row] = (uint8_t)(dies ? pm : row);
+            if (dies) {
+                atomicAdd(&X.deaths, 1u);
+            } else {
+                if (pm != 0xFFu) X.size[row] = (uint8_t)((uint32_t)X.size[row] + (uint32_t)X.size[pm]);      // (pm goes: it writes nothing, nobody else reads this)
+                atomicOr((unsigned long long *)&X.amask[L ^ 1u][NW == 1 ? 0 : (row >> 6)], 1ull << (row & 63u));
+            }
+        }
+        sync();
+        CL_STAMP(0x4B);
+        const uint32_t d = X.deaths;
+        if (d == seen) break;
+        seen = d;
+        contract();
+        CL_STAMP(0x4C);
+    }
+    // the clusters' rows and sums at their heads (the head is the cluster's smallest row)
+    CL_STAMP(0x46);
+    __syncthreads();                                         // (everybody again)
+    if (tid < (uint32_t)NCAP) {
+        for (int i = 0; i < NW; ++i) X.m1[tid][i] = 0;
+        X.sum[tid][0] = 0;
+        X.sum[tid][1] = 0;
+    }
+    if (tid == 0)
+        for (int i = 0; i < NW; ++i) X.heads[i] = 0;
+    __syncthreads();
+    if (tid < n) {
+        const uint32_t r = X.root[tid];
+        const uint2 me = X.ps[tid];
+        atomicOr((unsigned long long *)&X.m1[r][NW == 1 ? 0 : (tid >> 6)], 1ull << (tid & 63u));
+        atomicAdd(&X.sum[r][0], (unsigned long long)me.x);
+        atomicAdd(&X.sum[r][1], (unsigned long long)me.y);
+        if (r == tid) atomicOr((unsigned long long *)&X.heads[NW == 1 ? 0 : (tid >> 6)], 1ull << (tid & 63u));
+    }
+    __syncthreads();
+    // what cl_emit needs (emit_prep): every mark's place in the output, the clusters' records
+    if (tid < n) {
+        const uint32_t rt = X.root[tid];
+        const BitSet<NW> F = bits_load<NW>(X.m1[rt]), H = bits_load<NW>(X.heads);
+        BitSet<NW> below = H;
+        uint32_t before = 0;
+        while (below.any()) {
+            const uint32_t h = below.pop_first();
+            if (h >= rt) break;
+            before += bits_load<NW>(X.m1[h]).count();
+        }
+        const uint32_t size = F.count(), rank = before + F.count_below(tid);
+        p.order[s + rank] = X.mk[tid];
+        if (p.sv_mark_out) p.sv_mark_out[s + rank] = X.rd[tid];
+        if (rt == tid) {
+            const uint32_t ci = H.count_below(rt);
+            uint4 *at_ = ci ? p.e_rec + (s + ci) : p.e_first + part;
+            *at_ = make_uint4(rank | ((before + size) << 8), (uint32_t)((double)X.sum[tid][0] / (double)size),
+                              (uint32_t)((double)X.sum[tid][1] / (double)size), p.rec_mode ? p.srec[s].w >> p.idx_bits : 0u);
+        }
+        if (tid == 0) p.pc[part] = H.count();
+    }
+    CL_STAMP(0x47);
+}
+
+// the partitions of more than 64 marks, found from the partition starts alone (cl_tight_big's scheme: the launches start beside cl_box) and
+// listed first: a workgroup per listed partition (one that found two in its own stretch of partitions took them one after the other --
+// 70 us for the launch where a unit takes 35)
+__global__ __launch_bounds__(256) void cl_find_big(const ClParams p, uint32_t *big_list, uint32_t *count /* zero on entry */)
+{
+    const uint32_t n_parts = *p.n_parts;
+    for (uint32_t part = blockIdx.x * 256u + threadIdx.x; part < n_parts; part += gridDim.x * 256u)
+        if (p.part_start[part + 1] - p.part_start[part] > 64u) big_list[atomicAdd(count, 1u)] = part;
+}
+__global__ __launch_bounds__(512) void cl_wide_big(const ClParams p, const uint32_t *big_list, const uint32_t *count)
+{
+    CL_STAMP_INIT(3);
+    __shared__ WideSmem<128> X;
+    const uint32_t cnt = *count;
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) wide_unit<128>(p, big_list[i], p.gather_rows != 0u, X);
+}
+
+// the listed partitions of the classes c_lo .. 3 (up to 64 marks; their rows where cl_box laid them out).  Tests only (DUET_DBG_CLUSTER_WIDE_ALL):
+// measured at 1.0 M marks the four-wavefront units LOSE on these partitions, whatever sizes they take (profiles/history/r06_wide_units.txt)
+__global__ __launch_bounds__(256) void cl_wide_list(const ClParams p, const uint32_t *lists, const uint32_t *cnts /* [kClasses][kShards] */, uint32_t c_lo)
+{
+    CL_STAMP_INIT(5);
+    __shared__ WideSmem<64> X;
+    __shared__ uint32_t s_pref[kShards + 1];
+    const uint32_t span = p.tps * kScanTile;
+    for (uint32_t c = 3; c + 1u > c_lo; --c) {
+        __syncthreads();
+        if (threadIdx.x < 64u) worklist_prefix(cnts + c * kShards, s_pref);
+        __syncthreads();
+        const WorkList l{lists + (size_t)c * p.M, s_pref, span, 0u};
+        const uint32_t L = l.size();
+        for (uint32_t i = blockIdx.x; i < L; i += gridDim.x) wide_unit<64>(p, l[i], false, X);
+        if (c == 0u) break;
+    }
+}
+
 // One LANE PER CLUSTER: a wavefront takes 64 consecutive partitions (their count lives on the device: the grid strides over an upper
 // bound), and their clusters -- records dense from each partition's start, candidates cbase[part] ... -- are dealt to the lanes
 // 64 at a time: a lane finds its cluster's partition among the wave's 64 by bisection over the lanes' candidate bases (six
@@ -2383,6 +2858,18 @@ __global__ void cl_gate(const uint32_t *flag, uint32_t epoch)
     const unsigned long long t0 = wall_clock64();
     // (epochs only grow; a later run's value serves as well: its main stream is behind this run's)
     while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 200000000ull) __builtin_trap();
+    }
+}
+
+// (the join of two side streams in one launch)
+__global__ void cl_gate2(const uint32_t *flag_a, const uint32_t *flag_b, uint32_t epoch)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(flag_a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0 ||
+           (int32_t)(__hip_atomic_load(flag_b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(16);
         if (wall_clock64() - t0 > 200000000ull) __builtin_trap();
     }
@@ -2536,7 +3023,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const uint32_t nb_rx = (M + kRxTile - 1) / kRxTile;
     const uint32_t nb_hs = (256u * nb_rx + kScanTile - 1) / kScanTile;      // scan tiles of the radix histogram
     int rc;
-    if ((rc = duet_reserve(ctx, ctx->cl_ws[11], 4 * (64 + 2 * kClasses * kShards)))) return rc;
+    if ((rc = duet_reserve(ctx, ctx->cl_ws[11], 4 * ((size_t)64 + 2 * kClasses * kShards + M / 64 + 16)))) return rc;
     uint32_t *scal = (uint32_t *)ctx->cl_ws[11].ptr;      // [0] = n_parts
 
     ClParams p;
@@ -2596,7 +3083,7 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         const size_t sizes[16] = {rec_mode ? 16 : (size_t)M * 8, rec_mode ? 16 : (size_t)M * 8, (size_t)M * 4, rec_mode ? (size_t)M * 2 + 16 : (size_t)M * 4,
                                   rec_mode ? hist_rec : hist_legacy,
                                   ((size_t)nb_sc + 1) * sizeof(PartSum) + 16 + (size_t)nb_sc * kScanThreads, ((size_t)nb_sc + 2) * 4, ((size_t)(nb_sc > nb_hs ? nb_sc : nb_hs) + 1) * 4,
-                                  ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * (64 + 2 * kClasses * kShards), (size_t)M * 4 * kClasses,
+                                  ((size_t)M + 1) * 4, (size_t)M * 16, (size_t)M * 4, 4 * ((size_t)64 + 2 * kClasses * kShards + M / 64 + 16), (size_t)M * 4 * kClasses,
                                   ((size_t)M + 1) * 4 * 2 + 16 + (size_t)M * ((sv || rec_mode) ? 16 : 8), (size_t)M * 16, (size_t)M * 16};
         for (int i = 0; i < 16; ++i)
             if ((rc = duet_reserve(ctx, ctx->cl_ws[i], sizes[i]))) return rc;
@@ -2789,6 +3276,21 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // from the first tier's first launch -- measured: 2,187 against 2,127 us)
     const bool gate_forks = small && !(ctx->dbg & DUET_DBG_CLUSTER_EVENT_FORKS);
     const uint32_t epoch = ++ctx->cl_epoch;
+    const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
+    // small inputs: every partition of more than 64 marks on its own workgroup of eight wavefronts (wide_unit), on the side stream beside cl_box and
+    // cl_fast_all; DUET_DBG_CLUSTER_WIDE_ALL: every listed partition on four wavefronts as well (tests)
+    const bool wide = !tiers && !(ctx->dbg & DUET_DBG_CLUSTER_WIDE_OFF);
+    const bool wide_all = wide && (ctx->dbg & DUET_DBG_CLUSTER_WIDE_ALL);
+    // (measured, profiles/history/r06_wide_units.txt: for the listed partitions of up to 64 marks the four-wavefront units LOSE -- cl_fast_all is
+    // bound by the chip's throughput there, not by a chain -- so only the partitions of more than 64 marks take them outside the tests)
+    const bool wide_list = wide_all;
+    auto join_signal = [&]() -> int {
+        // the join the same way on small inputs: the side stream says when it is through, a gate on the main stream waits for it (the
+        // side stream's launches are queued in front of that gate, so even one shared hardware queue would run them first)
+        if (gate_forks) hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[0], ctx->cl_flags + 4, epoch);
+        else HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
+        return DUET_OK;
+    };
     auto launch_big = [&](bool next_kernel_signals) -> int {
         if (gate_forks) {
             if (!next_kernel_signals) hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, st, ctx->cl_flags + 0, epoch);
@@ -2799,16 +3301,18 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         }
         ClParams pb = p;
         pb.gather_rows = rec_mode ? 0u : 1u;                     // (rec_mode: the sorted rows are there already)
+        if (wide) {
+            uint32_t *big_parts = scal + 64 + 2 * kClasses * kShards;           // [M / 65 + 1] the partitions of more than 64 marks; o4[0] counts them
+            hipLaunchKernelGGL(cl_find_big, dim3(std::max(1u, std::min(512u, (M / 8u + 255u) / 256u))), dim3(256), 0, ctx->cl_side[0], pb, big_parts, o4);
+            hipLaunchKernelGGL(cl_wide_big, dim3(256), dim3(512), 0, ctx->cl_side[0], pb, (const uint32_t *)big_parts, (const uint32_t *)o4);
+            return join_signal();
+        }
         const uint32_t gb = std::min(4096u, std::max(256u, (M / 64u + 63u) / 64u));      // (partitions <= marks; 64 of them per wavefront and step)
         hipLaunchKernelGGL((cl_tight_big<64>), dim3(gb), dim3(64), 0, ctx->cl_side[0], pb, l4, o4, c4);
         const uint32_t gl = std::min(gb, 1024u);
         if (cap100) hipLaunchKernelGGL((cl_link_one<64, 2, 100>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
         else hipLaunchKernelGGL((cl_link_one<64, 2, 128>), dim3(gl), dim3(64), 0, ctx->cl_side[0], pb, (const uint32_t *)l4, (const uint32_t *)o4);
-        // the join the same way on small inputs: the side stream says when it is through, a gate on the main stream waits for it (the
-        // side stream's launches are queued in front of that gate, so even one shared hardware queue would run them first)
-        if (gate_forks) hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[0], ctx->cl_flags + 4, epoch);
-        else HIP_TRY(ctx, hipEventRecord(ctx->cl_join[0], ctx->cl_side[0]));
-        return DUET_OK;
+        return join_signal();
     };
     // (small inputs: cl_box itself signals as it starts -- a signal kernel of its own was 5.9 us on the main stream)
     p.fork_flag = (!box_applies && gate_forks) ? ctx->cl_flags + 0 : nullptr;
@@ -2816,7 +3320,6 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // (the side stream's launches are queued BEHIND cl_box's: were the two streams ever to share a hardware queue, a gate in front of the
     // kernel that opens it would never see it start; an event fork goes in front, as in rounds 1-5)
     if (!box_applies && !gate_forks && (rc = launch_big(false))) return rc;
-    const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // the bounding-box test finishes the partitions it can (on SV-like data: most) and lists the others by size class
     if (box_applies)
         hipLaunchKernelGGL((cl_box<true, true>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)nullptr, lists, cnts, (const uint8_t *)hbits, (const PartSum *)tiles, part_start, scal);
@@ -2826,8 +3329,24 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         hipLaunchKernelGGL((cl_box<false, false>), dim3(nb_sc), dim3(kBoxThreads), 0, st, p, (const uint32_t *)tile_first, lists, cnts, (const uint8_t *)nullptr, (const PartSum *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     if ((box_applies || gate_forks) && (rc = launch_big(!box_applies && gate_forks))) return rc;
     if (!tiers) {
-        // one launch for the classes of up to 64 marks, nothing handed on
-        hipLaunchKernelGGL(cl_fast_all, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
+        // one launch for the classes of up to 64 marks (32 beside the wide units), nothing handed on
+        if (wide_list && !gate_forks) {
+            HIP_TRY(ctx, hipEventRecord(ctx->cl_join[1], st));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_side[1], ctx->cl_join[1], 0));
+        }
+        p.fast_classes = wide_all ? 0u : 15u;
+        p.box_done_flag = (wide_list && gate_forks) ? ctx->cl_flags + 8 : nullptr;
+        if (wide_list) hipLaunchKernelGGL(cl_fast_all<false>, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
+        else hipLaunchKernelGGL(cl_fast_all<true>, dim3(gridw), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)cnts);
+        if (wide_list) {
+            // the listed partitions of 33..64 marks on a side stream of their own: behind cl_box (cl_fast_all's first workgroup says when that
+            // is), beside cl_fast_all and the partitions of more than 64
+            if (gate_forks) hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, ctx->cl_side[1], (const uint32_t *)(ctx->cl_flags + 8), epoch);
+            const uint32_t gwl = std::min(8192u, std::max(256u, M / 512u));
+            hipLaunchKernelGGL(cl_wide_list, dim3(gwl), dim3(256), 0, ctx->cl_side[1], p, (const uint32_t *)lists, (const uint32_t *)cnts, 0u);
+            if (gate_forks) hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[1], ctx->cl_flags + 12, epoch);
+            else HIP_TRY(ctx, hipEventRecord(ctx->cl_join[2], ctx->cl_side[1]));
+        }
     } else if (small) {
         hipLaunchKernelGGL(cl_tight_all, dim3(gridw), dim3(64), 0, st, p, lists, (const uint32_t *)cnts, over);
     } else {
@@ -2852,8 +3371,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     }
     // what they handed on
     if (tiers) hipLaunchKernelGGL(cl_tier2_all, dim3(std::min(gridw, 2048u)), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)over, small ? 1u : 0u);
-    if (!small) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[2], 0));
-    if (gate_forks) hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), epoch);
+    if (!small || (wide_list && !gate_forks)) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[2], 0));
+    if (gate_forks && wide_list) hipLaunchKernelGGL(cl_gate2, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), (const uint32_t *)(ctx->cl_flags + 12), epoch);
+    else if (gate_forks) hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), epoch);
     else HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
     // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
     launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate

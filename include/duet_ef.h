@@ -153,6 +153,9 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 #define DUET_DBG_EF_OWN_SMALLTAB 0x2000000u /* ... and their seed set in LDS holds 8 distinct seeds (default 2048): contigs with more take the array-free walk */
 #define DUET_DBG_CLUSTER_EVENT_FORKS 0x4000000u /* A0: the side streams fork off behind hipEventRecord / hipStreamWaitEvent (rounds 1-5) instead of a signal kernel on the
                                           * main stream and a gate kernel on the side stream (round 6) */
+#define DUET_DBG_CLUSTER_WIDE_OFF 0x8000000u /* A0: small inputs keep ONE wavefront per partition of more than 64 marks (rounds 1-5: cl_tight_big + cl_link_one) instead
+                                              * of a workgroup of eight (cl_find_big + cl_wide_big: wide_unit) */
+#define DUET_DBG_CLUSTER_WIDE_ALL 0x10000000u /* A0: small inputs send EVERY listed partition through the multi-wavefront units (cl_wide_list; tests: measured, they lose there) */
 #define DUET_DBG_CLUSTER_EXACT 0x100u
 #define DUET_DBG_CLUSTER_LARGE 0x200u   /* A0: take the launch structure of large inputs (> 4 M marks: one launch per size class,
                                            generic tile-offset scan in the sort, scans with a spine launch) whatever the size */

@@ -39,7 +39,11 @@ def check(ctx, marks, **kw):
                        (True, 0x20000), (False, 0x20200), (True, 0x21200),
                        (True, 0x40000), (False, 0x40000), (True, 0x40100), (True, 0x40800), (True, 0x44000), (True, 0x41000), (True, 0x42000), (True, 0x60000),
                        # DUET_DBG_CLUSTER_EVENT_FORKS = 0x4000000 (round 6): the side streams behind events instead of signal / gate kernels
-                       (True, 0x4000000), (False, 0x4040000), (True, 0x4002000)):
+                       (True, 0x4000000), (False, 0x4040000), (True, 0x4002000),
+                       # DUET_DBG_CLUSTER_WIDE_OFF = 0x8000000: small inputs keep one wavefront per partition of more than 32 marks (the default
+                       # since round 6: four, cl_wide_list / cl_wide_big); DUET_DBG_CLUSTER_WIDE_ALL = 0x10000000: every listed partition on four
+                       (True, 0x8000000), (False, 0x8000800), (True, 0x8000100), (True, 0xC000000), (True, 0x10000000), (False, 0x10000800),
+                       (True, 0x10000100), (True, 0x14000000), (False, 0x10040000), (True, 0x10040800)):
         ctx.set_debug(dbg)
         try:
             got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], hints=hints, **kw)

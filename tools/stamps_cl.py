@@ -17,7 +17,10 @@ TAGS = {0x10: 'fast: unit', 0x11: 'fast: rows in LDS', 0x12: 'fast: threshold gr
         0x20: 'link: start', 0x21: 'link: triangle filled', 0x22: 'link: tight groups merged', 0x23: 'link: round', 0x24: 'link: rounds over',
         0x30: 'tight: unit', 0x31: 'tight: rows in LDS', 0x32: 'tight: pair tests done', 0x33: 'tight: cliques at the threshold',
         0x34: 'tight: half / quarter levels done', 0x35: 'tight: their cliques', 0x36: 'tight: groups set up', 0x37: 'tight: cross-group sums done',
-        0x38: 'tight: round', 0x39: 'tight: rounds over', 0x3A: 'tight: before emit', 0x3B: 'tight: emitted'}
+        0x38: 'tight: round', 0x39: 'tight: rounds over', 0x3A: 'tight: before emit', 0x3B: 'tight: emitted',
+        0x40: 'wide: unit', 0x41: 'wide: rows in LDS', 0x42: 'wide: pair pass done', 0x43: 'wide: cliques known', 0x44: 'wide: tight groups contracted',
+        0x45: 'wide: round', 0x46: 'wide: rounds over', 0x47: 'wide: emitted', 0x48: 'wide: r scanned', 0x49: 'wide: r lanes met', 0x4A: 'wide: r nn known',
+        0x4B: 'wide: r merges known', 0x4C: 'wide: r contracted'}
 big = 'big' in sys.argv[1:]
 contigs = synth.bench_genome(20000000, 3) if big else [synth.bench_contig('1', 200000, 100000, 1)]
 soa0 = engine.soa_from_synth(contigs)
@@ -34,7 +37,7 @@ lib.duet_dbg_stamps(ctx.handle, 1, None)
 ds.run_fused(ctx, wait=True)
 buf = np.zeros(6 * 65536 * 8, dtype=np.uint64)
 lib.duet_dbg_stamps(ctx.handle, 0, buf.ctypes.data)
-for area, name in ((3, 'cl_tight_big'), (4, 'cl_fast_all (1.0 M marks) / cl_tight_one<64> (large inputs)'), (5, 'cl_link_one + cl_tight_one<32> (large inputs)')):
+for area, name in ((3, 'cl_wide_big / cl_tight_big'), (4, 'cl_fast_all (1.0 M marks) / cl_tight_one<64> (large inputs)'), (5, 'cl_wide_list / cl_link_one + cl_tight_one<32> (large inputs)')):
     log = buf[area * 65536 * 8:(area + 1) * 65536 * 8].reshape(8192, 64)[:, 2:]
     used = (log != 0).sum(axis=1)
     blocks = np.nonzero(used)[0]
@@ -62,7 +65,7 @@ for area, name in ((3, 'cl_tight_big'), (4, 'cl_fast_all (1.0 M marks) / cl_tigh
         prev = int(tim[b, 0]); rounds = []
         for i in range(used[b]):
             tg, t = int(tag[b, i]), int(tim[b, i])
-            if tg in (0x23, 0x38):
+            if tg in (0x23, 0x38, 0x45):
                 rounds.append((t - t0) / 100.0)
                 continue
             if rounds:

@@ -51,7 +51,7 @@ for i in range(n_cl):
     kw = dict(max_dist=[0.1, 0.3, 0.9, 1.5, 0.5, 0.7][rng.one(6)], part_gap=[10, 1000, 5000][rng.one(3)], part_max=[7, 100, 128][rng.one(3)])
     want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
     # (launch structures and paths in turn: default, everything through the exact linkage, large-input structure, no box test)
-    ctx.set_debug([0, 0x100, 0x200, 0x800, 0xA00, 0x300, 0x1000, 0x1800, 0x1A00, 0x2000, 0x3800, 0x4000, 0x8000, 0x10000, 0x10200, 0x4200, 0x40000, 0x20000, 0x20200, 0x200, 0x40100, 0x40800, 0x44000, 0x60000, 0x4000000, 0x4040000][i % 26])
+    ctx.set_debug([0, 0x100, 0x200, 0x800, 0xA00, 0x300, 0x1000, 0x1800, 0x1A00, 0x2000, 0x3800, 0x4000, 0x8000, 0x10000, 0x10200, 0x4200, 0x40000, 0x20000, 0x20200, 0x200, 0x40100, 0x40800, 0x44000, 0x60000, 0x4000000, 0x4040000, 0x8000000, 0x8000800, 0x10000000, 0x10000800, 0x14000000, 0x10040000][i % 32])
     got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'], **kw)
     ctx.set_debug(0)
     if any(got[f].shape != want[f].shape or not np.array_equal(got[f], want[f]) for f in FIELDS):
