@@ -2863,6 +2863,23 @@ __global__ void cl_gate(const uint32_t *flag, uint32_t epoch)
     }
 }
 
+// A kernel that waits for another queue's kernel needs the device to run the two side by side.  Where it takes ONE kernel at a time -- a profiler
+// collecting counters (rocprofv3 --pmc serialises the dispatches: round 6's last collection hung there), AMD_SERIALIZE_KERNEL, a debugger -- a gate at the
+// head of its queue can be picked before the kernel that opens it, deep in the other queue, and then waits for ever.  So a context tries it out
+// once, bounded, before its first gated run: two kernels on one side stream, then the gate at the head of ANOTHER (up to 20 ms), then the kernel that
+// opens it behind the first two.  Only a context that saw the gate open forks through gates; the others fork behind events.
+__global__ void cl_gate_try(const uint32_t *flag, uint32_t epoch, uint32_t *opened)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    uint32_t ok = 1;
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 2000000ull) { ok = 0; break; }
+    }
+    *opened = ok;
+}
+
 // (the join of two side streams in one launch)
 __global__ void cl_gate2(const uint32_t *flag_a, const uint32_t *flag_b, uint32_t epoch)
 {
@@ -3274,7 +3291,19 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // cl_box) -- except where cl_box itself numbers the partitions (large inputs: the chain is far from critical there).
     // (small inputs only: at 2e7 marks the forks' gaps are 15 of 2,100 us, and a side chain that starts 7 us earlier takes compute units
     // from the first tier's first launch -- measured: 2,187 against 2,127 us)
-    const bool gate_forks = small && !(ctx->dbg & DUET_DBG_CLUSTER_EVENT_FORKS);
+    if (small && ctx->cl_gates == 0) {
+        const uint32_t e0 = ++ctx->cl_epoch;
+        uint32_t opened = 0;
+        hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[1], ctx->cl_flags + 13, e0);
+        hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[1], ctx->cl_flags + 13, e0);
+        hipLaunchKernelGGL(cl_gate_try, dim3(1), dim3(64), 0, ctx->cl_side[0], (const uint32_t *)(ctx->cl_flags + 14), e0, ctx->cl_flags + 15);
+        hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[1], ctx->cl_flags + 14, e0);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->cl_side[1]));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->cl_side[0]));
+        HIP_TRY(ctx, hipMemcpy(&opened, ctx->cl_flags + 15, 4, hipMemcpyDeviceToHost));
+        ctx->cl_gates = opened ? 1 : -1;
+    }
+    const bool gate_forks = small && ctx->cl_gates > 0 && !(ctx->dbg & DUET_DBG_CLUSTER_EVENT_FORKS);
     const uint32_t epoch = ++ctx->cl_epoch;
     const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // small inputs: every partition of more than 64 marks on its own workgroup of eight wavefronts (wide_unit), on the side stream beside cl_box and

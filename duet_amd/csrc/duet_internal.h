@@ -54,6 +54,7 @@ struct duet_ctx {
     hipStream_t cl_side[3] = {nullptr, nullptr, nullptr};     // the size classes of A0 agglomerate side by side
     hipEvent_t cl_fork = nullptr, cl_join[3] = {nullptr, nullptr, nullptr};
     uint32_t *cl_flags = nullptr;                             // [16] device words: what the side streams' gate kernels wait for (stage A0's forks, round 6)
+    int cl_gates = 0;                                         // 0: not tried yet; 1: a gate on one stream sees a signal from another (the device runs them side by side); -1: it does not
     uint32_t cl_epoch = 0;                                    // ... the value the current run's forks write there
     // profiling events: 6 per run
     std::vector<hipEvent_t> ev_pool;

@@ -222,7 +222,11 @@ typedef struct duet_cluster_result {
 
 /* (Up to 4 M marks the stage's side-stream chains fork off and join through one-lane signal / gate kernels and a per-call epoch word
  * of the context, not through events -- an event record cost the main stream 7-14 us each.  Such a call cannot be captured into a
- * hipGraph: set DUET_DBG_CLUSTER_EVENT_FORKS with duet_ctx_set_debug for that; it also applies to duet_svim_phase_device.) */
+ * hipGraph: set DUET_DBG_CLUSTER_EVENT_FORKS with duet_ctx_set_debug for that; it also applies to duet_svim_phase_device.
+ * A gate waits for a kernel of another queue, which needs the device to run the two side by side: the first such call of a context
+ * tries that out once (three one-lane kernels on two internal streams, a bounded wait of at most 20 ms, two stream synchronisations)
+ * and a context on a device that takes one kernel at a time -- under a counter-collecting profiler, AMD_SERIALIZE_KERNEL -- forks
+ * behind events instead.) */
 DUET_API int duet_cluster_run_device(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res,
                             void *stream);
 DUET_API int duet_cluster_run_host(duet_ctx *ctx, const duet_cluster_problem *prob, const duet_cluster_result *res);

@@ -28,7 +28,7 @@ stats() {   # name, command...
 }
 pmc() {     # name, counter, command...
   name=$1; ctr=$2; shift; shift
-  timeout 900 rocprofv3 --pmc $ctr --output-format csv -d $P/${name}_$ctr -- "$@" > $P/${name}_$ctr.log 2>&1
+  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $P/${name}_$ctr -- "$@" > $P/${name}_$ctr.log 2>&1
   f=$(find $P/${name}_$ctr -name '*counter_collection.csv' | head -1)
   grep -E "Counter_Name|ef_classify|ef_seed_sort|ef_finalize" $f > $P/${name}_pmc_$ctr.csv 2>/dev/null
   cp $f /tmp/${T}_${name}_$ctr.csv
@@ -62,7 +62,7 @@ timeout 900 python3 tools/own_sweep.py 200 > $P/ef_two_launches_against_three_sw
 timeout 300 python3 tools/stamps.py cfg2 > $P/stamps_config2_two_launches.txt 2>&1
 timeout 300 python3 tools/stamps.py cfg2 3k > $P/stamps_config2_three_launches.txt 2>&1
 nproc > $P/e2e_host.txt; lscpu | grep -E "Model name|^CPU\(s\)" >> $P/e2e_host.txt
-DUET_E2E_QUIET=1 timeout 1500 python3 tools/e2e_time.py 2e7 4,8,16,32 > $P/e2e_time_2e7.txt 2>&1
+DUET_E2E_QUIET=1 timeout 900 python3 tools/e2e_time.py 2e7 4,8,16 > $P/e2e_time_2e7.txt 2>&1
 timeout 900 python3 tools/e2e_profile.py 8 2e7 > $P/e2e_profile_2e7_t8.txt 2>&1
 DUET_E2E_QUIET=1 timeout 300 python3 tools/e2e_time.py 0 1,2,4,8,16,32 > $P/e2e_time_config2.txt 2>&1
 tail -2 $O/${T}_tests.log; tail -3 $O/${T}_stress.log; ls $P | head -60; tail -1 $P/fused_config2_timeline.txt; tail -1 $P/fused_2e7_timeline.txt; grep -v amdgpu $P/ef_two_launches_against_three_sweep.txt; grep -v "duet_ingest\]\|^---\|amdgpu" $P/e2e_time_2e7.txt | tail -6; tail -2 $O/${T}_bench_default.err; head -c 3000 $O/${T}_bench_default.json
