@@ -1317,13 +1317,9 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
         uint32_t na_max = na;
 #pragma unroll
         for (int d = 32; d >= GROUP && d > 0; d >>= 1) na_max = max(na_max, (uint32_t)__shfl_xor((int)na_max, d, 64));
-        // (the list's next four ids and sizes are fetched while this step's four entries are: an entry waited for its list word, two
-        // dependent LDS trips per step)
-        uint32_t ks = *reinterpret_cast<const uint32_t *>(&X.alist[sub][0]), ns = *reinterpret_cast<const uint32_t *>(&X.asize[sub][0]);
         for (uint32_t t = 0; t < na_max; t += 4) {
-            const uint32_t tn = t + 4u < (uint32_t)NMAX ? t + 4u : 0u;
-            const uint32_t ks_next = *reinterpret_cast<const uint32_t *>(&X.alist[sub][tn]);
-            const uint32_t ns_next = *reinterpret_cast<const uint32_t *>(&X.asize[sub][tn]);
+            const uint32_t ks = *reinterpret_cast<const uint32_t *>(&X.alist[sub][t < NMAX ? t : 0u]);
+            const uint32_t ns = *reinterpret_cast<const uint32_t *>(&X.asize[sub][t < NMAX ? t : 0u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t k = (ks >> (8 * u)) & 0xFFu;
@@ -1343,8 +1339,6 @@ __device__ __forceinline__ void link_unit(const ClParams &p, bool go, uint32_t n
                     bk[r] = better ? k : bk[r];
                 }
             }
-            ks = ks_next;
-            ns = ns_next;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -2139,11 +2133,9 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
             double bs = kNothing, bn = 1.0;
             uint32_t bk = 0xFFu;
             const uint32_t nl_all = wave_max(nl);
-            uint32_t ks = *reinterpret_cast<const uint32_t *>(&S.alist[sub][0]), ns = *reinterpret_cast<const uint32_t *>(&S.asize[sub][0]);
             for (uint32_t t = 0; t < nl_all; t += 4) {
-                const uint32_t tn = t + 4u < (uint32_t)KC ? t + 4u : 0u;            // (the next step's list words leave with this step's entries)
-                const uint32_t ks_next = *reinterpret_cast<const uint32_t *>(&S.alist[sub][tn]);
-                const uint32_t ns_next = *reinterpret_cast<const uint32_t *>(&S.asize[sub][tn]);
+                const uint32_t ks = *reinterpret_cast<const uint32_t *>(&S.alist[sub][t < (uint32_t)KC ? t : 0u]);
+                const uint32_t ns = *reinterpret_cast<const uint32_t *>(&S.asize[sub][t < (uint32_t)KC ? t : 0u]);
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const uint32_t b = (ks >> (8 * w)) & 0xFFu;
@@ -2157,8 +2149,6 @@ __device__ __forceinline__ bool tight_unit(const ClParams &p, const WorkList &li
                     bn = better ? nk : bn;
                     bk = better ? b : bk;
                 }
-                ks = ks_next;
-                ns = ns_next;
             }
             const bool within = bs <= (double)kQOne * (bn * sizeA);
             bk = (aliveA && within) ? bk : 0xFFu;
