@@ -6,7 +6,7 @@
 // statement of the published SVIM 1.4.2 scheme, normative text in oracle/cluster_oracle.c / DESIGN.md section 9.
 //
 // Pipeline (DESIGN.md section 9 has the rule, the argument and the measurements):
-//   record sort    (round 4, from 1.5 M marks on; duet_recsort.hip.h) the 16-byte mark record travels with the key -- LSD passes
+//   record sort    (round 4, from 1.25 M marks on; duet_recsort.hip.h) the 16-byte mark record travels with the key -- LSD passes
 //                  over the key's top bits, the low bits ordered group by group --, so that everything behind the sort reads its
 //                  rows where they lie: no permutation, no gather.  Else:
 //   cl_keys        key = (contig, type, centre = pos + span/2) packed into the fewest bits, the mark index in the spare
@@ -3071,11 +3071,13 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     p.idx_packed = key_bits + bits_for(M - 1) <= 64 && !(ctx->dbg & DUET_DBG_CLUSTER_PAIRS);
     // The record travels with the key (duet_recsort.hip.h) when contig, type and mark index fit one word of it
     const uint32_t idx_bits = bits_for(M - 1);
-    // ... from 1.5 M marks on: below, every pass is launch-latency bound and 8-byte keys are the cheaper thing to move (measured
-    // on the fused pipeline: 1.0 M marks, one contig 0.277 ms with the key sort against 0.287; 2 M marks over 24 contigs 0.369
-    // against 0.316, 4 M 0.483 / 0.455, 8 M 0.946 / 0.869, 2e7 2.35 / 2.22); DUET_DBG_CLUSTER_RECSORT takes it at any size
+    // ... from 1.25 M marks on: below, every pass is launch-latency bound and 8-byte keys are the cheaper thing to move (measured
+    // on the fused pipeline, round 4: 1.0 M marks, one contig 0.277 ms with the key sort against 0.287; 2 M marks over 24 contigs 0.369
+    // against 0.316, 4 M 0.483 / 0.455, 8 M 0.946 / 0.869, 2e7 2.35 / 2.22; round 6, 24 contigs, key sort / record sort: 0.9 M 0.252 / 0.259,
+    // 1.1 M 0.253 / 0.253, 1.2 M 0.229 / 0.227, 1.3 M 0.283 / 0.249, 1.5 M 0.276 / 0.240 -- rounds 4-5 drew the line at 1.5 M);
+    // DUET_DBG_CLUSTER_RECSORT takes it at any size
     const bool rec_mode = contig_bits + p.type_bits + idx_bits <= 32u &&
-                          (M >= (3u << 19) || (ctx->dbg & (DUET_DBG_CLUSTER_RECSORT | DUET_DBG_CLUSTER_LARGE))) &&
+                          (M >= 1250000u || (ctx->dbg & (DUET_DBG_CLUSTER_RECSORT | DUET_DBG_CLUSTER_LARGE))) &&
                           !(ctx->dbg & (DUET_DBG_CLUSTER_PAIRS | DUET_DBG_CLUSTER_LSD | DUET_DBG_CLUSTER_KEYSORT));
     p.rec_mode = rec_mode ? 1u : 0u;
     p.idx_bits = idx_bits;

@@ -7,7 +7,7 @@
 // IS the sort element:
 //     x = pos, y = span, z = read index (fused pipeline; else 0), w = (contig << type_bits | type) << idx_bits | mark index
 // -- 16 bytes, and the key is a function of it (contig | type in w's high bits, centre = x + y / 2), so no key array exists
-// at all.  Taken from 1.5 M marks on (below, every pass is launch-latency bound and 8-byte keys are the cheaper thing to move)
+// at all.  Taken from 1.25 M marks on (below, every pass is launch-latency bound and 8-byte keys are the cheaper thing to move)
 // when contig, type and mark index fit w's 32 bits (2e7 marks over a genome: 5 + 1 + 25); everything else keeps the key-only
 // path.
 //

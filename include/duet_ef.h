@@ -163,7 +163,7 @@ DUET_API int duet_ef_profile_collect(duet_ctx *ctx, duet_ef_stats *stats);
 #define DUET_DBG_CLUSTER_NOBOX 0x800u   /* A0: no bounding-box test: every partition goes through the threshold-graph pair loops */
 #define DUET_DBG_CLUSTER_KEYSORT 0x10000u /* A0: the key-only sort of rounds 1-3 (8-byte keys, the records gathered through the permutation afterwards)
                                             also where the 16-byte mark record could travel with the key (duet_recsort.hip.h) */
-#define DUET_DBG_CLUSTER_RECSORT 0x40000u /* A0: the record sort also below 1.5 M marks (where the key-only sort is the default: launch-bound passes) */
+#define DUET_DBG_CLUSTER_RECSORT 0x40000u /* A0: the record sort also below 1.25 M marks (where the key-only sort is the default: launch-bound passes) */
 #define DUET_DBG_CLUSTER_NOSYM 0x20000u  /* A0: the contracted linkage's pair tests column by column (every ordered pair) also where a unit holds one partition and
                                             could evaluate every unordered pair once */
 #define DUET_DBG_CLUSTER_LSD 0x8000u     /* A0: plain LSD passes over all key bits also where small inputs would sort the low bits locally */

@@ -32,7 +32,7 @@ def check(ctx, marks, **kw):
     # DUET_DBG_CLUSTER_KEYSORT = 0x10000: the key-only sort of rounds 1-3 (+ the gather through the permutation) where the
     # default now carries the 16-byte record with the key; DUET_DBG_CLUSTER_NOSYM = 0x20000: the pair tests of one-partition units column
     # by column (every ordered pair) instead of every unordered pair once; DUET_DBG_CLUSTER_RECSORT = 0x40000: the record sort also
-    # below 1.5 M marks (the default there is the key-only sort; DUET_DBG_CLUSTER_LARGE implies it)
+    # below 1.25 M marks (the default there is the key-only sort; DUET_DBG_CLUSTER_LARGE implies it)
     for hints, dbg in ((True, 0), (False, 0), (True, 0x100), (True, 0x200), (True, 0x400), (False, 0x600), (True, 0x800),
                        (True, 0xA00), (True, 0x300), (True, 0x1000), (True, 0x1800), (False, 0x1A00), (True, 0x2000), (True, 0x3800), (True, 0x4000), (False, 0x8000),
                        (True, 0x10000), (False, 0x10200), (True, 0x14000), (False, 0x4200), (True, 0x10800),
@@ -223,9 +223,14 @@ def test_between_one_and_four_million_marks(ctx):
     marks = synth.raw_marks([synth.bench_contig('1', 300000, 150000, 11)], 11)
     assert 1400000 < len(marks['pos']) < 1600000
     want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'])
-    got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'])
-    for f in FIELDS:
-        assert np.array_equal(got[f], want[f]), f
+    for dbg in (0x10000, 0):             # DUET_DBG_CLUSTER_KEYSORT: the key-only sort this test was written for; 0: the record sort (the default from 1.25 M marks on)
+        ctx.set_debug(dbg)
+        try:
+            got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'])
+        finally:
+            ctx.set_debug(0)
+        for f in FIELDS:
+            assert np.array_equal(got[f], want[f]), (f, dbg)
 
 
 @pytest.mark.parametrize('M', [3, 200, 5000, 70000])

@@ -67,7 +67,7 @@ def fused_case(contigs, seed, waits, contig_ids=None, extra=0):
     ctx = _lib.Context(0)
     ds = DeviceSvim(marks, soa.read_tag, depth, depth_off, 1000, 50, 2)
     # with / without the host round trip; reruns reuse every workspace.  Small inputs sort 8-byte keys by default: every second
-    # run takes the record sort as well (DUET_DBG_CLUSTER_RECSORT = 0x40000; the default from 1.5 M marks on).  The device-planned
+    # run takes the record sort as well (DUET_DBG_CLUSTER_RECSORT = 0x40000; the default from 1.25 M marks on).  The device-planned
     # ef_finalize takes two tiles per workgroup from a bound of 8 M candidates on: the last run of a small case forces that
     # (DUET_DBG_EF_FIN_TPB2 = 0x20), and the wave-cooperative walk of ef_classify on every candidate (0x80000)
     for it, wait in enumerate(waits):
