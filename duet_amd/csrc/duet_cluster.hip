@@ -3310,7 +3310,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     const bool tiers = !small || (ctx->dbg & DUET_DBG_CLUSTER_TIERS);
     // small inputs: every partition of more than 64 marks on its own workgroup of eight wavefronts (wide_unit), on the side stream beside cl_box and
     // cl_fast_all; DUET_DBG_CLUSTER_WIDE_ALL: every listed partition on four wavefronts as well (tests)
-    const bool wide = !tiers && !(ctx->dbg & DUET_DBG_CLUSTER_WIDE_OFF);
+    // (up to 2 M marks: a wide unit holds 143 KB of LDS, i.e. a CU, for 50 us -- at 4 M marks the 80-odd of them take a third of the chip from
+    // cl_fast_all for that long and the pipeline is 1 % slower with them, 0.423 against 0.419 ms; level at 2 M)
+    const bool wide = !tiers && M <= (2u << 20) && !(ctx->dbg & DUET_DBG_CLUSTER_WIDE_OFF);
     const bool wide_all = wide && (ctx->dbg & DUET_DBG_CLUSTER_WIDE_ALL);
     // (measured, profiles/history/r06_wide_units.txt: for the listed partitions of up to 64 marks the four-wavefront units LOSE -- cl_fast_all is
     // bound by the chip's throughput there, not by a chain -- so only the partitions of more than 64 marks take them outside the tests)
