@@ -121,7 +121,8 @@ struct ClParams {
     uint4 *e_first;                                   // [P] cluster 0 of every partition, by partition number: most partitions have one cluster, and
                                                       // cl_emit reads these records side by side instead of one 16-byte record per line
     uint32_t *pc;                                     // [P] clusters per partition
-    const uint32_t *cbase;                            // [P] first candidate of each partition
+    const uint32_t *csum, *tsum;                      // clusters per 64 partitions / per 2048 (cl_pc_sums): cl_emit numbers the candidates from them
+    uint32_t *n_cands_w;                              // ... and leaves their number here
     // outputs
     uint32_t *order, *cand_off, *cand_pos, *cand_span;
     uint16_t *cand_contig;
@@ -258,17 +259,6 @@ __device__ __forceinline__ void load_head_bits(const uint8_t *hbits, uint32_t t0
     for (int j = 0; j < kScanItems; ++j) head[j] = (byte >> j) & 1u;
 }
 
-// clusters of partition i.  The partition count lives on the device: the scan is launched over the M positions (an upper
-// bound) and the elements past the count neither load nor store anything
-struct LoadPc {
-    const uint32_t *pc, *n_parts;
-    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return i < *n_parts ? pc[i] : 0u; }
-};
-struct StorePc {
-    uint32_t *out;
-    const uint32_t *n_parts;
-    __device__ __forceinline__ void operator()(uint32_t i, uint32_t v, uint32_t) const { if (i < *n_parts) out[i] = v; }
-};
 // ---------------------------------------------------------------------------------------------
 // partitions: ONE scan over a composite element instead of a max-scan + a sum-scan
 // ---------------------------------------------------------------------------------------------
@@ -2892,6 +2882,41 @@ __global__ void cl_gate2(const uint32_t *flag_a, const uint32_t *flag_b, uint32_
     }
 }
 
+// clusters per partition -> their sums over every 64 partitions and over every 2048: what cl_emit needs to number the candidates itself (rounds 1-5: a
+// generic exclusive scan in two launches, then cl_emit -- three launches, 5 us apiece at 1.0 M marks whatever they do).  gate (or null): the launch is also the
+// JOIN of the side stream -- every workgroup waits for the word the side stream's last kernel writes (cl_gate's bounded wait; one launch less on the main
+// stream, and at 1.0 M marks the side chain is through 25 us before this starts).
+__global__ __launch_bounds__(256) void cl_pc_sums(const uint32_t *pc, const uint32_t *n_parts_p, uint32_t *csum, uint32_t *tsum, const uint32_t *gate, uint32_t epoch)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_parts = *n_parts_p, base = blockIdx.x * 2048u;       // (the main stream's own: it leaves beside the gate's first load)
+    if (base >= n_parts) return;
+    if (gate) {
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while ((int32_t)(__hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > 200000000ull) __builtin_trap();
+            }
+        }
+        __syncthreads();
+    }
+    uint32_t tot = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t i = base + (wave * 8u + c) * 64u + lane;
+        uint32_t v = i < n_parts ? pc[i] : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        if (lane == 0) csum[blockIdx.x * 32u + wave * 8u + c] = v;
+        tot += v;
+    }
+    if (lane == 0) s_w[wave] = tot;
+    __syncthreads();
+    if (tid == 0) tsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
 __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) p.cand_off[0] = 0;
@@ -2900,15 +2925,36 @@ __global__ __launch_bounds__(256) void cl_emit(const ClParams p)
     // those behind it; the per-contig seed counts and the status words are zeroed here.  (A launch of its own for K + 1
     // binary searches cost 6 us at 1.0 M marks.)
     const bool plan = p.ef_ctg_off != nullptr;
-    const uint32_t n_cands = plan ? *p.n_cands : 0u;
     if (plan && blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < p.n_contigs + 8u; i += blockDim.x) p.ef_zero[i] = 0u;
     const uint32_t n_parts = *p.n_parts, lane = threadIdx.x & 63u;
+    // the candidates' number: every wave adds up the tiles' sums (a few hundred at 2e7 marks); the first one leaves it for step E/F
+    uint32_t n_cands = 0;
+    for (uint32_t i = lane, nt = (n_parts + 2047u) >> 11; i < nt; i += 64u) n_cands += p.tsum[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_cands += (uint32_t)__shfl_xor((int)n_cands, d, 64);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.n_cands_w = n_cands;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t b0 = wave * 64u; b0 < n_parts; b0 += n_waves * 64u) {
         const uint32_t part = b0 + lane;
         const bool has = part < n_parts;
-        const uint32_t s = has ? p.part_start[part] : 0u, nc = has ? p.pc[part] : 0u, c0 = has ? p.cbase[part] : 0u;
+        const uint32_t s = has ? p.part_start[part] : 0u, nc = has ? p.pc[part] : 0u;
+        // the first candidate of every partition of the wave: the tiles in front, the 64s in front within the tile, the lanes in front
+        uint32_t c0;
+        {
+            const uint32_t tile = b0 >> 11, cin = (b0 >> 6) & 31u;
+            uint32_t acc = lane < cin ? p.csum[(tile << 5) + lane] : 0u;
+            for (uint32_t i = lane; i < tile; i += 64u) acc += p.tsum[i];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
+            uint32_t x = nc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
+                if ((int)lane >= d) x += y;
+            }
+            c0 = acc + x - nc;
+        }
         uint32_t hi = 0;                                        // contig | type: in the cluster records (record sort), else from the sorted key
         if (has && !p.rec_mode) hi = (uint32_t)((p.skeys[s] & key_mask(p.key_bits)) >> p.centre_bits);
         // (the plan: the contig of the partition in front of the wave's first one, through lane 0)
@@ -3406,11 +3452,14 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     if (tiers) hipLaunchKernelGGL(cl_tier2_all, dim3(std::min(gridw, 2048u)), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)over, small ? 1u : 0u);
     if (!small || (wide_list && !gate_forks)) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[2], 0));
     if (gate_forks && wide_list) hipLaunchKernelGGL(cl_gate2, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), (const uint32_t *)(ctx->cl_flags + 12), epoch);
-    else if (gate_forks) hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), epoch);
-    else HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
-    // clusters per partition -> candidate bases (a scan over the partitions; see LoadPc about their count)
-    launch_scan<0>(LoadPc{pc, scal}, M, spart, StorePc{cbase, scal}, res->n_cands, st, nullptr, big_sort, scal);       // cbase[part] = its first candidate
-    p.cbase = cbase;
+    else if (!gate_forks) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
+    // clusters per partition -> their sums per 64 and per 2048 partitions (cl_emit numbers the candidates from them); with gate forks the launch is
+    // also the join of the side stream
+    hipLaunchKernelGGL(cl_pc_sums, dim3((M + 2047u) / 2048u), dim3(256), 0, st, (const uint32_t *)pc, (const uint32_t *)scal, cbase, spart,
+                       (gate_forks && !wide_list) ? (const uint32_t *)(ctx->cl_flags + 4) : (const uint32_t *)nullptr, epoch);
+    p.csum = cbase;
+    p.tsum = spart;
+    p.n_cands_w = res->n_cands;
     p.n_cands = res->n_cands;
     hipLaunchKernelGGL(cl_emit, dim3(std::min((M + 16383u) / 16384u * 8u, 4096u)), b256, 0, st, p);        // (a wave per 64 partitions, striding)
     HIP_TRY(ctx, hipGetLastError());

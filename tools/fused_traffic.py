@@ -35,7 +35,7 @@ pipeline = [k for k in ft if k.split('<')[0] in ('rs_hist', 'rs_hist_dig', 'rs_o
                                                   'cl_link_one', 'cl_fast_all', 'cl_tight_all', 'cl_tight_one', 'cl_tier2_one', 'cl_tier2_all',
                                                   'scan_reduce', 'scan_spine', 'scan_apply', 'cl_emit', 'plan_device_contigs', 'ef_classify',
                                                   'ef_seed_sort', 'ef_finalize', 'cl_keys', 'rx_hist', 'rx_offsets', 'rx_scatter', 'cl_find_big', 'cl_wide_big', 'cl_wide_list', 'cl_signal',
-                                                  'cl_gate', 'cl_gate2')]
+                                                  'cl_gate', 'cl_gate2', 'cl_pc_sums')]
 def runs_of(c):       # one first-pass histogram (record sort) or one cl_keys (key-only sort) per run
     first = [v for k, v in c.items() if k.startswith('rs_hist<true')]
     return max(1, first[0] if first else c.get('cl_keys', 1))
