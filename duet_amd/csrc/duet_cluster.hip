@@ -3451,12 +3451,16 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
     // what they handed on
     if (tiers) hipLaunchKernelGGL(cl_tier2_all, dim3(std::min(gridw, 2048u)), dim3(64), 0, st, p, (const uint32_t *)lists, (const uint32_t *)over, small ? 1u : 0u);
     if (!small || (wide_list && !gate_forks)) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[2], 0));
+    // (the join inside cl_pc_sums: its waiting workgroups hold wave slots -- up to M / 2048 workgroups of four wavefronts when every mark is a partition of its
+    // own -- so only up to 2 M marks, where they cannot take more than half of the chip's from the side stream's kernels; beyond, a one-lane gate kernel)
+    const bool join_in_sums = gate_forks && !wide_list && M <= (2u << 20);
     if (gate_forks && wide_list) hipLaunchKernelGGL(cl_gate2, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), (const uint32_t *)(ctx->cl_flags + 12), epoch);
+    else if (gate_forks && !join_in_sums) hipLaunchKernelGGL(cl_gate, dim3(1), dim3(64), 0, st, (const uint32_t *)(ctx->cl_flags + 4), epoch);
     else if (!gate_forks) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->cl_join[0], 0));
     // clusters per partition -> their sums per 64 and per 2048 partitions (cl_emit numbers the candidates from them); with gate forks the launch is
     // also the join of the side stream
     hipLaunchKernelGGL(cl_pc_sums, dim3((M + 2047u) / 2048u), dim3(256), 0, st, (const uint32_t *)pc, (const uint32_t *)scal, cbase, spart,
-                       (gate_forks && !wide_list) ? (const uint32_t *)(ctx->cl_flags + 4) : (const uint32_t *)nullptr, epoch);
+                       join_in_sums ? (const uint32_t *)(ctx->cl_flags + 4) : (const uint32_t *)nullptr, epoch);
     p.csum = cbase;
     p.tsum = spart;
     p.n_cands_w = res->n_cands;
