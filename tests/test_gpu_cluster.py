@@ -233,6 +233,18 @@ def test_between_one_and_four_million_marks(ctx):
             assert np.array_equal(got[f], want[f]), (f, dbg)
 
 
+def test_between_two_and_four_million_marks(ctx):
+    """2.3 M marks: still a small input (gate forks, one launch for the classes up to 64 marks), but beyond the sizes at which the partitions of
+    more than 64 marks take the wide units and the side stream's join sits inside cl_pc_sums (2 M marks): cl_tight_big + cl_link_one behind a
+    gate, a gate kernel of its own in front of cl_pc_sums."""
+    marks = synth.raw_marks([synth.bench_contig('1', 460000, 230000, 13)], 13)
+    assert 2200000 < len(marks['pos']) < 2500000
+    want = c_oracle.cluster(marks['contig'], marks['type'], marks['pos'], marks['span'])
+    got = ctx.cluster_host(marks['contig'], marks['type'], marks['pos'], marks['span'])
+    for f in FIELDS:
+        assert np.array_equal(got[f], want[f]), f
+
+
 @pytest.mark.parametrize('M', [3, 200, 5000, 70000])
 def test_wide_keys_few_marks(ctx, M):
     """Positions next to 2^32 with contig ids next to 65535 and many types: 33 + 16 + 8 = 57 key bits.  With few marks the
