@@ -3346,9 +3346,9 @@ int cluster_run(duet_ctx *ctx, const duet_cluster_problem *pr, const duet_cluste
         hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[1], ctx->cl_flags + 13, e0);
         hipLaunchKernelGGL(cl_gate_try, dim3(1), dim3(64), 0, ctx->cl_side[0], (const uint32_t *)(ctx->cl_flags + 14), e0, ctx->cl_flags + 15);
         hipLaunchKernelGGL(cl_signal, dim3(1), dim3(64), 0, ctx->cl_side[1], ctx->cl_flags + 14, e0);
+        HIP_TRY(ctx, hipMemcpyAsync(&opened, ctx->cl_flags + 15, 4, hipMemcpyDeviceToHost, ctx->cl_side[0]));     // (not the null stream: it would wait for the caller's)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->cl_side[1]));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->cl_side[0]));
-        HIP_TRY(ctx, hipMemcpy(&opened, ctx->cl_flags + 15, 4, hipMemcpyDeviceToHost));
         ctx->cl_gates = opened ? 1 : -1;
     }
     const bool gate_forks = small && ctx->cl_gates > 0 && !(ctx->dbg & DUET_DBG_CLUSTER_EVENT_FORKS);
